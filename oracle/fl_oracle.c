@@ -1,0 +1,79 @@
+/*
+ * fl_oracle.c -- CPU oracle for the FastLanes 1024-value codec hot path.
+ * TEST INFRASTRUCTURE ONLY; see fl_oracle.h for scope and parity status.
+ * Restates /root/reference/src/{lib,macros,bitpacking,delta,ffor,transpose}.rs
+ * (each function cites the lines it follows).  No reference source is copied:
+ * the Rust macros are re-expressed as plain C loops.
+ */
+#include "fl_oracle.h"
+#include <pthread.h>
+
+/* lib.rs:22 */
+const unsigned fl_oracle_FL_ORDER[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+
+/* macros.rs:20-24 (duplicated at :46-50 and :112-116) */
+unsigned fl_oracle_index(unsigned row, unsigned lane)
+{
+    unsigned o = row / 8;
+    unsigned s = row % 8;
+    return fl_oracle_FL_ORDER[o] * 16 + s * 128 + lane;
+}
+
+/* transpose.rs:29-36 */
+unsigned fl_oracle_transpose_index(unsigned idx)
+{
+    unsigned lane = idx % 16;
+    unsigned order = (idx / 16) % 8;
+    unsigned row = idx / 128;
+    return lane * 64 + fl_oracle_FL_ORDER[order] * 8 + row;
+}
+
+/* What the spliced unpack! body does with each (idx, elem). */
+enum { FL_BODY_STORE = 0, FL_BODY_ADD_REF = 1, FL_BODY_UNDELTA = 2 };
+
+#define T_ uint8_t
+#define S_ u8
+#define TB_ 8u
+#define LN_ 128u
+#define FL_FAST_LIST_ FL_FAST_(0, 3) FL_FAST_(1, 3)
+#include "fl_oracle_impl.inc"
+#undef T_
+#undef S_
+#undef TB_
+#undef LN_
+#undef FL_FAST_LIST_
+
+#define T_ uint16_t
+#define S_ u16
+#define TB_ 16u
+#define LN_ 64u
+/* benches/bitpacking.rs (W=3), benches/delta.rs (W=9 fused undelta) */
+#define FL_FAST_LIST_ FL_FAST_(0, 3) FL_FAST_(1, 3) FL_FAST_(3, 9)
+#include "fl_oracle_impl.inc"
+#undef T_
+#undef S_
+#undef TB_
+#undef LN_
+#undef FL_FAST_LIST_
+
+#define T_ uint32_t
+#define S_ u32
+#define TB_ 32u
+#define LN_ 32u
+/* BASELINE.json configs 2 and 4 (+ W=10 of bitpacking.rs:248-256) */
+#define FL_FAST_LIST_ FL_FAST_(0, 7) FL_FAST_(1, 7) FL_FAST_(2, 7) FL_FAST_(1, 10) \
+    FL_FAST_(0, 12) FL_FAST_(1, 12) FL_FAST_(3, 12)
+#include "fl_oracle_impl.inc"
+#undef T_
+#undef S_
+#undef TB_
+#undef LN_
+#undef FL_FAST_LIST_
+
+#define T_ uint64_t
+#define S_ u64
+#define TB_ 64u
+#define LN_ 16u
+/* BASELINE.json config 3 */
+#define FL_FAST_LIST_ FL_FAST_(0, 17) FL_FAST_(1, 17)
+#include "fl_oracle_impl.inc"
