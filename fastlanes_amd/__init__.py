@@ -1,0 +1,13 @@
+"""fastlanes_amd -- MI355X-native FastLanes codec hot path (pack / unpack /
+FoR / Delta / transpose of 1024-value blocks) behind the reference's trait
+names.  The compute lives in libfastlanes_amd.so (hand-written gfx950 HIP
+kernels, C ABI in include/fastlanes_amd.h); this package is the thin host-side
+mirror of the reference interface.  No CPU fallback exists."""
+from ._lib import LIB_PATH, exported_symbols, load  # noqa: F401
+from .codec import (BitPacking, Delta, FastLanesError, FoR, Transpose,  # noqa: F401
+                    packed_len)
+
+FL_ORDER = (0, 4, 2, 6, 1, 5, 3, 7)  # lib.rs:22
+
+__all__ = ["BitPacking", "FoR", "Delta", "Transpose", "FastLanesError", "packed_len",
+           "FL_ORDER", "load", "exported_symbols", "LIB_PATH"]

@@ -1,0 +1,86 @@
+"""ctypes loader for libfastlanes_amd.so (the C ABI of include/fastlanes_amd.h).
+
+There is no fallback: if the HIP library is missing or fails to load, importing
+the codec raises.  Nothing here (or anywhere in this package) touches oracle/.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfastlanes_amd.so")
+
+TYPES = ("u8", "u16", "u32", "u64")
+CTYPE = {"u8": ctypes.c_uint8, "u16": ctypes.c_uint16, "u32": ctypes.c_uint32, "u64": ctypes.c_uint64}
+BITS = {"u8": 8, "u16": 16, "u32": 32, "u64": 64}
+
+# method -> (device-tier argtypes builder, host-tier argtypes builder); P = void*
+_P = ctypes.c_void_p
+_U = ctypes.c_uint
+_Z = ctypes.c_size_t
+_Q = ctypes.c_uint64
+
+
+def _signatures(ty):
+    c = CTYPE[ty]
+    dev = {
+        "pack": [_U, _P, _P, _Z, _P],
+        "unpack": [_U, _P, _P, _Z, _P],
+        "unpack_single": [_U, _P, _Z, _P, _Z, _P, _P, _P],
+        "for_pack": [_U, _P, _P, _Z, _P, _Z, _P],
+        "unfor_pack": [_U, _P, _P, _Z, _P, _Z, _P],
+        "delta": [_P, _P, _P, _Z, _P],
+        "undelta": [_P, _P, _P, _Z, _P],
+        "undelta_pack": [_U, _P, _P, _P, _Z, _P],
+        "transpose": [_P, _P, _Z, _P],
+        "untranspose": [_P, _P, _Z, _P],
+    }
+    host = {
+        "pack_host": [_U, _P, _P, _Z],
+        "unpack_host": [_U, _P, _P, _Z],
+        "unpack_single_host": [_U, _P, _Z, _Q, _P],
+        "for_pack_host": [_U, _P, c, _P, _Z],
+        "unfor_pack_host": [_U, _P, c, _P, _Z],
+        "delta_host": [_P, _P, _P, _Z],
+        "undelta_host": [_P, _P, _P, _Z],
+        "undelta_pack_host": [_U, _P, _P, _P, _Z],
+        "transpose_host": [_P, _P, _Z],
+        "untranspose_host": [_P, _P, _Z],
+    }
+    dev.update(host)
+    return dev
+
+
+def exported_symbols():
+    """Every symbol include/fastlanes_amd.h declares."""
+    names = ["fl_version", "fl_status_string", "fl_last_hip_error", "fl_packed_len"]
+    for ty in TYPES:
+        names += [f"fl_{ty}_{m}" for m in _signatures(ty)]
+    return names
+
+
+_LIB = None
+
+
+def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C fastlanes_amd/csrc). "
+            "fastlanes_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.fl_version.restype = ctypes.c_char_p
+    lib.fl_status_string.restype = ctypes.c_char_p
+    lib.fl_status_string.argtypes = [ctypes.c_int]
+    lib.fl_last_hip_error.restype = ctypes.c_int
+    lib.fl_packed_len.restype = ctypes.c_size_t
+    lib.fl_packed_len.argtypes = [_U, _U]
+    for ty in TYPES:
+        for m, argtypes in _signatures(ty).items():
+            fn = getattr(lib, f"fl_{ty}_{m}")
+            fn.restype = ctypes.c_int
+            fn.argtypes = argtypes
+    _LIB = lib
+    return lib

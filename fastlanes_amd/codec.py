@@ -1,0 +1,303 @@
+"""Host-side mirror of the reference's codec traits over the C ABI.
+
+The reference (a Rust crate; no Rust toolchain in this image) exposes static
+trait methods per element type:
+
+    BitPacking::{pack::<W>, unpack::<W>, unpack_single::<W>, unchecked_pack,
+                 unchecked_unpack, unchecked_unpack_single}   (bitpacking.rs:16-59)
+    FoR::{for_pack::<W>, unfor_pack::<W>}                     (ffor.rs:4-18)
+    Delta::{delta, undelta, undelta_pack::<W>}                (delta.rs:6-17)
+    Transpose::{transpose, untranspose}                       (transpose.rs:4-7)
+
+This module keeps those names and argument meanings.  The element type is taken
+from the array dtype (u8/u16/u32/u64 by item size), the const generic W becomes
+the runtime `width` argument (as in the reference's own `unchecked_*` methods),
+and every method is batched over `n_blocks = len(input) / block_len` contiguous
+1024-value blocks (n_blocks = 1 is exactly one trait call).
+
+* torch CUDA tensors  -> device tier (asynchronous on the current HIP stream)
+* numpy arrays        -> host tier   (staged through device memory, synchronous)
+
+Errors follow the reference: width > T and index >= 1024 are panics there
+(bitpacking.rs:93,126,152,197) and raise FastLanesError here.  There is no CPU
+implementation behind any of these calls.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+_NP = {1: "u8", 2: "u16", 4: "u32", 8: "u64"}
+_NP_DTYPE = {"u8": np.uint8, "u16": np.uint16, "u32": np.uint32, "u64": np.uint64}
+
+
+class FastLanesError(RuntimeError):
+    def __init__(self, status, where):
+        lib = _lib.load()
+        msg = lib.fl_status_string(status).decode()
+        if status == 5:
+            msg += f" (hipError_t {lib.fl_last_hip_error()})"
+        super().__init__(f"{where}: {msg}")
+        self.status = status
+
+
+def packed_len(ty, width):
+    """bitpacking.rs:77: elements per packed block = 1024 * W / T."""
+    return 1024 * width // _lib.BITS[ty]
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _ty_of(x):
+    if _is_torch(x):
+        return _NP[x.element_size()]
+    return _NP[np.asarray(x).dtype.itemsize]
+
+
+def _check(rc, where):
+    if rc != 0:
+        raise FastLanesError(rc, where)
+
+
+class _Arg:
+    """Uniform view of a numpy array or a torch CUDA tensor."""
+
+    def __init__(self, x, ty=None):
+        self.torch = _is_torch(x)
+        if self.torch:
+            if not x.is_cuda:
+                raise TypeError("torch tensors must live on the GPU (use numpy arrays for the host tier)")
+            if not x.is_contiguous():
+                raise ValueError("tensor must be contiguous")
+            self.x = x
+            self.n = x.numel()
+            self.ptr = x.data_ptr()
+        else:
+            a = np.ascontiguousarray(x)
+            if ty is not None and a.dtype != _NP_DTYPE[ty]:
+                a = a.astype(_NP_DTYPE[ty])
+            self.x = a
+            self.n = a.size
+            self.ptr = a.ctypes.data
+        self.ty = ty or _ty_of(x)
+
+
+def _empty_like(arg, n, ty):
+    if arg.torch:
+        import torch
+        return torch.empty(n, dtype=arg.x.dtype, device=arg.x.device)
+    return np.empty(n, dtype=_NP_DTYPE[ty])
+
+
+def _stream(arg):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(arg.x.device).cuda_stream)
+
+
+def _run(method, ty, width, src, out, n_blocks, aux=None, aux_stride=None, scalar=None):
+    """Dispatch to fl_<ty>_<method>[_host]."""
+    lib = _lib.load()
+    dev = src.torch
+    fn = getattr(lib, f"fl_{ty}_{method}" + ("" if dev else "_host"))
+    args = []
+    if width is not None:
+        args.append(width)
+    args.append(src.ptr)
+    if method in ("for_pack", "unfor_pack"):
+        if dev:
+            args += [aux.ptr, aux_stride]
+        else:
+            args.append(scalar)
+    elif aux is not None:
+        args.append(aux.ptr)
+    args += [out.ptr, n_blocks]
+    if dev:
+        import torch
+        with torch.cuda.device(src.x.device):
+            args.append(_stream(src))
+            rc = fn(*args)
+    else:
+        rc = fn(*args)
+    _check(rc, f"fl_{ty}_{method}")
+    return out.x
+
+
+def _blocks(n, per_block, what):
+    if per_block == 0:
+        return None
+    if n % per_block:
+        raise ValueError(f"{what}: length {n} is not a multiple of {per_block}")
+    return n // per_block
+
+
+class BitPacking:
+    """bitpacking.rs:16-59"""
+
+    @staticmethod
+    def pack(width, input, output=None):
+        """BitPacking::pack::<W> / unchecked_pack (bitpacking.rs:19,30,65-96)."""
+        src = _Arg(input)
+        ty = src.ty
+        if width > _lib.BITS[ty]:
+            raise FastLanesError(1, f"fl_{ty}_pack")
+        n = _blocks(src.n, 1024, "pack input")
+        out = _Arg(output, ty) if output is not None else _Arg(_empty_like(src, n * packed_len(ty, width), ty), ty)
+        if out.n != n * packed_len(ty, width):
+            raise ValueError("Output buffer must be of size 1024 * W / T per block")  # bitpacking.rs:78
+        return _run("pack", ty, width, src, out, n)
+
+    unchecked_pack = pack
+
+    @staticmethod
+    def unpack(width, input, output=None, n_blocks=None):
+        """BitPacking::unpack::<W> / unchecked_unpack (bitpacking.rs:33,44,98-129).
+        n_blocks is only needed for width == 0 (the packed input is empty)."""
+        src = _Arg(input)
+        ty = src.ty
+        if width > _lib.BITS[ty]:
+            raise FastLanesError(1, f"fl_{ty}_unpack")
+        n = _blocks(src.n, packed_len(ty, width), "unpack input")
+        if n is None:
+            n = n_blocks if n_blocks is not None else (_Arg(output, ty).n // 1024 if output is not None else 0)
+        out = _Arg(output, ty) if output is not None else _Arg(_empty_like(src, n * 1024, ty), ty)
+        if out.n != n * 1024:
+            raise ValueError("Output buffer must be of size 1024 per block")  # bitpacking.rs:112
+        return _run("unpack", ty, width, src, out, n)
+
+    unchecked_unpack = unpack
+
+    @staticmethod
+    def unpack_single(width, packed, index, n_blocks=None):
+        """BitPacking::unpack_single::<W> / unchecked_unpack_single (bitpacking.rs:47,58,132-200).
+        `index` is an int (host tier: returns an int) or, on the device tier, a CUDA int64/uint64
+        tensor of column-global element indices (block*1024 + i): returns a tensor of values."""
+        lib = _lib.load()
+        src = _Arg(packed)
+        ty = src.ty
+        if width > _lib.BITS[ty]:
+            raise FastLanesError(1, f"fl_{ty}_unpack_single")
+        pl = packed_len(ty, width)
+        nb = n_blocks if n_blocks is not None else (src.n // pl if pl else 1)
+        if not src.torch:
+            val = _lib.CTYPE[ty](0)
+            rc = getattr(lib, f"fl_{ty}_unpack_single_host")(width, src.ptr, nb, int(index), ctypes.byref(val))
+            _check(rc, f"fl_{ty}_unpack_single")
+            return val.value
+        import torch
+        idx = index if _is_torch(index) else torch.as_tensor(np.asarray(index, dtype=np.int64).reshape(-1), device=src.x.device)
+        idx = idx.contiguous()
+        assert idx.element_size() == 8
+        out = torch.empty(idx.numel(), dtype=src.x.dtype, device=src.x.device)
+        err = torch.zeros(1, dtype=torch.int32, device=src.x.device)
+        with torch.cuda.device(src.x.device):
+            rc = getattr(lib, f"fl_{ty}_unpack_single")(width, src.ptr, nb, idx.data_ptr(), idx.numel(),
+                                                        out.data_ptr(), err.data_ptr(), _stream(src))
+        _check(rc, f"fl_{ty}_unpack_single")
+        if int(err.item()) != 0:
+            raise FastLanesError(2, f"fl_{ty}_unpack_single")  # bitpacking.rs:152
+        return out
+
+    unchecked_unpack_single = unpack_single
+
+
+class FoR:
+    """ffor.rs:4-18.  `reference` is a scalar, or (device tier) a per-block CUDA tensor."""
+
+    @staticmethod
+    def _ref(src, ty, reference, n):
+        if not src.torch:
+            return None, None, _lib.CTYPE[ty](int(reference) & ((1 << _lib.BITS[ty]) - 1))
+        import torch
+        if _is_torch(reference):
+            r = _Arg(reference.contiguous(), ty)
+            if r.n not in (1, n):
+                raise ValueError("references must hold 1 or n_blocks elements")
+            return r, (0 if r.n == 1 else 1), None
+        host = np.array([int(reference) & ((1 << _lib.BITS[ty]) - 1)], dtype=_NP_DTYPE[ty])
+        r = torch.from_numpy(host.view(np.uint8)).to(src.x.device).view(src.x.dtype)
+        return _Arg(r, ty), 0, None
+
+    @staticmethod
+    def for_pack(width, input, reference, output=None):
+        """FoR::for_pack::<W> (ffor.rs:5-9,24-36)."""
+        src = _Arg(input)
+        ty = src.ty
+        if width > _lib.BITS[ty]:
+            raise FastLanesError(1, f"fl_{ty}_for_pack")
+        n = _blocks(src.n, 1024, "for_pack input")
+        out = _Arg(output, ty) if output is not None else _Arg(_empty_like(src, n * packed_len(ty, width), ty), ty)
+        aux, stride, scalar = FoR._ref(src, ty, reference, n)
+        return _run("for_pack", ty, width, src, out, n, aux=aux, aux_stride=stride, scalar=scalar)
+
+    @staticmethod
+    def unfor_pack(width, input, reference, output=None, n_blocks=None):
+        """FoR::unfor_pack::<W> (ffor.rs:11-17,38-50)."""
+        src = _Arg(input)
+        ty = src.ty
+        if width > _lib.BITS[ty]:
+            raise FastLanesError(1, f"fl_{ty}_unfor_pack")
+        n = _blocks(src.n, packed_len(ty, width), "unfor_pack input")
+        if n is None:
+            n = n_blocks if n_blocks is not None else 0
+        out = _Arg(output, ty) if output is not None else _Arg(_empty_like(src, n * 1024, ty), ty)
+        aux, stride, scalar = FoR._ref(src, ty, reference, n)
+        return _run("unfor_pack", ty, width, src, out, n, aux=aux, aux_stride=stride, scalar=scalar)
+
+
+class Delta:
+    """delta.rs:6-17.  `base` holds LANES = 1024/T elements per block."""
+
+    @staticmethod
+    def _go(method, width, input, base, output, per_block, n_blocks=None):
+        src = _Arg(input)
+        ty = src.ty
+        if width is not None and width > _lib.BITS[ty]:
+            raise FastLanesError(1, f"fl_{ty}_{method}")
+        n = _blocks(src.n, per_block(ty), f"{method} input")
+        b = _Arg(base, ty)
+        if n is None:
+            n = n_blocks if n_blocks is not None else b.n // (1024 // _lib.BITS[ty])
+        if b.n != n * (1024 // _lib.BITS[ty]):
+            raise ValueError("base must hold LANES elements per block")
+        out = _Arg(output, ty) if output is not None else _Arg(_empty_like(src, n * 1024, ty), ty)
+        return _run(method, ty, width, src, out, n, aux=b)
+
+    @staticmethod
+    def delta(input, base, output=None):
+        """Delta::delta (delta.rs:7,24-33)."""
+        return Delta._go("delta", None, input, base, output, lambda ty: 1024)
+
+    @staticmethod
+    def undelta(input, base, output=None):
+        """Delta::undelta (delta.rs:9,36-45)."""
+        return Delta._go("undelta", None, input, base, output, lambda ty: 1024)
+
+    @staticmethod
+    def undelta_pack(width, input, base, output=None):
+        """Delta::undelta_pack::<W> (delta.rs:11-16,47-63); output is in transposed order."""
+        return Delta._go("undelta_pack", width, input, base, output, lambda ty: packed_len(ty, width))
+
+
+class Transpose:
+    """transpose.rs:4-7"""
+
+    @staticmethod
+    def _go(method, input, output):
+        src = _Arg(input)
+        ty = src.ty
+        n = _blocks(src.n, 1024, f"{method} input")
+        out = _Arg(output, ty) if output is not None else _Arg(_empty_like(src, n * 1024, ty), ty)
+        return _run(method, ty, None, src, out, n)
+
+    @staticmethod
+    def transpose(input, output=None):
+        """Transpose::transpose (transpose.rs:5,11-15)."""
+        return Transpose._go("transpose", input, output)
+
+    @staticmethod
+    def untranspose(input, output=None):
+        """Transpose::untranspose (transpose.rs:6,17-22)."""
+        return Transpose._go("untranspose", input, output)

@@ -1,0 +1,233 @@
+// fl_capi.hip -- the extern "C" boundary declared in include/fastlanes_amd.h.
+// Validates arguments, maps the runtime width to the per-(T,W) kernel instance
+// (the reference's `match width`, bitpacking.rs:82-95) and launches it.  No CPU
+// compute path exists in this library: every entry point ends in a HIP launch.
+#include "../../include/fastlanes_amd.h"
+#include "fl_kernels.hpp"
+#include "fl_misc.hpp"
+
+namespace {
+
+using namespace fl;
+
+thread_local int g_last_hip_error = 0;
+
+inline int hip_fail(hipError_t e)
+{
+    g_last_hip_error = (int)e;
+    return FL_ERR_HIP;
+}
+
+inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
+
+template <typename T>
+int run_stream(stream_launch_t fn, const T* in, T* out, const void* aux, size_t aux_stride,
+               size_t n_blocks, bool need_in, bool need_out, bool need_aux, void* stream)
+{
+    if (n_blocks == 0) return FL_OK;
+    if ((need_in && !in) || (need_out && !out) || (need_aux && !aux)) return FL_ERR_NULL;
+    if (misaligned(in) || misaligned(out)) return FL_ERR_ALIGN;
+    StreamArgs a;
+    a.in = reinterpret_cast<const u32x4*>(in);
+    a.out = reinterpret_cast<u32x4*>(out);
+    a.aux = aux;
+    a.aux_stride = aux_stride;
+    a.n_blocks = n_blocks;
+    hipError_t e = fn(a, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? FL_OK : hip_fail(e);
+}
+
+template <typename T> int dev_pack(unsigned w, const T* in, T* out, size_t n, void* s)
+{
+    if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
+    return run_stream<T>(pack_table_impl<T, false>().fn[w], in, out, nullptr, 0, n, true, w != 0, false, s);
+}
+template <typename T> int dev_unpack(unsigned w, const T* in, T* out, size_t n, void* s)
+{
+    if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
+    return run_stream<T>(unpack_table_impl<T, BODY_STORE>().fn[w], in, out, nullptr, 0, n, w != 0, true, false, s);
+}
+template <typename T>
+int dev_for_pack(unsigned w, const T* in, const T* refs, size_t stride, T* out, size_t n, void* s)
+{
+    if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
+    return run_stream<T>(pack_table_impl<T, true>().fn[w], in, out, refs, stride ? 1 : 0, n, true, w != 0, true, s);
+}
+template <typename T>
+int dev_unfor_pack(unsigned w, const T* in, const T* refs, size_t stride, T* out, size_t n, void* s)
+{
+    if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
+    return run_stream<T>(unpack_table_impl<T, BODY_ADD_REF>().fn[w], in, out, refs, stride ? 1 : 0, n, w != 0, true, true, s);
+}
+template <typename T>
+int dev_undelta_pack(unsigned w, const T* in, const T* bases, T* out, size_t n, void* s)
+{
+    if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
+    if (n && misaligned(bases)) return FL_ERR_ALIGN;
+    return run_stream<T>(unpack_table_impl<T, BODY_UNDELTA>().fn[w], in, out, bases, 0, n, w != 0, true, true, s);
+}
+template <typename T> int dev_delta(bool inverse, const T* in, const T* bases, T* out, size_t n, void* s)
+{
+    if (n && misaligned(bases)) return FL_ERR_ALIGN;
+    return run_stream<T>(delta_launcher<T>(inverse), in, out, bases, 0, n, true, true, true, s);
+}
+template <typename T> int dev_transpose(bool inverse, const T* in, T* out, size_t n, void* s)
+{
+    return run_stream<T>(transpose_launcher<T>(inverse), in, out, nullptr, 0, n, true, true, false, s);
+}
+template <typename T>
+int dev_unpack_single(unsigned w, const T* packed, size_t n_blocks, const uint64_t* idx, size_t n_idx,
+                      T* out, uint32_t* err_flag, void* s)
+{
+    if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
+    if (n_idx == 0) return FL_OK;
+    if (!idx || !out || (w != 0 && !packed)) return FL_ERR_NULL;
+    SingleArgs a{packed, idx, out, err_flag, n_blocks, n_idx, w};
+    hipError_t e = unpack_single_launch<T>(a, static_cast<hipStream_t>(s));
+    return e == hipSuccess ? FL_OK : hip_fail(e);
+}
+
+// ---------------------------------------------------------------------------
+// Host tier: stage host slices through device memory and run the same kernels.
+// ---------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    hipError_t alloc(size_t bytes) { return bytes ? hipMalloc(&p, bytes) : hipSuccess; }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+#define FL_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return hip_fail(e_); } while (0)
+
+template <typename T, typename F>
+int host_run(const T* in, size_t in_elems, const T* aux, size_t aux_elems, T* out, size_t out_elems, F&& dev)
+{
+    if ((in_elems && !in) || (out_elems && !out) || (aux_elems && !aux)) return FL_ERR_NULL;
+    DevBuf din, daux, dout;
+    FL_HIP(din.alloc(in_elems * sizeof(T)));
+    FL_HIP(daux.alloc(aux_elems * sizeof(T)));
+    FL_HIP(dout.alloc(out_elems * sizeof(T)));
+    if (in_elems) FL_HIP(hipMemcpy(din.p, in, in_elems * sizeof(T), hipMemcpyHostToDevice));
+    if (aux_elems) FL_HIP(hipMemcpy(daux.p, aux, aux_elems * sizeof(T), hipMemcpyHostToDevice));
+    int rc = dev(static_cast<const T*>(din.p), static_cast<const T*>(daux.p), static_cast<T*>(dout.p));
+    if (rc != FL_OK) return rc;
+    FL_HIP(hipStreamSynchronize(nullptr));
+    if (out_elems) FL_HIP(hipMemcpy(out, dout.p, out_elems * sizeof(T), hipMemcpyDeviceToHost));
+    return FL_OK;
+}
+
+template <typename T> size_t plen(unsigned w) { return (size_t)1024 * w / Elem<T>::BITS; }
+
+}  // namespace
+
+extern "C" {
+
+const char* fl_version(void) { return "fastlanes_amd 0.1.0 (gfx950; wire format of spiraldb/fastlanes 0.1.8)"; }
+
+const char* fl_status_string(int status)
+{
+    switch (status) {
+    case FL_OK: return "ok";
+    case FL_ERR_WIDTH: return "width > T";
+    case FL_ERR_INDEX: return "index out of range";
+    case FL_ERR_NULL: return "null pointer";
+    case FL_ERR_ALIGN: return "device pointer not 16-byte aligned";
+    case FL_ERR_HIP: return "HIP runtime error";
+    default: return "unknown status";
+    }
+}
+
+int fl_last_hip_error(void) { return g_last_hip_error; }
+
+size_t fl_packed_len(unsigned type_bits, unsigned width)
+{
+    if (type_bits != 8 && type_bits != 16 && type_bits != 32 && type_bits != 64) return 0;
+    if (width > type_bits) return 0;
+    return (size_t)1024 * width / type_bits;
+}
+
+#define FL_DEFINE_TYPE(T, S)                                                                              \
+    int fl_##S##_pack(unsigned w, const T* in, T* out, size_t n, void* s) { return dev_pack<T>(w, in, out, n, s); } \
+    int fl_##S##_unpack(unsigned w, const T* in, T* out, size_t n, void* s) { return dev_unpack<T>(w, in, out, n, s); } \
+    int fl_##S##_unpack_single(unsigned w, const T* pk, size_t n, const uint64_t* idx, size_t ni, T* out,  \
+                               uint32_t* ef, void* s)                                                     \
+    { return dev_unpack_single<T>(w, pk, n, idx, ni, out, ef, s); }                                       \
+    int fl_##S##_for_pack(unsigned w, const T* in, const T* r, size_t rs, T* out, size_t n, void* s)      \
+    { return dev_for_pack<T>(w, in, r, rs, out, n, s); }                                                  \
+    int fl_##S##_unfor_pack(unsigned w, const T* in, const T* r, size_t rs, T* out, size_t n, void* s)    \
+    { return dev_unfor_pack<T>(w, in, r, rs, out, n, s); }                                                \
+    int fl_##S##_delta(const T* in, const T* b, T* out, size_t n, void* s) { return dev_delta<T>(false, in, b, out, n, s); } \
+    int fl_##S##_undelta(const T* in, const T* b, T* out, size_t n, void* s) { return dev_delta<T>(true, in, b, out, n, s); } \
+    int fl_##S##_undelta_pack(unsigned w, const T* in, const T* b, T* out, size_t n, void* s)             \
+    { return dev_undelta_pack<T>(w, in, b, out, n, s); }                                                  \
+    int fl_##S##_transpose(const T* in, T* out, size_t n, void* s) { return dev_transpose<T>(false, in, out, n, s); } \
+    int fl_##S##_untranspose(const T* in, T* out, size_t n, void* s) { return dev_transpose<T>(true, in, out, n, s); } \
+    int fl_##S##_pack_host(unsigned w, const T* in, T* out, size_t n)                                     \
+    {                                                                                                     \
+        if (w > sizeof(T) * 8) return FL_ERR_WIDTH;                                                       \
+        return host_run<T>(in, n * 1024, nullptr, 0, out, n * plen<T>(w),                                 \
+                           [&](const T* di, const T*, T* d_o) { return dev_pack<T>(w, di, d_o, n, nullptr); }); \
+    }                                                                                                     \
+    int fl_##S##_unpack_host(unsigned w, const T* in, T* out, size_t n)                                   \
+    {                                                                                                     \
+        if (w > sizeof(T) * 8) return FL_ERR_WIDTH;                                                       \
+        return host_run<T>(in, n * plen<T>(w), nullptr, 0, out, n * 1024,                                 \
+                           [&](const T* di, const T*, T* d_o) { return dev_unpack<T>(w, di, d_o, n, nullptr); }); \
+    }                                                                                                     \
+    int fl_##S##_unpack_single_host(unsigned w, const T* pk, size_t n, uint64_t index, T* value)          \
+    {                                                                                                     \
+        if (w > sizeof(T) * 8) return FL_ERR_WIDTH;                                                       \
+        if (!value) return FL_ERR_NULL;                                                                   \
+        if (w == 0) { *value = 0; return FL_OK; } /* bitpacking.rs:136-139 precedes the assert */         \
+        if (index >= (uint64_t)n * 1024) return FL_ERR_INDEX;                                             \
+        DevBuf didx;                                                                                      \
+        FL_HIP(didx.alloc(sizeof(uint64_t)));                                                             \
+        FL_HIP(hipMemcpy(didx.p, &index, sizeof(uint64_t), hipMemcpyHostToDevice));                       \
+        return host_run<T>(pk, n * plen<T>(w), nullptr, 0, value, 1, [&](const T* di, const T*, T* d_o) {  \
+            return dev_unpack_single<T>(w, di, n, static_cast<const uint64_t*>(didx.p), 1, d_o, nullptr, nullptr); \
+        });                                                                                               \
+    }                                                                                                     \
+    int fl_##S##_for_pack_host(unsigned w, const T* in, T reference, T* out, size_t n)                    \
+    {                                                                                                     \
+        if (w > sizeof(T) * 8) return FL_ERR_WIDTH;                                                       \
+        return host_run<T>(in, n * 1024, &reference, 1, out, n * plen<T>(w),                              \
+                           [&](const T* di, const T* da, T* d_o) { return dev_for_pack<T>(w, di, da, 0, d_o, n, nullptr); }); \
+    }                                                                                                     \
+    int fl_##S##_unfor_pack_host(unsigned w, const T* in, T reference, T* out, size_t n)                  \
+    {                                                                                                     \
+        if (w > sizeof(T) * 8) return FL_ERR_WIDTH;                                                       \
+        return host_run<T>(in, n * plen<T>(w), &reference, 1, out, n * 1024,                              \
+                           [&](const T* di, const T* da, T* d_o) { return dev_unfor_pack<T>(w, di, da, 0, d_o, n, nullptr); }); \
+    }                                                                                                     \
+    int fl_##S##_delta_host(const T* in, const T* b, T* out, size_t n)                                    \
+    {                                                                                                     \
+        return host_run<T>(in, n * 1024, b, n * (1024 / (sizeof(T) * 8)), out, n * 1024,                  \
+                           [&](const T* di, const T* da, T* d_o) { return dev_delta<T>(false, di, da, d_o, n, nullptr); }); \
+    }                                                                                                     \
+    int fl_##S##_undelta_host(const T* in, const T* b, T* out, size_t n)                                  \
+    {                                                                                                     \
+        return host_run<T>(in, n * 1024, b, n * (1024 / (sizeof(T) * 8)), out, n * 1024,                  \
+                           [&](const T* di, const T* da, T* d_o) { return dev_delta<T>(true, di, da, d_o, n, nullptr); }); \
+    }                                                                                                     \
+    int fl_##S##_undelta_pack_host(unsigned w, const T* in, const T* b, T* out, size_t n)                 \
+    {                                                                                                     \
+        if (w > sizeof(T) * 8) return FL_ERR_WIDTH;                                                       \
+        return host_run<T>(in, n * plen<T>(w), b, n * (1024 / (sizeof(T) * 8)), out, n * 1024,            \
+                           [&](const T* di, const T* da, T* d_o) { return dev_undelta_pack<T>(w, di, da, d_o, n, nullptr); }); \
+    }                                                                                                     \
+    int fl_##S##_transpose_host(const T* in, T* out, size_t n)                                            \
+    {                                                                                                     \
+        return host_run<T>(in, n * 1024, nullptr, 0, out, n * 1024,                                       \
+                           [&](const T* di, const T*, T* d_o) { return dev_transpose<T>(false, di, d_o, n, nullptr); }); \
+    }                                                                                                     \
+    int fl_##S##_untranspose_host(const T* in, T* out, size_t n)                                          \
+    {                                                                                                     \
+        return host_run<T>(in, n * 1024, nullptr, 0, out, n * 1024,                                       \
+                           [&](const T* di, const T*, T* d_o) { return dev_transpose<T>(true, di, d_o, n, nullptr); }); \
+    }
+
+FL_DEFINE_TYPE(uint8_t, u8)
+FL_DEFINE_TYPE(uint16_t, u16)
+FL_DEFINE_TYPE(uint32_t, u32)
+FL_DEFINE_TYPE(uint64_t, u64)
+
+}  // extern "C"

@@ -1,0 +1,251 @@
+// fl_device.hpp -- device-side building blocks of the FastLanes codec for gfx950.
+//
+// Geometry (all element types).  A 1024-value block is a matrix of 16-byte
+// CELLS, 8 cells (=128 B) per row:
+//   * packed   : W rows  -- row w holds word w of every FL lane
+//                (reference: `packed[LANES * w + lane]`, macros.rs:89/:158)
+//   * unpacked : T rows  -- logical row r (the r-th value of every FL lane)
+//                lives at cell-row  (r%8)*T + FL_ORDER[r/8]*sizeof(T)
+//                (reference: index(row,lane), macros.rs:20-24)
+// One GPU thread owns ONE CELL COLUMN c (0..7) of one block, i.e. 16/sizeof(T)
+// adjacent FL lanes for ALL rows.  Consequences:
+//   * every global access is a 16-byte dwordx4; 8 neighbouring threads cover a
+//     full 128-byte row (one L2 line) of their block;
+//   * row, word index, shift and mask are compile-time constants for every
+//     thread -- exactly the property the reference gets from its unrolled macro;
+//   * Delta's per-lane serial chain (delta.rs:56-61) is thread-local: no LDS, no
+//     cross-lane traffic;
+//   * u8/u16 lanes are processed SWAR inside 32-bit registers (masks are chosen
+//     so no bit ever crosses an element boundary).
+// A 64-lane wavefront therefore processes 8 blocks, a 256-thread workgroup 32.
+//
+// This header is also the user-extensible "functor" surface corresponding to
+// the reference's exported pack!/unpack!/iterate! macros (macros.rs:11,34,100):
+// unpack_rows<T,W>(cells, f) calls f(row_constant, cell) in row order, and
+// pack_rows<T,W>(src_of_row, sink_of_word) is its inverse.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include <utility>
+
+namespace fl {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// lib.rs:22 FL_ORDER = [0,4,2,6,1,5,3,7], nibble-packed so it folds.
+__host__ __device__ constexpr int fl_order(int o) { return (0x73516240u >> (4 * o)) & 7; }
+
+template <int N, typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>)
+{
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+// Compile-time unrolled loop: f(integral_constant<int,0>) ... f(integral_constant<int,N-1>).
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// ---------------------------------------------------------------------------
+// Element traits (lib.rs:24-32: T = bits, LANES = 1024 / T)
+// ---------------------------------------------------------------------------
+template <typename T> struct Elem {
+    static constexpr int BITS = sizeof(T) * 8;
+    static constexpr int LANES = 1024 / BITS;
+    static constexpr int PER_CELL = 16 / sizeof(T);   // FL lanes per 16-byte cell
+    static constexpr int ROWS = BITS;                 // unpacked cell-rows per block
+    static constexpr int CELLS_PER_BLOCK = 8 * BITS;  // 1024*sizeof(T)/16
+    // cell-row of logical row r inside an unpacked block (macros.rs:20-24 in cells)
+    __host__ __device__ static constexpr int row_cell(int r)
+    {
+        return (r % 8) * BITS + fl_order(r / 8) * (int)sizeof(T);
+    }
+};
+
+// A cell: 16 bytes = 4 dwords (u8/u16/u32) or 2 qwords (u64).
+template <typename T> struct Cell {
+    using word_t = std::conditional_t<sizeof(T) == 8, uint64_t, uint32_t>;
+    static constexpr int NW = 16 / sizeof(word_t);
+    static constexpr int TB = sizeof(T) * 8;
+    word_t x[NW];
+
+    // element mask replicated across the word (SWAR for u8/u16)
+    __host__ __device__ static constexpr word_t rep(int bits)
+    {
+        const uint64_t m = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
+        if (sizeof(T) == 1) return (word_t)((m & 0xffu) * 0x01010101u);
+        if (sizeof(T) == 2) return (word_t)((m & 0xffffu) * 0x00010001u);
+        return (word_t)m;
+    }
+    __device__ __forceinline__ static Cell zero()
+    {
+        Cell c;
+        for (int i = 0; i < NW; ++i) c.x[i] = 0;
+        return c;
+    }
+    __device__ __forceinline__ static Cell splat(T v)
+    {
+        Cell c;
+        word_t w = (word_t)v;
+        if (sizeof(T) == 1) w = (word_t)((uint32_t)(uint8_t)v * 0x01010101u);
+        if (sizeof(T) == 2) w = (word_t)((uint32_t)(uint16_t)v * 0x00010001u);
+        for (int i = 0; i < NW; ++i) c.x[i] = w;
+        return c;
+    }
+    // (elem >> SH) & mask(BITS)   requires SH + BITS <= TB   (macros.rs:150,164)
+    template <int SH, int BITS> __device__ __forceinline__ Cell extract() const
+    {
+        static_assert(SH + BITS <= TB, "field must lie inside the element");
+        Cell c;
+        for (int i = 0; i < NW; ++i) {
+            if (BITS == 0) c.x[i] = 0;
+            else if (SH + BITS == TB && sizeof(T) >= 4) c.x[i] = x[i] >> SH;
+            else c.x[i] = (x[i] >> SH) & rep(BITS);
+        }
+        return c;
+    }
+    // (elem & mask(BITS)) << SH   requires SH + BITS <= TB   (macros.rs:79,160)
+    template <int SH, int BITS> __device__ __forceinline__ Cell deposit() const
+    {
+        static_assert(SH + BITS <= TB, "field must lie inside the element");
+        Cell c;
+        for (int i = 0; i < NW; ++i) {
+            if (BITS == 0) c.x[i] = 0;
+            else if (SH + BITS == TB && sizeof(T) >= 4) c.x[i] = x[i] << SH;
+            else c.x[i] = (x[i] & rep(BITS)) << SH;
+        }
+        return c;
+    }
+    __device__ __forceinline__ Cell operator|(const Cell& o) const
+    {
+        Cell c;
+        for (int i = 0; i < NW; ++i) c.x[i] = x[i] | o.x[i];
+        return c;
+    }
+    // element-wise wrapping add / sub
+    __device__ __forceinline__ Cell add(const Cell& o) const
+    {
+        Cell c;
+        for (int i = 0; i < NW; ++i) {
+            if constexpr (sizeof(T) == 1) {
+                const uint32_t H = 0x80808080u;
+                c.x[i] = ((x[i] & ~H) + (o.x[i] & ~H)) ^ ((x[i] ^ o.x[i]) & H);
+            } else if constexpr (sizeof(T) == 2) {
+                u16x2 a = __builtin_bit_cast(u16x2, x[i]), b = __builtin_bit_cast(u16x2, o.x[i]);
+                c.x[i] = __builtin_bit_cast(uint32_t, (u16x2)(a + b));   // v_pk_add_u16
+            } else {
+                c.x[i] = x[i] + o.x[i];
+            }
+        }
+        return c;
+    }
+    __device__ __forceinline__ Cell sub(const Cell& o) const
+    {
+        Cell c;
+        for (int i = 0; i < NW; ++i) {
+            if constexpr (sizeof(T) == 1) {
+                const uint32_t H = 0x80808080u;
+                c.x[i] = ((x[i] | H) - (o.x[i] & ~H)) ^ ((x[i] ^ ~o.x[i]) & H);
+            } else if constexpr (sizeof(T) == 2) {
+                u16x2 a = __builtin_bit_cast(u16x2, x[i]), b = __builtin_bit_cast(u16x2, o.x[i]);
+                c.x[i] = __builtin_bit_cast(uint32_t, (u16x2)(a - b));   // v_pk_sub_u16
+            } else {
+                c.x[i] = x[i] - o.x[i];
+            }
+        }
+        return c;
+    }
+};
+
+// 16-byte global accesses.  NT = non-temporal (streamed once, never re-read).
+template <typename T, bool NT = false>
+__device__ __forceinline__ Cell<T> load_cell(const u32x4* p)
+{
+    u32x4 v = NT ? __builtin_nontemporal_load(p) : *p;
+    return __builtin_bit_cast(Cell<T>, v);
+}
+template <typename T, bool NT = false>
+__device__ __forceinline__ void store_cell(u32x4* p, const Cell<T>& c)
+{
+    u32x4 v = __builtin_bit_cast(u32x4, c);
+    if (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+// ---------------------------------------------------------------------------
+// unpack_rows: the unpack! macro (macros.rs:100-174) on one cell column.
+//   in[w]   : packed word-row w of this column (W cells, all in registers)
+//   f(R, c) : called for R = integral_constant<int,row>, row = 0..T-1 in order
+// ---------------------------------------------------------------------------
+template <typename T, int W, typename F>
+__device__ __forceinline__ void unpack_rows(const Cell<T>* in, F&& f)
+{
+    constexpr int TB = Elem<T>::BITS;
+    static_assert(W >= 0 && W <= TB, "BitPackWidth<W>: W <= T (bitpacking.rs:8-13)");
+    static_for<TB>([&](auto R) {
+        constexpr int row = decltype(R)::value;
+        if constexpr (W == 0) {
+            f(R, Cell<T>::zero());                       // macros.rs:118-125
+        } else if constexpr (W == TB) {
+            f(R, in[row]);                               // macros.rs:126-132
+        } else {
+            constexpr int curr = (row * W) / TB;         // macros.rs:144
+            constexpr int next = ((row + 1) * W) / TB;   // macros.rs:145
+            constexpr int shift = (row * W) % TB;        // macros.rs:147
+            if constexpr (next > curr) {
+                constexpr int rem = ((row + 1) * W) % TB;
+                constexpr int cur = W - rem;
+                Cell<T> v = in[curr].template extract<shift, cur>();   // macros.rs:152
+                if constexpr (next < W && rem > 0)                     // macros.rs:156-161
+                    v = v | in[next].template deposit<cur, rem>();
+                f(R, v);
+            } else {
+                f(R, in[curr].template extract<shift, W>());           // macros.rs:164
+            }
+        }
+    });
+}
+
+// ---------------------------------------------------------------------------
+// pack_rows: the pack! macro (macros.rs:34-98) on one cell column.
+//   src(R)     : returns the (already body-transformed) cell of logical row R
+//   sink(Wd,c) : receives packed word-row Wd = integral_constant<int,w>
+// W == 0 produces nothing (macros.rs:52-53); W == T copies unmasked (:54-59).
+// ---------------------------------------------------------------------------
+template <typename T, int W, typename S, typename K>
+__device__ __forceinline__ void pack_rows(S&& src, K&& sink)
+{
+    constexpr int TB = Elem<T>::BITS;
+    static_assert(W >= 0 && W <= TB, "BitPackWidth<W>: W <= T (bitpacking.rs:8-13)");
+    if constexpr (W == 0) {
+        return;
+    } else if constexpr (W == TB) {
+        static_for<TB>([&](auto R) { sink(R, src(R)); });
+    } else {
+        Cell<T> tmp = Cell<T>::zero();
+        static_for<TB>([&](auto R) {
+            constexpr int row = decltype(R)::value;
+            constexpr int shift = (row * W) % TB;
+            constexpr int curr = (row * W) / TB;
+            constexpr int next = ((row + 1) * W) / TB;
+            // bits of this value that stay in word `curr`; the rest is the carry.
+            // (src & mask(W)) << shift drops bits past T (macros.rs:73,79); masking
+            // to `keep` bits first gives the same word and keeps SWAR lanes apart.
+            constexpr int keep = (shift + W <= TB) ? W : TB - shift;
+            const Cell<T> s = src(R);
+            if constexpr (row == 0) tmp = s.template deposit<0, keep>();
+            else tmp = tmp | s.template deposit<shift, keep>();
+            if constexpr (next > curr) {
+                sink(std::integral_constant<int, curr>{}, tmp);        // macros.rs:89
+                constexpr int rem = ((row + 1) * W) % TB;
+                tmp = s.template extract<W - rem, rem>();              // macros.rs:92
+            }
+        });
+    }
+}
+
+}  // namespace fl

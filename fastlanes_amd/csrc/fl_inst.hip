@@ -1,0 +1,49 @@
+// fl_inst.hip -- explicit instantiation unit.  Compiled once per
+// (element type, family) with -DFL_T=<type> -DFL_FAMILY=<n> so the 124 (T,W)
+// pairs x 5 width-parameterised kernels build in parallel:
+//   0 unpack (store)   1 unfor_pack   2 undelta_pack   3 pack   4 for_pack
+//   5 delta / undelta / transpose / untranspose / unpack_single
+#include "fl_kernels.hpp"
+#include "fl_misc.hpp"
+
+#ifndef FL_STREAM_NT
+#define FL_STREAM_NT 0
+#endif
+
+namespace fl {
+using T = FL_T;
+constexpr bool kNT = FL_STREAM_NT != 0;
+using Ws = std::make_integer_sequence<int, Elem<T>::BITS + 1>;
+
+#if FL_FAMILY == 0
+static constexpr WidthTable<T> t_store = make_unpack_table<T, BODY_STORE, kNT>(Ws{});
+template <> const WidthTable<T>& unpack_table_impl<T, BODY_STORE>() { return t_store; }
+#elif FL_FAMILY == 1
+static constexpr WidthTable<T> t_addref = make_unpack_table<T, BODY_ADD_REF, kNT>(Ws{});
+template <> const WidthTable<T>& unpack_table_impl<T, BODY_ADD_REF>() { return t_addref; }
+#elif FL_FAMILY == 2
+static constexpr WidthTable<T> t_undelta = make_unpack_table<T, BODY_UNDELTA, kNT>(Ws{});
+template <> const WidthTable<T>& unpack_table_impl<T, BODY_UNDELTA>() { return t_undelta; }
+#elif FL_FAMILY == 3
+static constexpr WidthTable<T> t_pack = make_pack_table<T, false, kNT>(Ws{});
+template <> const WidthTable<T>& pack_table_impl<T, false>() { return t_pack; }
+#elif FL_FAMILY == 4
+static constexpr WidthTable<T> t_forpack = make_pack_table<T, true, kNT>(Ws{});
+template <> const WidthTable<T>& pack_table_impl<T, true>() { return t_forpack; }
+#elif FL_FAMILY == 5
+template <> stream_launch_t delta_launcher<T>(bool inverse)
+{
+    return inverse ? &launch_delta<T, true, kNT> : &launch_delta<T, false, kNT>;
+}
+template <> stream_launch_t transpose_launcher<T>(bool inverse)
+{
+    return inverse ? &launch_transpose<T, true> : &launch_transpose<T, false>;
+}
+template <> hipError_t unpack_single_launch<T>(const SingleArgs& a, hipStream_t s)
+{
+    return launch_unpack_single<T>(a, s);
+}
+#else
+#error "FL_FAMILY must be 0..5"
+#endif
+}  // namespace fl

@@ -1,0 +1,109 @@
+// fl_misc.hpp -- transpose / untranspose (transpose.rs:9-36) and batched
+// unpack_single (bitpacking.rs:132-179) kernels.
+#pragma once
+#include "fl_kernels.hpp"
+
+namespace fl {
+
+// transpose.rs:29-36:  tau(i) = (i%16)*64 + FL_ORDER[(i/16)%8]*8 + i/128
+__host__ __device__ constexpr unsigned tau(unsigned i)
+{
+    return (i % 16) * 64 + fl_order((i / 16) % 8) * 8 + i / 128;
+}
+// inverse: j = a*64 + b*8 + r  ->  r*128 + FL_ORDER[b]*16 + a   (FL_ORDER is self-inverse, lib.rs:53-59)
+__host__ __device__ constexpr unsigned tau_inv(unsigned j)
+{
+    return (j % 8) * 128 + fl_order((j / 8) % 8) * 16 + j / 64;
+}
+
+// One thread per 16-byte OUTPUT cell; the PER_CELL source elements are gathered
+// from the (L1/L2-resident) input block.  transpose: out[i] = in[tau(i)]
+// (transpose.rs:12-14); untranspose: out[tau(i)] = in[i] <=> out[j] = in[tau_inv(j)]
+// (transpose.rs:19-21).
+template <typename T, bool INVERSE>
+__global__ __launch_bounds__(WG) void k_transpose(StreamArgs a)
+{
+    constexpr int PC = Elem<T>::PER_CELL;
+    constexpr int CPB = Elem<T>::CELLS_PER_BLOCK;
+    const uint64_t g = (uint64_t)blockIdx.x * WG + threadIdx.x;
+    const uint64_t blk = g / CPB;
+    const unsigned cell = (unsigned)(g % CPB);
+    if (blk >= a.n_blocks) return;
+    const T* src = reinterpret_cast<const T*>(a.in) + blk * 1024;
+    T v[PC];
+#pragma unroll
+    for (int e = 0; e < PC; ++e) {
+        const unsigned o = cell * PC + e;
+        v[e] = src[INVERSE ? tau_inv(o) : tau(o)];
+    }
+    u32x4 packed;
+    __builtin_memcpy(&packed, v, 16);
+    a.out[blk * CPB + cell] = packed;
+}
+
+template <typename T, bool INVERSE>
+hipError_t launch_transpose(const StreamArgs& a, hipStream_t s)
+{
+    if (a.n_blocks == 0) return hipSuccess;
+    const uint64_t threads = a.n_blocks * Elem<T>::CELLS_PER_BLOCK;
+    hipLaunchKernelGGL((k_transpose<T, INVERSE>), dim3((unsigned)((threads + WG - 1) / WG)), dim3(WG), 0, s, a);
+    return hipGetLastError();
+}
+
+struct SingleArgs {
+    const void* packed;
+    const uint64_t* indices;
+    void* out;
+    uint32_t* err_flag;
+    uint64_t n_blocks;
+    uint64_t n_indices;
+    unsigned width;
+};
+
+// bitpacking.rs:132-179 with the lookup tables of :207-232 computed in closed form.
+template <typename T>
+__global__ __launch_bounds__(WG) void k_unpack_single(SingleArgs a)
+{
+    constexpr unsigned TB = Elem<T>::BITS;
+    constexpr unsigned LANES = Elem<T>::LANES;
+    const uint64_t k = (uint64_t)blockIdx.x * WG + threadIdx.x;
+    if (k >= a.n_indices) return;
+    const uint64_t gi = a.indices[k];
+    T* out = static_cast<T*>(a.out);
+    const unsigned W = a.width;
+    if (W == 0) { out[k] = 0; return; }                       // bitpacking.rs:136-139
+    const uint64_t blk = gi >> 10;
+    if (blk >= a.n_blocks) {                                  // bitpacking.rs:152
+        out[k] = 0;
+        if (a.err_flag) *a.err_flag = 1u;
+        return;
+    }
+    const unsigned index = (unsigned)gi & 1023u;
+    const unsigned lane = index % LANES;                      // bitpacking.rs:210
+    const unsigned s = index / 128;                           // bitpacking.rs:226
+    const unsigned o = fl_order((index - s * 128 - lane) / 16);   // bitpacking.rs:227-228
+    const unsigned row = o * 8 + s;                           // bitpacking.rs:229
+    const T* pk = static_cast<const T*>(a.packed) + blk * (uint64_t)(1024u * W / TB);
+    if (W == TB) { out[k] = pk[LANES * row + lane]; return; } // bitpacking.rs:159-162
+    const T mask = (T)(((T)1 << W) - (T)1);
+    const unsigned start_bit = row * W;
+    const unsigned start_word = start_bit / TB;
+    const unsigned lo_shift = start_bit % TB;
+    const unsigned remaining = TB - lo_shift;
+    T v = (T)(pk[LANES * start_word + lane] >> lo_shift);
+    if (remaining < W) v = (T)(v | (T)(pk[LANES * (start_word + 1) + lane] << remaining));
+    out[k] = (T)(v & mask);
+}
+
+template <typename T>
+hipError_t launch_unpack_single(const SingleArgs& a, hipStream_t s)
+{
+    if (a.n_indices == 0) return hipSuccess;
+    hipLaunchKernelGGL((k_unpack_single<T>), dim3((unsigned)((a.n_indices + WG - 1) / WG)), dim3(WG), 0, s, a);
+    return hipGetLastError();
+}
+
+template <typename T> stream_launch_t transpose_launcher(bool inverse);
+template <typename T> hipError_t unpack_single_launch(const SingleArgs& a, hipStream_t s);
+
+}  // namespace fl

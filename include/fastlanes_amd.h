@@ -1,0 +1,131 @@
+/*
+ * fastlanes_amd.h -- C ABI of the MI355X-native FastLanes codec (libfastlanes_amd.so).
+ *
+ * The drop-in boundary for spiraldb/fastlanes' BitPacking / FoR / Delta /
+ * Transpose trait methods (reference: /root/reference/src).  The Rust traits
+ * are static methods monomorphised per element type and const width W; an FFI
+ * cannot carry const generics, so every entry point takes the runtime `width`
+ * exactly like the reference's own `unchecked_*` methods do
+ * (bitpacking.rs:30,44,58) and dispatches to a per-(T,W) gfx950 kernel.
+ *
+ * Naming:  fl_<ty>_<method>[_host],  <ty> in {u8,u16,u32,u64},  <method> the
+ * reference's method name.  Each function cites the reference interface it
+ * replaces.
+ *
+ * Two tiers, same kernels:
+ *   DEVICE tier  fl_<ty>_<method>(..., n_blocks, stream)
+ *       All data pointers are DEVICE pointers (HBM).  The op is applied to
+ *       n_blocks contiguous 1024-value blocks: block b reads
+ *       in + b*in_block_elems and writes out + b*out_block_elems, where an
+ *       unpacked block is 1024 elements and a packed block is 1024*W/T elements
+ *       (= 128*W bytes; bitpacking.rs:77).  This is the reference's caller loop
+ *       (benches/bitpacking.rs:80-97) moved on-device.  Asynchronous on `stream`
+ *       (a hipStream_t, passed as void*; NULL = default stream); never
+ *       synchronises, never allocates, retains no pointer.
+ *   HOST tier    fl_<ty>_<method>_host(..., n_blocks)
+ *       Same semantics with HOST pointers (the trait methods' `&[T]` slices,
+ *       e.g. bitpacking.rs:19,33): stages through device memory, runs the same
+ *       kernels, synchronises before returning.  n_blocks = 1 is the exact
+ *       shape of one trait-method call.  There is no CPU code path: without a
+ *       GPU these return FL_ERR_HIP.
+ *
+ * Preconditions.  Device pointers 16-byte aligned (every block is a multiple
+ * of 128 bytes, so block starts stay aligned; 128-byte alignment of the
+ * column base is recommended for full-line accesses).  in/out must not
+ * overlap.  width <= T.  Outputs are fully overwritten (pack with width 0
+ * writes nothing, macros.rs:52-53; unpack with width 0 writes 1024 zeros per
+ * block, macros.rs:118-125).
+ *
+ * Errors.  The reference has no Result type: `unchecked_*` panics via
+ * unreachable!() on width > T (bitpacking.rs:93,126,197) and unpack_single
+ * asserts index < 1024 (bitpacking.rs:152).  Here every function returns an
+ * fl_status; a binding maps nonzero to panic! to match.
+ * Nothing throws or aborts across the ABI.
+ *
+ * Threading.  Re-entrant and thread-safe; no global state besides HIP's own.
+ * Kernels run on the device that is current for the calling thread (the
+ * device `stream` belongs to).
+ */
+#ifndef FASTLANES_AMD_H
+#define FASTLANES_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum fl_status {
+    FL_OK = 0,
+    FL_ERR_WIDTH = 1,   /* width > T              (bitpacking.rs:93 unreachable!) */
+    FL_ERR_INDEX = 2,   /* index >= 1024*n_blocks (bitpacking.rs:152 assert!)      */
+    FL_ERR_NULL = 3,    /* required pointer is NULL                                */
+    FL_ERR_ALIGN = 4,   /* device pointer not 16-byte aligned                      */
+    FL_ERR_HIP = 5      /* HIP runtime error; see fl_last_hip_error()              */
+} fl_status;
+
+/* Library / build identification and diagnostics. */
+const char *fl_version(void);
+const char *fl_status_string(int status);
+/* hipError_t of the most recent FL_ERR_HIP on the calling thread (0 if none). */
+int fl_last_hip_error(void);
+/* Elements in one packed block: 1024*width/T (bitpacking.rs:77); 0 if width > T. */
+size_t fl_packed_len(unsigned type_bits, unsigned width);
+
+#define FL_DECLARE_TYPE(T, S)                                                                   \
+    /* BitPacking::unchecked_pack (bitpacking.rs:30,76-96) -> pack::<W> (:65-74) */             \
+    int fl_##S##_pack(unsigned width, const T *in, T *out, size_t n_blocks, void *stream);      \
+    /* BitPacking::unchecked_unpack (bitpacking.rs:44,109-129) -> unpack::<W> (:98-107) */      \
+    int fl_##S##_unpack(unsigned width, const T *in, T *out, size_t n_blocks, void *stream);    \
+    /* BitPacking::unchecked_unpack_single (bitpacking.rs:58,181-200) -> unpack_single::<W>    \
+     * (:132-179), batched: out[k] = value at element indices[k] of the column, where          \
+     * indices[k] = block*1024 + index_in_block.  Out-of-range indices make the call return    \
+     * FL_ERR_INDEX on the host tier; on the device tier they write 0 and set *err_flag        \
+     * (a device uint32, may be NULL) to 1. */                                                 \
+    int fl_##S##_unpack_single(unsigned width, const T *packed, size_t n_blocks,                \
+                               const uint64_t *indices, size_t n_indices, T *out,               \
+                               uint32_t *err_flag, void *stream);                               \
+    /* FoR::for_pack::<W> (ffor.rs:5-9,24-36).  references[b*reference_stride] is block b's    \
+     * scalar; reference_stride 0 broadcasts references[0]. */                                 \
+    int fl_##S##_for_pack(unsigned width, const T *in, const T *references,                     \
+                          size_t reference_stride, T *out, size_t n_blocks, void *stream);      \
+    /* FoR::unfor_pack::<W> (ffor.rs:11-17,38-50) */                                            \
+    int fl_##S##_unfor_pack(unsigned width, const T *in, const T *references,                   \
+                            size_t reference_stride, T *out, size_t n_blocks, void *stream);    \
+    /* Delta::delta (delta.rs:7,24-33); bases is [n_blocks][LANES] (128 bytes per block) */     \
+    int fl_##S##_delta(const T *in, const T *bases, T *out, size_t n_blocks, void *stream);     \
+    /* Delta::undelta (delta.rs:9,36-45) */                                                     \
+    int fl_##S##_undelta(const T *in, const T *bases, T *out, size_t n_blocks, void *stream);   \
+    /* Delta::undelta_pack::<W> (delta.rs:11-16,47-63); output stays in transposed order */     \
+    int fl_##S##_undelta_pack(unsigned width, const T *in, const T *bases, T *out,              \
+                              size_t n_blocks, void *stream);                                   \
+    /* Transpose::transpose (transpose.rs:5,11-15) */                                           \
+    int fl_##S##_transpose(const T *in, T *out, size_t n_blocks, void *stream);                 \
+    /* Transpose::untranspose (transpose.rs:6,17-22) */                                         \
+    int fl_##S##_untranspose(const T *in, T *out, size_t n_blocks, void *stream);               \
+    /* ---- host-pointer tier: the trait methods' own slice arguments ---- */                   \
+    int fl_##S##_pack_host(unsigned width, const T *in, T *out, size_t n_blocks);               \
+    int fl_##S##_unpack_host(unsigned width, const T *in, T *out, size_t n_blocks);             \
+    int fl_##S##_unpack_single_host(unsigned width, const T *packed, size_t n_blocks,           \
+                                    uint64_t index, T *value);                                  \
+    int fl_##S##_for_pack_host(unsigned width, const T *in, T reference, T *out,                \
+                               size_t n_blocks);                                                \
+    int fl_##S##_unfor_pack_host(unsigned width, const T *in, T reference, T *out,              \
+                                 size_t n_blocks);                                              \
+    int fl_##S##_delta_host(const T *in, const T *bases, T *out, size_t n_blocks);              \
+    int fl_##S##_undelta_host(const T *in, const T *bases, T *out, size_t n_blocks);            \
+    int fl_##S##_undelta_pack_host(unsigned width, const T *in, const T *bases, T *out,         \
+                                   size_t n_blocks);                                            \
+    int fl_##S##_transpose_host(const T *in, T *out, size_t n_blocks);                          \
+    int fl_##S##_untranspose_host(const T *in, T *out, size_t n_blocks);
+
+FL_DECLARE_TYPE(uint8_t, u8)
+FL_DECLARE_TYPE(uint16_t, u16)
+FL_DECLARE_TYPE(uint32_t, u32)
+FL_DECLARE_TYPE(uint64_t, u64)
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTLANES_AMD_H */

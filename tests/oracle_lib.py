@@ -144,7 +144,7 @@ class Oracle:
         return out
 
     # ---- batched convenience over the literal functions ---------------------
-    def batch(self, op, ty, w, data, aux=None):
+    def batch(self, op, ty, w, data, aux=None, n_blocks=None):
         """Apply a single-block literal oracle op to n contiguous blocks."""
         dt = TYPES[ty][0]
         data = np.ascontiguousarray(data, dtype=dt)
@@ -158,7 +158,7 @@ class Oracle:
                                             else self.for_pack(ty, w, blk, aux[b]))
             return out
         if op in ("unpack", "unfor_pack", "undelta_pack"):
-            n = data.size // pl if pl else len(aux) if aux is not None else 0
+            n = n_blocks if n_blocks is not None else (data.size // pl if pl else 0)
             out = np.zeros(n * 1024, dtype=dt)
             L = lanes(ty)
             for b in range(n):
@@ -209,6 +209,15 @@ class Oracle:
         if rc:
             raise ValueError(f"oracle fast rc={rc}")
         return out
+
+
+def load_native_oracle():
+    """-march=native build for the CPU-baseline leg (falls back to the portable build)."""
+    try:
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "native"])
+        return Oracle(os.path.join(ORACLE_DIR, "libfl_oracle_native.so")), "-march=native"
+    except Exception:
+        return load_oracle(), "-mavx2 -mbmi2 (portable build)"
 
 
 _ORACLE = None

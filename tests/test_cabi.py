@@ -1,0 +1,88 @@
+"""CPU: the C-ABI library builds, loads, and exports every symbol that
+include/fastlanes_amd.h declares; argument validation that needs no GPU works;
+the product package never references oracle/."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build_library()
+    import fastlanes_amd
+    return fastlanes_amd.load()
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "fastlanes_amd.h")).read()
+    body = text.split("#define FL_DECLARE_TYPE(T, S)")[1].split("FL_DECLARE_TYPE(uint8_t, u8)")[0]
+    per_type = re.findall(r"fl_##S##_(\w+)\(", body)
+    syms = [f"fl_{ty}_{m}" for ty in ("u8", "u16", "u32", "u64") for m in per_type]
+    syms += re.findall(r"\b(fl_(?:version|status_string|last_hip_error|packed_len))\(", text)
+    return sorted(set(syms))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    import fastlanes_amd
+    syms = _header_symbols()
+    assert len(syms) == 4 * 20 + 4
+    assert sorted(fastlanes_amd.exported_symbols()) == syms
+    for s in syms:
+        assert hasattr(lib, s), s
+
+
+def test_packed_len_and_strings(lib):
+    assert lib.fl_packed_len(16, 3) == 192       # benches/bitpacking.rs:22
+    assert lib.fl_packed_len(32, 10) == 320      # bitpacking.rs:251
+    assert lib.fl_packed_len(64, 17) == 272
+    assert lib.fl_packed_len(32, 33) == 0
+    assert lib.fl_packed_len(12, 3) == 0
+    assert lib.fl_status_string(1) == b"width > T"
+    assert b"gfx950" in lib.fl_version()
+
+
+def test_width_validation_needs_no_gpu(lib):
+    buf = np.zeros(2048, dtype=np.uint64)
+    p = buf.ctypes.data
+    for ty, T in (("u8", 8), ("u16", 16), ("u32", 32), ("u64", 64)):
+        assert getattr(lib, f"fl_{ty}_pack")(T + 1, p, p, 1, None) == 1
+        assert getattr(lib, f"fl_{ty}_unpack")(T + 1, p, p, 1, None) == 1
+        assert getattr(lib, f"fl_{ty}_undelta_pack")(T + 1, p, p, p, 1, None) == 1
+        assert getattr(lib, f"fl_{ty}_unfor_pack")(T + 1, p, p, 1, p, 1, None) == 1
+        assert getattr(lib, f"fl_{ty}_pack_host")(T + 1, p, p, 1) == 1
+        assert getattr(lib, f"fl_{ty}_unpack")(3, None, p, 1, None) == 3         # FL_ERR_NULL
+        assert getattr(lib, f"fl_{ty}_unpack")(3, p + 4, p, 1, None) == 4        # FL_ERR_ALIGN
+        assert getattr(lib, f"fl_{ty}_unpack")(3, p, p, 0, None) == 0            # empty column
+        v = (ctypes.c_uint64 * 1)()
+        assert getattr(lib, f"fl_{ty}_unpack_single_host")(3, p, 1, 1024, v) == 2  # bitpacking.rs:152
+
+
+def test_python_mirror_raises_like_the_reference():
+    import fastlanes_amd as fl
+    with pytest.raises(fl.FastLanesError):
+        fl.BitPacking.pack(17, np.zeros(1024, dtype=np.uint16))
+    with pytest.raises(ValueError):
+        fl.BitPacking.pack(3, np.zeros(1000, dtype=np.uint16))
+
+
+def test_product_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "fastlanes_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if "build" in dirpath.split(os.sep):
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", "Makefile")):
+                text = open(os.path.join(dirpath, f)).read()
+                for line in text.splitlines():
+                    if "oracle" in line.lower():
+                        stripped = line.strip()
+                        assert stripped.startswith(("//", "#", "*", '"', "'")) or "oracle/" in stripped and (
+                            "touches" in stripped or "never" in stripped.lower()), (f, line)
+    header = open(os.path.join(ROOT, "include", "fastlanes_amd.h")).read()
+    assert "fl_oracle" not in header

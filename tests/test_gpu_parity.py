@@ -1,0 +1,264 @@
+"""GPU parity tests (pytest -m gpu): the HIP path, called through the C ABI,
+against the CPU oracle on the same seeded inputs, against the committed golden
+fixtures, and -- at BASELINE.json's full sizes -- through size-independent
+properties.  Bit-exact everywhere (integer work)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from datagen import sha, values
+from golden.make_golden import N_BLOCKS, case_inputs
+from oracle_lib import TYPES, lanes, packed_len, tbits
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden.json")))
+TYS = ["u8", "u16", "u32", "u64"]
+
+
+@pytest.fixture(scope="module")
+def fl():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    import fastlanes_amd
+    fastlanes_amd.load()  # fails loudly if the HIP extension is missing
+    return fastlanes_amd
+
+
+def to_dev(a):
+    import torch
+    a = np.ascontiguousarray(a)
+    if a.size == 0:
+        return torch.empty(0, dtype=getattr(torch, str(a.dtype)), device="cuda:0")
+    return torch.from_numpy(a.view(np.uint8)).to("cuda:0").view(getattr(torch, str(a.dtype)))
+
+
+def to_np(t, ty):
+    import torch
+    if t.numel() == 0:
+        return np.zeros(0, dtype=TYPES[ty][0])
+    return t.view(torch.uint8).cpu().numpy().view(TYPES[ty][0])
+
+
+# ---------------------------------------------------------------------------
+# every (T, W): all width-parameterised ops vs the oracle, ragged block count
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("ty", TYS)
+def test_all_widths_vs_oracle(fl, oracle, ty):
+    T = tbits(ty)
+    n = 37  # not a multiple of the 32-block workgroup, nor of the 8-block wavefront
+    for w in range(T + 1):
+        seed = 7000 + 64 * T + w
+        v = values(ty, n * 1024, seed)                       # over-wide: pack must truncate
+        pk = values(ty, n * packed_len(ty, w), seed + 1)     # arbitrary packed bits
+        refs = values(ty, n, seed + 2)
+        bases = values(ty, n * lanes(ty), seed + 3)
+        dv, dpk, drefs, dbases = to_dev(v), to_dev(pk), to_dev(refs), to_dev(bases)
+
+        got = to_np(fl.BitPacking.pack(w, dv), ty)
+        assert np.array_equal(got, oracle.batch("pack", ty, w, v)), (ty, w, "pack")
+        got = to_np(fl.BitPacking.unpack(w, dpk, n_blocks=n), ty)
+        assert np.array_equal(got, oracle.batch("unpack", ty, w, pk, n_blocks=n)), (ty, w, "unpack")
+        got = to_np(fl.FoR.for_pack(w, dv, drefs), ty)
+        assert np.array_equal(got, oracle.batch("for_pack", ty, w, v, aux=refs)), (ty, w, "for_pack")
+        got = to_np(fl.FoR.unfor_pack(w, dpk, drefs, n_blocks=n), ty)
+        assert np.array_equal(got, oracle.batch("unfor_pack", ty, w, pk, aux=refs, n_blocks=n)), (ty, w, "unfor_pack")
+        got = to_np(fl.Delta.undelta_pack(w, dpk, dbases), ty)
+        assert np.array_equal(got, oracle.batch("undelta_pack", ty, w, pk, aux=bases, n_blocks=n)), (ty, w, "undelta_pack")
+
+
+@pytest.mark.parametrize("ty", TYS)
+def test_delta_transpose_vs_oracle(fl, oracle, ty):
+    n = 37
+    v = values(ty, n * 1024, 91 + tbits(ty))
+    bases = values(ty, n * lanes(ty), 92 + tbits(ty))
+    dv, db = to_dev(v), to_dev(bases)
+    assert np.array_equal(to_np(fl.Delta.delta(dv, db), ty), oracle.batch("delta", ty, None, v, aux=bases))
+    assert np.array_equal(to_np(fl.Delta.undelta(dv, db), ty), oracle.batch("undelta", ty, None, v, aux=bases))
+    assert np.array_equal(to_np(fl.Transpose.transpose(dv), ty), oracle.batch("transpose", ty, None, v))
+    assert np.array_equal(to_np(fl.Transpose.untranspose(dv), ty), oracle.batch("untranspose", ty, None, v))
+
+
+@pytest.mark.parametrize("ty", TYS)
+def test_unpack_single_vs_oracle(fl, oracle, ty):
+    import torch
+    T = tbits(ty)
+    n = 5
+    rng = np.random.default_rng(5 + T)
+    for w in sorted({0, 1, 3, T // 2, T - 1, T}):
+        pk = values(ty, n * packed_len(ty, w), 300 + w)
+        idx = rng.integers(0, n * 1024, size=777, dtype=np.int64)
+        idx[:4] = [0, 1023, 1024, n * 1024 - 1]
+        got = to_np(fl.BitPacking.unpack_single(w, to_dev(pk), torch.from_numpy(idx).cuda(), n_blocks=n), ty)
+        pl = packed_len(ty, w)
+        want = [oracle.unpack_single(ty, w, pk[(i // 1024) * pl:(i // 1024 + 1) * pl], int(i % 1024)) for i in idx]
+        assert [int(x) for x in got] == want, (ty, w)
+    # out-of-range index: the reference asserts (bitpacking.rs:152)
+    with pytest.raises(fl.FastLanesError):
+        fl.BitPacking.unpack_single(3, to_dev(values(ty, packed_len(ty, 3), 1)),
+                                    torch.tensor([1024], dtype=torch.int64).cuda(), n_blocks=1)
+
+
+# ---------------------------------------------------------------------------
+# committed golden fixtures (no oracle involved at run time)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("ty", TYS)
+def test_golden_fixtures(fl, ty):
+    T = tbits(ty)
+    for w in range(T + 1):
+        i = case_inputs(ty, w)
+        g = GOLDEN["cases"][f"{ty}/{w}"]
+        dv, dpk, drefs, dbases = (to_dev(i[k]) for k in ("values", "packed", "refs", "bases"))
+        assert sha(to_np(fl.BitPacking.pack(w, dv), ty)) == g["pack"], (ty, w)
+        assert sha(to_np(fl.BitPacking.unpack(w, dpk, n_blocks=N_BLOCKS), ty)) == g["unpack"], (ty, w)
+        assert sha(to_np(fl.FoR.for_pack(w, dv, drefs), ty)) == g["for_pack"], (ty, w)
+        assert sha(to_np(fl.FoR.unfor_pack(w, dpk, drefs, n_blocks=N_BLOCKS), ty)) == g["unfor_pack"], (ty, w)
+        assert sha(to_np(fl.Delta.undelta_pack(w, dpk, dbases), ty)) == g["undelta_pack"], (ty, w)
+    i = case_inputs(ty, T)
+    g = GOLDEN["cases"][f"{ty}/misc"]
+    dv, dbases = to_dev(i["values"]), to_dev(i["bases"])
+    assert sha(to_np(fl.Delta.delta(dv, dbases), ty)) == g["delta"]
+    assert sha(to_np(fl.Delta.undelta(dv, dbases), ty)) == g["undelta"]
+    assert sha(to_np(fl.Transpose.transpose(dv), ty)) == g["transpose"]
+    assert sha(to_np(fl.Transpose.untranspose(dv), ty)) == g["untranspose"]
+
+
+def test_survey_known_answer_vectors(fl):
+    k = GOLDEN["survey_kats"]
+    v = (np.arange(1024) % 8).astype(np.uint16)
+    assert sha(to_np(fl.BitPacking.pack(3, to_dev(v)), "u16")) == k["KAT-2 u16 W=3 v[i]=i%8"]
+    v = np.arange(1024, dtype=np.uint32)
+    assert sha(to_np(fl.BitPacking.pack(10, to_dev(v)), "u32")) == k["KAT-3 u32 W=10 v[i]=i"]
+    v = (np.arange(1024) & 127).astype(np.uint32)
+    assert sha(to_np(fl.BitPacking.pack(7, to_dev(v)), "u32")) == k["KAT-4 u32 W=7 v[i]=i&127"]
+    v = np.array([(i * 2654435761) & 0x1FFFF for i in range(1024)], dtype=np.uint64)
+    assert sha(to_np(fl.BitPacking.pack(17, to_dev(v)), "u64")) == k["KAT-5 u64 W=17 v[i]=(i*2654435761)&0x1FFFF"]
+    # KAT-7: benches/delta.rs:15-27  transpose -> delta(base 0) -> pack W=9, fused decode returns transposed
+    v = (np.arange(1024) // 8).astype(np.uint16)
+    t = fl.Transpose.transpose(to_dev(v))
+    base = to_dev(np.zeros(64, dtype=np.uint16))
+    pk = fl.BitPacking.pack(9, fl.Delta.delta(t, base))
+    assert sha(to_np(pk, "u16")) == k["KAT-7 u16 W=9 delta bench"]
+    import torch
+    assert torch.equal(fl.Delta.undelta_pack(9, pk, base).view(torch.int16), t.view(torch.int16))
+    assert np.array_equal(to_np(fl.Transpose.untranspose(t), "u16"), v)
+
+
+# ---------------------------------------------------------------------------
+# reference unit tests, run against the GPU path through the host tier
+# ---------------------------------------------------------------------------
+def test_readme_example_host_tier(fl):
+    # README.md:14-47 / lib.rs:71-96
+    W = 3
+    v = np.array([i % (1 << W) for i in range(1024)], dtype=np.uint16)
+    pk = fl.BitPacking.unchecked_pack(W, v)
+    assert pk.size == 128 * W // 2
+    assert np.array_equal(fl.BitPacking.unchecked_unpack(W, pk), v)
+    for i in range(0, 1024, 41):
+        assert fl.BitPacking.unchecked_unpack_single(W, pk, i) == v[i]
+    with pytest.raises(fl.FastLanesError):
+        fl.BitPacking.unpack_single(W, pk, 1024)
+
+
+def test_reference_ffor_and_delta_tests_host_tier(fl):
+    # ffor.rs:66-88
+    W = 15
+    v = np.array([i % (1 << W) for i in range(1024)], dtype=np.uint16)
+    pk = fl.FoR.for_pack(W, v, 10)
+    assert np.array_equal(fl.BitPacking.unpack(W, pk), (v - np.uint16(10)) & np.uint16((1 << W) - 1))
+    assert np.array_equal(fl.FoR.unfor_pack(W, pk, 10), ((v - np.uint16(10)) & np.uint16(0x7FFF)) + np.uint16(10))
+    # delta.rs:80-107
+    v = (np.arange(1024) // 8).astype(np.uint16)
+    t = fl.Transpose.transpose(v)
+    zero = np.zeros(64, dtype=np.uint16)
+    pk = fl.BitPacking.pack(W, fl.Delta.delta(t, zero))
+    assert np.array_equal(fl.Delta.undelta_pack(W, pk, zero), t)
+    assert np.array_equal(fl.Delta.undelta(fl.BitPacking.unpack(W, pk), zero), t)
+
+
+@pytest.mark.parametrize("ty", TYS)
+def test_edge_cases(fl, ty):
+    import torch
+    T = tbits(ty)
+    dt = getattr(torch, {"u8": "uint8", "u16": "uint16", "u32": "uint32", "u64": "uint64"}[ty])
+    empty = torch.empty(0, dtype=dt, device="cuda:0")
+    assert fl.BitPacking.pack(3, empty).numel() == 0                      # empty column
+    assert fl.BitPacking.unpack(3, empty).numel() == 0
+    with pytest.raises(fl.FastLanesError):                                 # bitpacking.rs:93
+        fl.BitPacking.pack(T + 1, torch.zeros(1024, dtype=dt, device="cuda:0"))
+    with pytest.raises(ValueError):                                        # bitpacking.rs:79
+        fl.BitPacking.pack(3, torch.zeros(1000, dtype=dt, device="cuda:0"))
+    # width 0: pack writes nothing, unpack zero-fills (macros.rs:52-53,118-125)
+    out = torch.full((2048,), 1, dtype=torch.uint8, device="cuda:0").repeat(T // 8).view(dt)
+    fl.BitPacking.unpack(0, empty, output=out, n_blocks=2)
+    assert not out.view(torch.uint8).any()
+    # single block, and exactly one workgroup / one wavefront worth of blocks
+    for n in (1, 8, 32, 33):
+        v = values(ty, n * 1024, n, bits=T - 1)
+        d = to_dev(v)
+        rt = fl.BitPacking.unpack(T - 1, fl.BitPacking.pack(T - 1, d))
+        assert np.array_equal(to_np(rt, ty), v)
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json full sizes, through size-independent properties
+# ---------------------------------------------------------------------------
+def _rand_dev(nbytes, seed):
+    import torch
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(seed)
+    return torch.randint(-2**63, 2**63 - 1, (nbytes // 8,), dtype=torch.int64, device="cuda:0", generator=g)
+
+
+def _sample_blocks(n):
+    return sorted({0, 1, 31, 32, n // 2, n - 33, n - 2, n - 1})
+
+
+def test_config2_u32_w7_10M_blocks(fl, oracle):
+    """u32 W=7 unpack, 10 M blocks: pack(unpack(x)) == x for EVERY packed x (all bit
+    patterns are valid packed data), plus oracle comparison of sampled blocks."""
+    import torch
+    n = 10_000_000
+    pk = _rand_dev(n * 896, 42).view(torch.uint32)
+    out = fl.BitPacking.unpack(7, pk)
+    assert out.numel() == n * 1024
+    assert int(out.view(torch.int32).max()) <= 127 and int(out.view(torch.int32).min()) >= 0
+    back = fl.BitPacking.pack(7, out)
+    assert torch.equal(back.view(torch.int32), pk.view(torch.int32))
+    for b in _sample_blocks(n):
+        got = to_np(out[b * 1024:(b + 1) * 1024], "u32")
+        assert np.array_equal(got, oracle.unpack("u32", 7, to_np(pk[b * 224:(b + 1) * 224], "u32"))), b
+
+
+def test_config3_u64_w17_10M_blocks(fl, oracle):
+    import torch
+    n = 10_000_000
+    pk = _rand_dev(n * 2176, 43).view(torch.uint64)
+    out = fl.BitPacking.unpack(17, pk)
+    back = fl.BitPacking.pack(17, out)
+    assert torch.equal(back.view(torch.int64), pk.view(torch.int64))
+    assert int(out.view(torch.int64).max()) < (1 << 17) and int(out.view(torch.int64).min()) >= 0
+    for b in _sample_blocks(n):
+        got = to_np(out[b * 1024:(b + 1) * 1024], "u64")
+        assert np.array_equal(got, oracle.unpack("u64", 17, to_np(pk[b * 272:(b + 1) * 272], "u64"))), b
+
+
+def test_config4_fused_delta_u32_w12_10M_blocks(fl, oracle):
+    import torch
+    n = 10_000_000
+    pk = _rand_dev(n * 1536, 44).view(torch.uint32)
+    bases = _rand_dev(n * 128, 45).view(torch.uint32)
+    fused = fl.Delta.undelta_pack(12, pk, bases)
+    unfused = fl.Delta.undelta(fl.BitPacking.unpack(12, pk), bases)           # benches/delta.rs:29-43
+    assert torch.equal(fused.view(torch.int32), unfused.view(torch.int32))
+    del unfused
+    # delta() inverts it, and re-packing the deltas gives the input back
+    back = fl.BitPacking.pack(12, fl.Delta.delta(fused, bases))
+    assert torch.equal(back.view(torch.int32), pk.view(torch.int32))
+    for b in _sample_blocks(n):
+        got = to_np(fused[b * 1024:(b + 1) * 1024], "u32")
+        want = oracle.undelta_pack("u32", 12, to_np(pk[b * 384:(b + 1) * 384], "u32"),
+                                   to_np(bases[b * 32:(b + 1) * 32], "u32"))
+        assert np.array_equal(got, want), b
