@@ -1,0 +1,11 @@
+set -x
+mkdir -p gpurun_out
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log
+tail -3 gpurun_out/smoke.log
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
+tail -15 gpurun_out/pytest_gpu.log
+timeout 600 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"
+cat gpurun_out/bench.json; tail -5 gpurun_out/bench.err
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_r01 -o bench -- python /root/repo/bench.py --steps 10 --no-cpu-baseline > /root/repo/gpurun_out/prof_bench.log 2>&1; echo "rocprof rc=$?"
+ls -R /root/repo/gpurun_out/prof_r01 | head -30
