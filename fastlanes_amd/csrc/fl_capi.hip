@@ -33,6 +33,7 @@ int run_stream(stream_launch_t fn, const T* in, T* out, const void* aux, size_t 
     a.aux = aux;
     a.aux_stride = aux_stride;
     a.n_blocks = n_blocks;
+    a.tiles_per_xcd = 0;   // filled by the launcher
     hipError_t e = fn(a, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }

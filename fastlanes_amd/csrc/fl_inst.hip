@@ -6,34 +6,29 @@
 #include "fl_kernels.hpp"
 #include "fl_misc.hpp"
 
-#ifndef FL_STREAM_NT
-#define FL_STREAM_NT 0
-#endif
-
 namespace fl {
 using T = FL_T;
-constexpr bool kNT = FL_STREAM_NT != 0;
 using Ws = std::make_integer_sequence<int, Elem<T>::BITS + 1>;
 
 #if FL_FAMILY == 0
-static constexpr WidthTable<T> t_store = make_unpack_table<T, BODY_STORE, kNT>(Ws{});
+static constexpr WidthTable<T> t_store = make_unpack_table<T, BODY_STORE>(Ws{});
 template <> const WidthTable<T>& unpack_table_impl<T, BODY_STORE>() { return t_store; }
 #elif FL_FAMILY == 1
-static constexpr WidthTable<T> t_addref = make_unpack_table<T, BODY_ADD_REF, kNT>(Ws{});
+static constexpr WidthTable<T> t_addref = make_unpack_table<T, BODY_ADD_REF>(Ws{});
 template <> const WidthTable<T>& unpack_table_impl<T, BODY_ADD_REF>() { return t_addref; }
 #elif FL_FAMILY == 2
-static constexpr WidthTable<T> t_undelta = make_unpack_table<T, BODY_UNDELTA, kNT>(Ws{});
+static constexpr WidthTable<T> t_undelta = make_unpack_table<T, BODY_UNDELTA>(Ws{});
 template <> const WidthTable<T>& unpack_table_impl<T, BODY_UNDELTA>() { return t_undelta; }
 #elif FL_FAMILY == 3
-static constexpr WidthTable<T> t_pack = make_pack_table<T, false, kNT>(Ws{});
+static constexpr WidthTable<T> t_pack = make_pack_table<T, false>(Ws{});
 template <> const WidthTable<T>& pack_table_impl<T, false>() { return t_pack; }
 #elif FL_FAMILY == 4
-static constexpr WidthTable<T> t_forpack = make_pack_table<T, true, kNT>(Ws{});
+static constexpr WidthTable<T> t_forpack = make_pack_table<T, true>(Ws{});
 template <> const WidthTable<T>& pack_table_impl<T, true>() { return t_forpack; }
 #elif FL_FAMILY == 5
 template <> stream_launch_t delta_launcher<T>(bool inverse)
 {
-    return inverse ? &launch_delta<T, true, kNT> : &launch_delta<T, false, kNT>;
+    return inverse ? &launch_delta<T, true> : &launch_delta<T, false>;
 }
 template <> stream_launch_t transpose_launcher<T>(bool inverse)
 {

@@ -5,13 +5,13 @@
 // Thread mapping: global thread g -> block g/8, cell column g%8 (fl_device.hpp).
 // Every kernel is a pure stream: each input byte is read once, each output byte
 // written once, 16 B per lane per access; no LDS, no cross-lane traffic, no
-// inter-workgroup communication.
+// inter-workgroup communication (XCD placement is used for speed only).
 #pragma once
 #include "fl_device.hpp"
 
 namespace fl {
 
-constexpr int WG = 256;             // 4 wavefronts; 32 blocks per workgroup
+constexpr int WG = 256;             // 4 wavefronts; 32 blocks ("one tile") per workgroup
 constexpr int BLOCKS_PER_WG = WG / 8;
 
 enum UnpackBody { BODY_STORE = 0, BODY_ADD_REF = 1, BODY_UNDELTA = 2 };
@@ -23,97 +23,158 @@ struct StreamArgs {
     const void* aux;       // references [n_blocks*aux_stride] or bases [n_blocks][LANES]
     uint64_t aux_stride;   // FoR: 0 = one scalar for all blocks, 1 = one per block
     uint64_t n_blocks;
+    uint64_t tiles_per_xcd;   // ceil(ceil(n_blocks/32) / 8)
+};
+
+// ---------------------------------------------------------------------------
+// Streaming policy, fixed by measurement on MI355X (profiles/abbench_r01*.txt):
+//  * XCD-contiguous tiles: workgroup b runs on XCD b%8 (observed dispatch order,
+//    used for speed only), so XCD x is handed the contiguous eighth
+//    [x*tiles_per_xcd, (x+1)*tiles_per_xcd) of the column instead of every 8th
+//    tile: +1..11 % (each XCD's L2/fabric path sees one dense stream).
+//  * Stores are write-through, non-temporal (`sc1 nt`, buffer-store aux 18):
+//    output is never re-read, so lines should not linger dirty in L2: +6..7 %.
+//  * Few waves in flight: 2 waves/SIMD (unpack) or 1 (pack, which already has
+//    T x 16 B of loads in flight per lane) beat full occupancy by 2..4 % --
+//    fewer concurrent DRAM streams.  Enforced with amdgpu_waves_per_eu.
+//  * Loads are non-temporal when the read side is large (pack; unpack W >= T/2).
+// ---------------------------------------------------------------------------
+constexpr int STORE_AUX = 18;   // nt (2) | sc1 (16)
+
+template <typename T, int W> struct UnpackPolicy {
+    static constexpr int MAXW = 2;
+    static constexpr bool NT_LOAD = (2 * W >= Elem<T>::BITS);
+};
+template <typename T> struct PackPolicy {
+    static constexpr int MAXW = sizeof(T) >= 4 ? 1 : 2;
+    static constexpr bool NT_LOAD = true;
+};
+
+// Tile (workgroup) index under the XCD-contiguous map; returns false for padding workgroups.
+__device__ __forceinline__ bool tile_of_workgroup(const StreamArgs& a, uint64_t& tile)
+{
+    const uint64_t n_tiles = (a.n_blocks + BLOCKS_PER_WG - 1) / BLOCKS_PER_WG;
+    tile = (uint64_t)(blockIdx.x & 7u) * a.tiles_per_xcd + (blockIdx.x >> 3);
+    return tile < n_tiles;
+}
+
+// Write-through streaming store window over one tile's output (wave-uniform descriptor).
+template <int BLOCK_BYTES> struct TileStore {
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned vo;
+    __device__ __forceinline__ TileStore(u32x4* out, uint64_t tile, uint64_t n_blocks, unsigned tid)
+    {
+        const uint64_t rem = n_blocks - tile * BLOCKS_PER_WG;
+        const unsigned nrec = (unsigned)(rem < BLOCKS_PER_WG ? rem : BLOCKS_PER_WG) * BLOCK_BYTES;
+        char* base = reinterpret_cast<char*>(out) + tile * (uint64_t)(BLOCKS_PER_WG * BLOCK_BYTES);
+        rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, nrec, 0x00020000);
+        vo = (tid >> 3) * BLOCK_BYTES + (tid & 7u) * 16;
+    }
+    template <typename T> __device__ __forceinline__ void store(unsigned cell_in_block, const Cell<T>& v) const
+    {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, vo + 16 * cell_in_block, 0, STORE_AUX);
+    }
 };
 
 // unpack / unfor_pack / undelta_pack  (bitpacking.rs:98-107, ffor.rs:38-50,
 // delta.rs:47-63): packed W cell-rows -> T cell-rows.
-template <typename T, int W, int BODY, bool NT>
-__global__ __launch_bounds__(WG) void k_unpack(StreamArgs a)
+template <typename T, int W, int BODY>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, UnpackPolicy<T, W>::MAXW)))
+void k_unpack(StreamArgs a)
 {
-    constexpr int TB = Elem<T>::BITS;
-    const uint64_t g = (uint64_t)blockIdx.x * WG + threadIdx.x;
-    const uint64_t blk = g >> 3;
-    const unsigned c = (unsigned)g & 7u;
+    constexpr bool NTL = UnpackPolicy<T, W>::NT_LOAD;
+    uint64_t tile;
+    if (!tile_of_workgroup(a, tile)) return;
+    const unsigned tid = threadIdx.x;
+    const uint64_t blk = tile * BLOCKS_PER_WG + (tid >> 3);
+    const unsigned c = tid & 7u;
     if (blk >= a.n_blocks) return;
 
     Cell<T> in[W ? W : 1];
     const u32x4* pk = a.in + blk * (uint64_t)(8 * W) + c;
-    static_for<W>([&](auto Wd) { in[decltype(Wd)::value] = load_cell<T, NT>(pk + 8 * decltype(Wd)::value); });
+    static_for<W>([&](auto Wd) { in[decltype(Wd)::value] = load_cell<T, NTL>(pk + 8 * decltype(Wd)::value); });
 
-    u32x4* un = a.out + blk * (uint64_t)Elem<T>::CELLS_PER_BLOCK + c;
+    const TileStore<Elem<T>::CELLS_PER_BLOCK * 16> st(a.out, tile, a.n_blocks, tid);
     if constexpr (BODY == BODY_STORE) {
         unpack_rows<T, W>(in, [&](auto R, const Cell<T>& v) {
-            store_cell<T, NT>(un + Elem<T>::row_cell(decltype(R)::value), v);   // bitpacking.rs:103-105
+            st.store(Elem<T>::row_cell(decltype(R)::value), v);                 // bitpacking.rs:103-105
         });
     } else if constexpr (BODY == BODY_ADD_REF) {
         const T* refs = static_cast<const T*>(a.aux);
         const Cell<T> ref = Cell<T>::splat(refs[blk * a.aux_stride]);
         unpack_rows<T, W>(in, [&](auto R, const Cell<T>& v) {
-            store_cell<T, NT>(un + Elem<T>::row_cell(decltype(R)::value), v.add(ref));   // ffor.rs:46-48
+            st.store(Elem<T>::row_cell(decltype(R)::value), v.add(ref));        // ffor.rs:46-48
         });
     } else {
         // base[lane] for this column's lanes = cell c of the block's 128-byte base row
         const u32x4* bases = static_cast<const u32x4*>(a.aux);
-        Cell<T> prev = load_cell<T, NT>(bases + blk * 8 + c);                  // delta.rs:56
+        Cell<T> prev = load_cell<T, false>(bases + blk * 8 + c);                // delta.rs:56
         unpack_rows<T, W>(in, [&](auto R, const Cell<T>& v) {
-            prev = v.add(prev);                                               // delta.rs:58-60
-            store_cell<T, NT>(un + Elem<T>::row_cell(decltype(R)::value), prev);
+            prev = v.add(prev);                                                 // delta.rs:58-60
+            st.store(Elem<T>::row_cell(decltype(R)::value), prev);
         });
     }
 }
 
 // pack / for_pack  (bitpacking.rs:65-74, ffor.rs:24-36): T cell-rows -> W cell-rows.
-template <typename T, int W, bool FOR, bool NT>
-__global__ __launch_bounds__(WG) void k_pack(StreamArgs a)
+template <typename T, int W, bool FOR>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, PackPolicy<T>::MAXW)))
+void k_pack(StreamArgs a)
 {
     constexpr int TB = Elem<T>::BITS;
-    const uint64_t g = (uint64_t)blockIdx.x * WG + threadIdx.x;
-    const uint64_t blk = g >> 3;
-    const unsigned c = (unsigned)g & 7u;
+    constexpr bool NTL = PackPolicy<T>::NT_LOAD;
+    uint64_t tile;
+    if (!tile_of_workgroup(a, tile)) return;
+    const unsigned tid = threadIdx.x;
+    const uint64_t blk = tile * BLOCKS_PER_WG + (tid >> 3);
+    const unsigned c = tid & 7u;
     if (blk >= a.n_blocks) return;
-    if constexpr (W == 0) return;                                             // macros.rs:52-53
+    if constexpr (W == 0) return;                                               // macros.rs:52-53
 
     const u32x4* un = a.in + blk * (uint64_t)Elem<T>::CELLS_PER_BLOCK + c;
-    u32x4* pk = a.out + blk * (uint64_t)(8 * W) + c;
     Cell<T> ref = Cell<T>::zero();
     if constexpr (FOR) ref = Cell<T>::splat(static_cast<const T*>(a.aux)[blk * a.aux_stride]);
 
     // Issue all T row loads up front (they are independent), then combine.
     Cell<T> rows[TB];
     static_for<TB>([&](auto R) {
-        rows[decltype(R)::value] = load_cell<T, NT>(un + Elem<T>::row_cell(decltype(R)::value));
+        rows[decltype(R)::value] = load_cell<T, NTL>(un + Elem<T>::row_cell(decltype(R)::value));
     });
+    const TileStore<(W ? W : 1) * 128> st(a.out, tile, a.n_blocks, tid);
     pack_rows<T, W>(
         [&](auto R) {
-            if constexpr (FOR) return rows[decltype(R)::value].sub(ref);      // ffor.rs:32-34
-            else return rows[decltype(R)::value];                             // bitpacking.rs:70-72
+            if constexpr (FOR) return rows[decltype(R)::value].sub(ref);        // ffor.rs:32-34
+            else return rows[decltype(R)::value];                               // bitpacking.rs:70-72
         },
-        [&](auto Wd, const Cell<T>& v) { store_cell<T, NT>(pk + 8 * decltype(Wd)::value, v); });
+        [&](auto Wd, const Cell<T>& v) { st.store(8 * decltype(Wd)::value, v); });
 }
 
 // delta / undelta  (delta.rs:24-45): T cell-rows -> T cell-rows, per-lane chain.
-template <typename T, bool INVERSE, bool NT>
-__global__ __launch_bounds__(WG) void k_delta(StreamArgs a)
+template <typename T, bool INVERSE>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, PackPolicy<T>::MAXW)))
+void k_delta(StreamArgs a)
 {
     constexpr int TB = Elem<T>::BITS;
-    const uint64_t g = (uint64_t)blockIdx.x * WG + threadIdx.x;
-    const uint64_t blk = g >> 3;
-    const unsigned c = (unsigned)g & 7u;
+    uint64_t tile;
+    if (!tile_of_workgroup(a, tile)) return;
+    const unsigned tid = threadIdx.x;
+    const uint64_t blk = tile * BLOCKS_PER_WG + (tid >> 3);
+    const unsigned c = tid & 7u;
     if (blk >= a.n_blocks) return;
     const u32x4* src = a.in + blk * (uint64_t)Elem<T>::CELLS_PER_BLOCK + c;
-    u32x4* dst = a.out + blk * (uint64_t)Elem<T>::CELLS_PER_BLOCK + c;
-    Cell<T> prev = load_cell<T, NT>(static_cast<const u32x4*>(a.aux) + blk * 8 + c);
+    Cell<T> prev = load_cell<T, false>(static_cast<const u32x4*>(a.aux) + blk * 8 + c);
     Cell<T> rows[TB];
     static_for<TB>([&](auto R) {
-        rows[decltype(R)::value] = load_cell<T, NT>(src + Elem<T>::row_cell(decltype(R)::value));
+        rows[decltype(R)::value] = load_cell<T, true>(src + Elem<T>::row_cell(decltype(R)::value));
     });
+    const TileStore<Elem<T>::CELLS_PER_BLOCK * 16> st(a.out, tile, a.n_blocks, tid);
     static_for<TB>([&](auto R) {
         constexpr int row = decltype(R)::value;
         if constexpr (INVERSE) {
-            prev = rows[row].add(prev);                                       // delta.rs:40-42
-            store_cell<T, NT>(dst + Elem<T>::row_cell(row), prev);
+            prev = rows[row].add(prev);                                         // delta.rs:40-42
+            st.store(Elem<T>::row_cell(row), prev);
         } else {
-            store_cell<T, NT>(dst + Elem<T>::row_cell(row), rows[row].sub(prev));   // delta.rs:28-30
+            st.store(Elem<T>::row_cell(row), rows[row].sub(prev));              // delta.rs:28-30
             prev = rows[row];
         }
     });
@@ -124,42 +185,54 @@ __global__ __launch_bounds__(WG) void k_delta(StreamArgs a)
 // ---------------------------------------------------------------------------
 typedef hipError_t (*stream_launch_t)(const StreamArgs&, hipStream_t);
 
-inline unsigned grid_for(uint64_t n_blocks) { return (unsigned)((n_blocks + BLOCKS_PER_WG - 1) / BLOCKS_PER_WG); }
+// grid = 8 XCD slots x tiles_per_xcd (padding workgroups exit immediately)
+inline unsigned plan_grid(StreamArgs& a)
+{
+    const uint64_t n_tiles = (a.n_blocks + BLOCKS_PER_WG - 1) / BLOCKS_PER_WG;
+    a.tiles_per_xcd = (n_tiles + 7) / 8;
+    return (unsigned)(a.tiles_per_xcd * 8);
+}
 
-template <typename T, int W, int BODY, bool NT>
-hipError_t launch_unpack(const StreamArgs& a, hipStream_t s)
+template <typename T, int W, int BODY>
+hipError_t launch_unpack(const StreamArgs& a0, hipStream_t s)
 {
-    if (a.n_blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL((k_unpack<T, W, BODY, NT>), dim3(grid_for(a.n_blocks)), dim3(WG), 0, s, a);
+    if (a0.n_blocks == 0) return hipSuccess;
+    StreamArgs a = a0;
+    const unsigned grid = plan_grid(a);
+    hipLaunchKernelGGL((k_unpack<T, W, BODY>), dim3(grid), dim3(WG), 0, s, a);
     return hipGetLastError();
 }
-template <typename T, int W, bool FOR, bool NT>
-hipError_t launch_pack(const StreamArgs& a, hipStream_t s)
+template <typename T, int W, bool FOR>
+hipError_t launch_pack(const StreamArgs& a0, hipStream_t s)
 {
-    if (a.n_blocks == 0 || W == 0) return hipSuccess;
-    hipLaunchKernelGGL((k_pack<T, W, FOR, NT>), dim3(grid_for(a.n_blocks)), dim3(WG), 0, s, a);
+    if (a0.n_blocks == 0 || W == 0) return hipSuccess;
+    StreamArgs a = a0;
+    const unsigned grid = plan_grid(a);
+    hipLaunchKernelGGL((k_pack<T, W, FOR>), dim3(grid), dim3(WG), 0, s, a);
     return hipGetLastError();
 }
-template <typename T, bool INVERSE, bool NT>
-hipError_t launch_delta(const StreamArgs& a, hipStream_t s)
+template <typename T, bool INVERSE>
+hipError_t launch_delta(const StreamArgs& a0, hipStream_t s)
 {
-    if (a.n_blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL((k_delta<T, INVERSE, NT>), dim3(grid_for(a.n_blocks)), dim3(WG), 0, s, a);
+    if (a0.n_blocks == 0) return hipSuccess;
+    StreamArgs a = a0;
+    const unsigned grid = plan_grid(a);
+    hipLaunchKernelGGL((k_delta<T, INVERSE>), dim3(grid), dim3(WG), 0, s, a);
     return hipGetLastError();
 }
 
 // Runtime width -> instance table, index 0..T inclusive.
 template <typename T> struct WidthTable { stream_launch_t fn[Elem<T>::BITS + 1]; };
 
-template <typename T, int BODY, bool NT, int... Ws>
+template <typename T, int BODY, int... Ws>
 constexpr WidthTable<T> make_unpack_table(std::integer_sequence<int, Ws...>)
 {
-    return WidthTable<T>{{&launch_unpack<T, Ws, BODY, NT>...}};
+    return WidthTable<T>{{&launch_unpack<T, Ws, BODY>...}};
 }
-template <typename T, bool FOR, bool NT, int... Ws>
+template <typename T, bool FOR, int... Ws>
 constexpr WidthTable<T> make_pack_table(std::integer_sequence<int, Ws...>)
 {
-    return WidthTable<T>{{&launch_pack<T, Ws, FOR, NT>...}};
+    return WidthTable<T>{{&launch_pack<T, Ws, FOR>...}};
 }
 
 // Specialised once per (element type, family) in fl_inst.hip

@@ -1,0 +1,306 @@
+// abbench.hip -- within-process interleaved A/B of launch-shape / cache-policy variants
+// of the u32 W=7 unpack kernel, next to plain read / write / copy streams of the same
+// byte mix (the in-situ ceilings).  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17
+// -I fastlanes_amd/csrc tools/abbench.hip -o tools/abbench ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <vector>
+#include "fl_device.hpp"
+
+using namespace fl;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+struct Args { const u32x4* in; u32x4* out; uint64_t n_blocks; };
+
+// MODE: 0 one-shot, 1 grid-stride, 2 XCD-contiguous remap (blockIdx%8 selects one of 8 contiguous chunks)
+template <typename T, int W, int WGS, bool NTL, bool NTS, int MODE>
+__global__ __launch_bounds__(WGS) void k_unpack_v(Args a)
+{
+    constexpr int BPW = WGS / 8;
+    const uint64_t n_wg = (a.n_blocks + BPW - 1) / BPW;
+    uint64_t wg = blockIdx.x;
+    if (MODE == 2) {
+        const uint64_t per = (n_wg + 7) / 8;
+        wg = (uint64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if (wg >= n_wg || (blockIdx.x >> 3) >= per) return;
+    }
+    for (; wg < n_wg; wg += (MODE == 1 ? gridDim.x : n_wg)) {
+        const uint64_t blk = wg * BPW + (threadIdx.x >> 3);
+        const unsigned c = threadIdx.x & 7u;
+        if (blk < a.n_blocks) {
+            Cell<T> in[W];
+            const u32x4* pk = a.in + blk * (uint64_t)(8 * W) + c;
+            static_for<W>([&](auto Wd) { in[decltype(Wd)::value] = load_cell<T, NTL>(pk + 8 * decltype(Wd)::value); });
+            u32x4* un = a.out + blk * (uint64_t)Elem<T>::CELLS_PER_BLOCK + c;
+            unpack_rows<T, W>(in, [&](auto R, const Cell<T>& v) {
+                store_cell<T, NTS>(un + Elem<T>::row_cell(decltype(R)::value), v);
+            });
+        }
+    }
+}
+
+// CHUNK-granular XCD remap + buffer-store cache policy (AUX: 0 plain, 1 sc0, 2 nt, 16 sc1, combos; -1 = global store)
+// blockIdx b runs on XCD b%8 (observed).  Remap so that each XCD owns runs of K consecutive workgroups:
+//   wg = (b / (8K)) * 8K + (b % 8) * K + (b / 8) % K
+template <typename T, int W, int AUX, int LAUX, int MAXW = 8>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, MAXW))) void k_unpack_x(Args a, unsigned K)
+{
+    constexpr int BPW = 32;
+    const uint64_t n_wg = (a.n_blocks + BPW - 1) / BPW;
+    const uint64_t b = blockIdx.x;
+    uint64_t wg = b;
+    if (K > 1) {
+        const uint64_t span = 8ull * K;                   // grid is rounded up to whole spans
+        wg = (b / span) * span + (b % 8) * K + (b / 8) % K;
+    }
+    if (wg >= n_wg) return;
+    const unsigned tid = threadIdx.x;
+    const uint64_t blk = wg * BPW + (tid >> 3);
+    const unsigned c = tid & 7u;
+    if (blk >= a.n_blocks) return;
+    Cell<T> in[W];
+    if constexpr (LAUX < 0) {
+        const u32x4* pk = a.in + blk * (uint64_t)(8 * W) + c;
+        static_for<W>([&](auto Wd) { in[decltype(Wd)::value] = load_cell<T, false>(pk + 8 * decltype(Wd)::value); });
+    } else {
+        const u32x4* wg_in = a.in + wg * (uint64_t)(BPW * 8 * W);
+        auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)wg_in, 0, BPW * 128 * W, 0x00020000);
+        const unsigned vo = (tid >> 3) * (128 * W) + c * 16;
+        static_for<W>([&](auto Wd) {
+            in[decltype(Wd)::value] = __builtin_bit_cast(Cell<T>, __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 128 * decltype(Wd)::value, 0, LAUX));
+        });
+    }
+    if constexpr (AUX < 0) {
+        u32x4* un = a.out + blk * (uint64_t)Elem<T>::CELLS_PER_BLOCK + c;
+        unpack_rows<T, W>(in, [&](auto R, const Cell<T>& v) { store_cell<T, false>(un + Elem<T>::row_cell(decltype(R)::value), v); });
+    } else {
+        u32x4* wg_out = a.out + wg * (uint64_t)(BPW * Elem<T>::CELLS_PER_BLOCK);
+        auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)wg_out, 0, BPW * Elem<T>::CELLS_PER_BLOCK * 16, 0x00020000);
+        const unsigned vo = (tid >> 3) * (Elem<T>::CELLS_PER_BLOCK * 16) + c * 16;
+        unpack_rows<T, W>(in, [&](auto R, const Cell<T>& v) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, vo + 16 * Elem<T>::row_cell(decltype(R)::value), 0, AUX);
+        });
+    }
+}
+
+template <typename T, int W, int AUX, int LAUX, int MAXW = 8>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, MAXW))) void k_pack_x(Args a, unsigned K)
+{
+    constexpr int BPW = 32;
+    constexpr int TB = Elem<T>::BITS;
+    const uint64_t b = blockIdx.x;
+    uint64_t wg = b;
+    if (K > 1) { const uint64_t span = 8ull * K; wg = (b / span) * span + (b % 8) * K + (b / 8) % K; }
+    const uint64_t n_wg = (a.n_blocks + BPW - 1) / BPW;
+    if (wg >= n_wg) return;
+    const unsigned tid = threadIdx.x;
+    const uint64_t blk = wg * BPW + (tid >> 3);
+    const unsigned c = tid & 7u;
+    if (blk >= a.n_blocks) return;
+    Cell<T> rows[TB];
+    if constexpr (LAUX < 0) {
+        const u32x4* un = a.in + blk * (uint64_t)Elem<T>::CELLS_PER_BLOCK + c;
+        static_for<TB>([&](auto R) { rows[decltype(R)::value] = load_cell<T, false>(un + Elem<T>::row_cell(decltype(R)::value)); });
+    } else {
+        const u32x4* wg_in = a.in + wg * (uint64_t)(BPW * Elem<T>::CELLS_PER_BLOCK);
+        auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)wg_in, 0, BPW * Elem<T>::CELLS_PER_BLOCK * 16, 0x00020000);
+        const unsigned vo = (tid >> 3) * (Elem<T>::CELLS_PER_BLOCK * 16) + c * 16;
+        static_for<TB>([&](auto R) {
+            rows[decltype(R)::value] = __builtin_bit_cast(Cell<T>, __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 16 * Elem<T>::row_cell(decltype(R)::value), 0, LAUX));
+        });
+    }
+    u32x4* wg_out = a.out + wg * (uint64_t)(BPW * 8 * W);
+    auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)wg_out, 0, BPW * 128 * W, 0x00020000);
+    const unsigned vo = (tid >> 3) * (128 * W) + c * 16;
+    u32x4* pk = a.out + blk * (uint64_t)(8 * W) + c;
+    pack_rows<T, W>([&](auto R) { return rows[decltype(R)::value]; },
+                    [&](auto Wd, const Cell<T>& v) {
+                        if constexpr (AUX < 0) store_cell<T, false>(pk + 8 * decltype(Wd)::value, v);
+                        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, vo + 128 * decltype(Wd)::value, 0, AUX);
+                    });
+}
+
+// Persistent XCD-aware stream: grid = 8 * wgs_per_xcd resident workgroups; XCD x (= blockIdx%8) owns the
+// contiguous eighth [x*per, (x+1)*per) of the workgroup-tiles and its workgroups stride through it together,
+// so each XCD's in-flight window is wgs_per_xcd consecutive 128-KiB tiles.  Next tile's packed words are
+// prefetched before the current tile's stores are issued (vmcnt is in-order for loads and stores).
+template <typename T, int W, int AUX, bool PREFETCH>
+__global__ __launch_bounds__(256) void k_unpack_p(Args a, unsigned wgs_per_xcd)
+{
+    constexpr int BPW = 32;
+    const uint64_t n_wg = (a.n_blocks + BPW - 1) / BPW;
+    const uint64_t per = (n_wg + 7) / 8;
+    const unsigned x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const uint64_t lo = x * per, hi = (lo + per < n_wg) ? lo + per : n_wg;
+    const unsigned tid = threadIdx.x;
+    const unsigned c = tid & 7u;
+    uint64_t wg = lo + j;
+    if (wg >= hi) return;
+    Cell<T> cur[W], nxt[W];
+    auto load_tile = [&](uint64_t w_, Cell<T>* dst) {
+        const uint64_t blk = w_ * BPW + (tid >> 3);
+        if (blk < a.n_blocks) {
+            const u32x4* pk = a.in + blk * (uint64_t)(8 * W) + c;
+            static_for<W>([&](auto Wd) { dst[decltype(Wd)::value] = load_cell<T, false>(pk + 8 * decltype(Wd)::value); });
+        }
+    };
+    load_tile(wg, cur);
+    for (; wg < hi; wg += wgs_per_xcd) {
+        const uint64_t nw = wg + wgs_per_xcd;
+        if (PREFETCH && nw < hi) load_tile(nw, nxt);
+        const uint64_t blk = wg * BPW + (tid >> 3);
+        if (blk < a.n_blocks) {
+            u32x4* wg_out = a.out + wg * (uint64_t)(BPW * Elem<T>::CELLS_PER_BLOCK);
+            auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)wg_out, 0, BPW * Elem<T>::CELLS_PER_BLOCK * 16, 0x00020000);
+            const unsigned vo = (tid >> 3) * (Elem<T>::CELLS_PER_BLOCK * 16) + c * 16;
+            unpack_rows<T, W>(cur, [&](auto R, const Cell<T>& v) {
+                if constexpr (AUX < 0) store_cell<T, false>(wg_out + (tid >> 3) * Elem<T>::CELLS_PER_BLOCK + c + Elem<T>::row_cell(decltype(R)::value), v);
+                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, vo + 16 * Elem<T>::row_cell(decltype(R)::value), 0, AUX);
+            });
+        }
+        if (nw < hi) {
+            if (PREFETCH) { static_for<W>([&](auto Wd) { cur[decltype(Wd)::value] = nxt[decltype(Wd)::value]; }); }
+            else load_tile(nw, cur);
+        }
+    }
+}
+
+// plain streams with the same per-thread shape: RD cells read, WR cells written per thread
+template <int RD, int WR, bool NT>
+__global__ __launch_bounds__(256) void k_stream(const u32x4* in, u32x4* out, uint64_t n_threads, u32x4* sink)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_threads) return;
+    const uint64_t wave = g >> 6; const unsigned lane = g & 63;
+    u32x4 acc = {0, 0, 0, 0};
+    // wave-contiguous 1 KiB accesses
+#pragma unroll
+    for (int i = 0; i < RD; ++i) {
+        const u32x4* p = in + (wave * RD + i) * 64 + lane;
+        acc += NT ? __builtin_nontemporal_load(p) : *p;
+    }
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+        u32x4 v = acc + (unsigned)i;
+        u32x4* p = out + (wave * WR + i) * 64 + lane;
+        if (NT) __builtin_nontemporal_store(v, p); else *p = v;
+    }
+    if (WR == 0 && acc.x == 0x12345678u) *sink = acc;
+}
+
+__global__ void k_fill(uint64_t* p, uint64_t n);
+
+struct Variant { std::string name; double bytes; std::function<void()> launch; std::vector<float> ms; };
+
+int main(int argc, char** argv)
+{
+    const uint64_t n = argc > 1 ? strtoull(argv[1], 0, 10) : 10000000ull;
+    const int rounds = argc > 2 ? atoi(argv[2]) : 7;
+    u32x4 *in, *out, *sink;
+    CK(hipMalloc(&in, n * 1088 + (128 << 20)));
+    CK(hipMalloc(&out, n * 4096 + (512 << 20)));
+    CK(hipMalloc(&sink, 64));
+    // random fill on device (never zero data: DVFS)
+    hipLaunchKernelGGL(k_fill, dim3(65536), dim3(256), 0, 0, (uint64_t*)in, (n * 1088 + (128 << 20)) / 8);
+    hipLaunchKernelGGL(k_fill, dim3(65536), dim3(256), 0, 0, (uint64_t*)out, n * 4096 / 8);
+    CK(hipDeviceSynchronize());
+
+    Args a{in, out, n};
+    std::vector<Variant> vs;
+    const double bytes = (double)n * 4992;
+    const uint64_t n_wg0 = (n + 31) / 32;
+    const unsigned G = (unsigned)((n_wg0 + 7) / 8);   // giant chunk: one contiguous eighth per XCD
+    auto addX = [&](const std::string& name, auto kern, unsigned K, Args aa, double by, unsigned lds) {
+        uint64_t n_wg = n_wg0;
+        if (K > 1) n_wg = (n_wg + 8ull * K - 1) / (8ull * K) * (8ull * K);
+        vs.push_back({name, by, [=]() { hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), lds, 0, aa, K); }, {}});
+    };
+    Args ap{out, in, n};
+    addX("unpack u32w7 base", k_unpack_x<uint32_t, 7, -1, -1>, 1, a, bytes, 0);
+    addX("unpack u32w7 G st18", k_unpack_x<uint32_t, 7, 18, -1>, G, a, bytes, 0);
+    addX("unpack u32w7 G st18 occ2(lds)", k_unpack_x<uint32_t, 7, 18, -1>, G, a, bytes, 160 * 1024 / 2 - 1024);
+    addX("unpack u32w7 G st18 maxw1", k_unpack_x<uint32_t, 7, 18, -1, 1>, G, a, bytes, 0);
+    addX("unpack u32w7 G st18 maxw2", k_unpack_x<uint32_t, 7, 18, -1, 2>, G, a, bytes, 0);
+    addX("unpack u32w7 G st18 maxw3", k_unpack_x<uint32_t, 7, 18, -1, 3>, G, a, bytes, 0);
+    addX("unpack u32w7 G st18 maxw4", k_unpack_x<uint32_t, 7, 18, -1, 4>, G, a, bytes, 0);
+    addX("pack u32w7 base", k_pack_x<uint32_t, 7, -1, -1>, 1, ap, bytes, 0);
+    addX("pack u32w7 G st18 ldnt", k_pack_x<uint32_t, 7, 18, 2>, G, ap, bytes, 0);
+    addX("pack u32w7 G st18 ldnt maxw1", k_pack_x<uint32_t, 7, 18, 2, 1>, G, ap, bytes, 0);
+    addX("pack u32w7 G st18 ldnt maxw2", k_pack_x<uint32_t, 7, 18, 2, 2>, G, ap, bytes, 0);
+    addX("pack u32w7 G st18 ldnt maxw3", k_pack_x<uint32_t, 7, 18, 2, 3>, G, ap, bytes, 0);
+    addX("pack u32w7 G st18 ldnt occ2(lds)", k_pack_x<uint32_t, 7, 18, 2>, G, ap, bytes, 160 * 1024 / 2 - 1024);
+    // u64 W=17: 2176 B packed / 8192 B unpacked per block; n/2 blocks fit the same buffers (in: n*896+128M >= n/2*2176)
+    Args a64{in, out, n / 2}, ap64{out, in, n / 2};
+    const double by64 = (double)(n / 2) * 10368;
+    const uint64_t nwg64 = (n / 2 + 31) / 32;
+    const unsigned G64 = (unsigned)((nwg64 + 7) / 8);
+    auto addY = [&](const std::string& name, auto kern, unsigned K, Args aa, double by, uint64_t nwg) {
+        uint64_t n_wg = nwg;
+        if (K > 1) n_wg = (n_wg + 8ull * K - 1) / (8ull * K) * (8ull * K);
+        vs.push_back({name, by, [=]() { hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), 0, 0, aa, K); }, {}});
+    };
+    addY("unpack u64w17 base", k_unpack_x<uint64_t, 17, -1, -1>, 1, a64, by64, nwg64);
+    addY("unpack u64w17 G st18", k_unpack_x<uint64_t, 17, 18, -1>, G64, a64, by64, nwg64);
+    addY("unpack u64w17 G st18 maxw2", k_unpack_x<uint64_t, 17, 18, -1, 2>, G64, a64, by64, nwg64);
+    addY("unpack u64w17 G st18 maxw3", k_unpack_x<uint64_t, 17, 18, -1, 3>, G64, a64, by64, nwg64);
+    addY("pack u64w17 base", k_pack_x<uint64_t, 17, -1, -1>, 1, ap64, by64, nwg64);
+    addY("pack u64w17 G st18 ldnt", k_pack_x<uint64_t, 17, 18, 2>, G64, ap64, by64, nwg64);
+    addY("pack u64w17 G st18 ldnt maxw1", k_pack_x<uint64_t, 17, 18, 2, 1>, G64, ap64, by64, nwg64);
+    // u16 W=3: 384 B packed / 2048 B unpacked; 2n blocks would overflow `in`, use n blocks
+    Args a16{in, out, n};
+    const double by16 = (double)n * 2432;
+    addY("unpack u16w3 base", k_unpack_x<uint16_t, 3, -1, -1>, 1, a16, by16, n_wg0);
+    addY("unpack u16w3 G st18", k_unpack_x<uint16_t, 3, 18, -1>, G, a16, by16, n_wg0);
+    addY("unpack u16w3 G st18 maxw2", k_unpack_x<uint16_t, 3, 18, -1, 2>, G, a16, by16, n_wg0);
+    addY("unpack u16w3 G st18 maxw4", k_unpack_x<uint16_t, 3, 18, -1, 4>, G, a16, by16, n_wg0);
+    // u32 W=31 (heavy loads: 31 packed words) and W=1
+    Args a31{in, out, n / 4};
+    addY("unpack u32w31 base", k_unpack_x<uint32_t, 31, -1, -1>, 1, a31, (double)(n / 4) * (128 * 31 + 4096), (n / 4 + 31) / 32);
+    addY("unpack u32w31 G st18", k_unpack_x<uint32_t, 31, 18, -1>, (unsigned)(((n / 4 + 31) / 32 + 7) / 8), a31, (double)(n / 4) * (128 * 31 + 4096), (n / 4 + 31) / 32);
+    addY("unpack u32w31 G st18 maxw2", k_unpack_x<uint32_t, 31, 18, -1, 2>, (unsigned)(((n / 4 + 31) / 32 + 7) / 8), a31, (double)(n / 4) * (128 * 31 + 4096), (n / 4 + 31) / 32);
+    addY("unpack u32w31 G st18 ldnt maxw2", k_unpack_x<uint32_t, 31, 18, 2, 2>, (unsigned)(((n / 4 + 31) / 32 + 7) / 8), a31, (double)(n / 4) * (128 * 31 + 4096), (n / 4 + 31) / 32);
+    addY("unpack u32w1 base", k_unpack_x<uint32_t, 1, -1, -1>, 1, a, (double)n * (128 + 4096), n_wg0);
+    addY("unpack u32w1 G st18 maxw2", k_unpack_x<uint32_t, 1, 18, -1, 2>, G, a, (double)n * (128 + 4096), n_wg0);
+    const uint64_t n_thr = n * 8;
+    auto addS = [&](const char* name, auto kern, double by) {
+        vs.push_back({name, by, [=]() { hipLaunchKernelGGL(kern, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, 0, (const u32x4*)in, out, n_thr, sink); }, {}});
+    };
+    addS("stream 7rd:32wr nt", k_stream<7, 32, true>, bytes);
+    addS("stream write-only 32", k_stream<0, 32, false>, (double)n * 4096);
+
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (auto& v : vs) { v.launch(); }
+    CK(hipDeviceSynchronize());
+    for (int r = 0; r < rounds; ++r)
+        for (auto& v : vs) {
+            CK(hipEventRecord(e0, 0));
+            v.launch();
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            v.ms.push_back(ms);
+        }
+    CK(hipGetLastError());
+    printf("%-36s %9s %9s %9s %9s\n", "variant", "med_ms", "min_ms", "GB/s_med", "GB/s_max");
+    for (auto& v : vs) {
+        std::sort(v.ms.begin(), v.ms.end());
+        float med = v.ms[v.ms.size() / 2], mn = v.ms[0];
+        printf("%-36s %9.4f %9.4f %9.1f %9.1f\n", v.name.c_str(), med, mn, v.bytes / med / 1e6, v.bytes / mn / 1e6);
+    }
+    return 0;
+}
+
+__global__ void k_fill(uint64_t* p, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t z = (i + 1) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        p[i] = z ^ (z >> 31);
+    }
+}
