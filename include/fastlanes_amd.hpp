@@ -1,0 +1,198 @@
+// fastlanes_amd.hpp -- C++ host-side mirror of the reference's codec traits over the
+// C ABI (include/fastlanes_amd.h).  The reference is compiled Rust; with no Rust
+// toolchain in the build image this header plays the role of the `impl BitPacking
+// for u32 { .. }` shim (INTEGRATION.md shows the Rust form): same method names,
+// argument meaning and error behaviour.
+//
+//   reference (Rust)                                    here (C++)
+//   <T as BitPacking>::pack::<W>(&in, &mut out)         fastlanes::BitPacking<T>::pack<W>(in, out)
+//   <T as BitPacking>::unchecked_pack(w, in, out)       fastlanes::BitPacking<T>::unchecked_pack(w, in, n_in, out, n_out)
+//   <T as FoR>::for_pack::<W>(&in, r, &mut out)         fastlanes::FoR<T>::for_pack<W>(in, r, out)
+//   <T as Delta>::undelta_pack::<W>(&in, &base, &mut o) fastlanes::Delta<T>::undelta_pack<W>(in, base, out)
+//   <T as Transpose>::transpose(&in, &mut out)          fastlanes::Transpose<T>::transpose(in, out)
+//
+// Fixed-size array references enforce the sizes the Rust types enforce
+// (bitpacking.rs:19,33); `W <= T` is a static_assert (bitpacking.rs:8-13).
+// The `unchecked_` forms take slices (pointer + length) and, like the reference's
+// debug_asserts (bitpacking.rs:78-80), check lengths -- here always.  Where the
+// reference panics (width > T: bitpacking.rs:93; index >= 1024: :152) this throws
+// fastlanes::Error.  Every call runs the gfx950 kernels (host slices are staged
+// through HBM); there is no CPU implementation.  `*_device` members are the batched,
+// device-resident form of the same methods (n_blocks contiguous blocks, async).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+
+#include "fastlanes_amd.h"
+
+namespace fastlanes {
+
+constexpr std::size_t FL_ORDER[8] = {0, 4, 2, 6, 1, 5, 3, 7};   // lib.rs:22
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int st, const char* where)
+        : std::runtime_error(std::string(where) + ": " + fl_status_string(st)), status(st) {}
+};
+
+namespace detail {
+inline void check(int st, const char* where) { if (st != FL_OK) throw Error(st, where); }
+
+template <typename T> struct Abi;
+#define FASTLANES_ABI(T, S)                                                                          \
+    template <> struct Abi<T> {                                                                      \
+        static constexpr auto pack = fl_##S##_pack;                                                  \
+        static constexpr auto unpack = fl_##S##_unpack;                                              \
+        static constexpr auto unpack_single = fl_##S##_unpack_single;                                \
+        static constexpr auto for_pack = fl_##S##_for_pack;                                          \
+        static constexpr auto unfor_pack = fl_##S##_unfor_pack;                                      \
+        static constexpr auto delta = fl_##S##_delta;                                                \
+        static constexpr auto undelta = fl_##S##_undelta;                                            \
+        static constexpr auto undelta_pack = fl_##S##_undelta_pack;                                  \
+        static constexpr auto transpose = fl_##S##_transpose;                                        \
+        static constexpr auto untranspose = fl_##S##_untranspose;                                    \
+        static constexpr auto pack_host = fl_##S##_pack_host;                                        \
+        static constexpr auto unpack_host = fl_##S##_unpack_host;                                    \
+        static constexpr auto unpack_single_host = fl_##S##_unpack_single_host;                      \
+        static constexpr auto for_pack_host = fl_##S##_for_pack_host;                                \
+        static constexpr auto unfor_pack_host = fl_##S##_unfor_pack_host;                            \
+        static constexpr auto delta_host = fl_##S##_delta_host;                                      \
+        static constexpr auto undelta_host = fl_##S##_undelta_host;                                  \
+        static constexpr auto undelta_pack_host = fl_##S##_undelta_pack_host;                        \
+        static constexpr auto transpose_host = fl_##S##_transpose_host;                              \
+        static constexpr auto untranspose_host = fl_##S##_untranspose_host;                          \
+    };
+FASTLANES_ABI(std::uint8_t, u8)
+FASTLANES_ABI(std::uint16_t, u16)
+FASTLANES_ABI(std::uint32_t, u32)
+FASTLANES_ABI(std::uint64_t, u64)
+#undef FASTLANES_ABI
+}  // namespace detail
+
+// lib.rs:24-32
+template <typename T> struct FastLanes {
+    static constexpr std::size_t T_BITS = sizeof(T) * 8;   // `const T`
+    static constexpr std::size_t LANES = 1024 / T_BITS;
+};
+
+// bitpacking.rs:16-59
+template <typename T> struct BitPacking : FastLanes<T> {
+    using A = detail::Abi<T>;
+    static constexpr std::size_t TB = sizeof(T) * 8;
+
+    template <std::size_t W> static void pack(const T (&input)[1024], T (&output)[W ? 1024 * W / TB : 1])
+    {
+        static_assert(W <= TB, "BitPackWidth<W>: SupportedBitPackWidth<T> (bitpacking.rs:8-13)");
+        detail::check(A::pack_host(W, input, output, 1), "pack");
+    }
+    template <std::size_t W> static void unpack(const T (&input)[W ? 1024 * W / TB : 1], T (&output)[1024])
+    {
+        static_assert(W <= TB, "BitPackWidth<W>: SupportedBitPackWidth<T>");
+        detail::check(A::unpack_host(W, input, output, 1), "unpack");
+    }
+    template <std::size_t W> static T unpack_single(const T (&packed)[W ? 1024 * W / TB : 1], std::size_t index)
+    {
+        static_assert(W <= TB, "BitPackWidth<W>: SupportedBitPackWidth<T>");
+        T v{};
+        detail::check(A::unpack_single_host(W, packed, 1, index, &v), "unpack_single");
+        return v;
+    }
+    // bitpacking.rs:76-96 -- lengths as in the debug_asserts (:78-80)
+    static void unchecked_pack(std::size_t width, const T* input, std::size_t in_len, T* output, std::size_t out_len)
+    {
+        if (width > TB) throw Error(FL_ERR_WIDTH, "unchecked_pack");
+        if (in_len != 1024 || out_len != 128 * width / sizeof(T)) throw std::length_error("unchecked_pack: buffer sizes");
+        detail::check(A::pack_host((unsigned)width, input, output, 1), "unchecked_pack");
+    }
+    // bitpacking.rs:109-129
+    static void unchecked_unpack(std::size_t width, const T* input, std::size_t in_len, T* output, std::size_t out_len)
+    {
+        if (width > TB) throw Error(FL_ERR_WIDTH, "unchecked_unpack");
+        if (out_len != 1024 || in_len != 128 * width / sizeof(T)) throw std::length_error("unchecked_unpack: buffer sizes");
+        detail::check(A::unpack_host((unsigned)width, input, output, 1), "unchecked_unpack");
+    }
+    // bitpacking.rs:181-200
+    static T unchecked_unpack_single(std::size_t width, const T* packed, std::size_t len, std::size_t index)
+    {
+        if (width > TB) throw Error(FL_ERR_WIDTH, "unchecked_unpack_single");
+        if (len != 128 * width / sizeof(T)) throw std::length_error("unchecked_unpack_single: buffer size");
+        T v{};
+        detail::check(A::unpack_single_host((unsigned)width, packed, 1, index, &v), "unchecked_unpack_single");
+        return v;
+    }
+    // batched, device-resident forms (stream = hipStream_t)
+    static void pack_device(std::size_t width, const T* d_in, T* d_out, std::size_t n_blocks, void* stream = nullptr)
+    { detail::check(A::pack((unsigned)width, d_in, d_out, n_blocks, stream), "pack_device"); }
+    static void unpack_device(std::size_t width, const T* d_in, T* d_out, std::size_t n_blocks, void* stream = nullptr)
+    { detail::check(A::unpack((unsigned)width, d_in, d_out, n_blocks, stream), "unpack_device"); }
+    static void unpack_single_device(std::size_t width, const T* d_packed, std::size_t n_blocks, const std::uint64_t* d_indices,
+                                     std::size_t n_indices, T* d_out, std::uint32_t* d_err, void* stream = nullptr)
+    { detail::check(A::unpack_single((unsigned)width, d_packed, n_blocks, d_indices, n_indices, d_out, d_err, stream), "unpack_single_device"); }
+};
+
+// ffor.rs:4-18
+template <typename T> struct FoR : BitPacking<T> {
+    using A = detail::Abi<T>;
+    static constexpr std::size_t TB = sizeof(T) * 8;
+    template <std::size_t W> static void for_pack(const T (&input)[1024], T reference, T (&output)[W ? 1024 * W / TB : 1])
+    {
+        static_assert(W <= TB, "BitPackWidth<W>: SupportedBitPackWidth<T>");
+        detail::check(A::for_pack_host(W, input, reference, output, 1), "for_pack");
+    }
+    template <std::size_t W> static void unfor_pack(const T (&input)[W ? 1024 * W / TB : 1], T reference, T (&output)[1024])
+    {
+        static_assert(W <= TB, "BitPackWidth<W>: SupportedBitPackWidth<T>");
+        detail::check(A::unfor_pack_host(W, input, reference, output, 1), "unfor_pack");
+    }
+    static void for_pack_device(std::size_t width, const T* d_in, const T* d_refs, std::size_t ref_stride, T* d_out,
+                                std::size_t n_blocks, void* stream = nullptr)
+    { detail::check(A::for_pack((unsigned)width, d_in, d_refs, ref_stride, d_out, n_blocks, stream), "for_pack_device"); }
+    static void unfor_pack_device(std::size_t width, const T* d_in, const T* d_refs, std::size_t ref_stride, T* d_out,
+                                  std::size_t n_blocks, void* stream = nullptr)
+    { detail::check(A::unfor_pack((unsigned)width, d_in, d_refs, ref_stride, d_out, n_blocks, stream), "unfor_pack_device"); }
+};
+
+// delta.rs:6-17
+template <typename T> struct Delta : BitPacking<T> {
+    using A = detail::Abi<T>;
+    static constexpr std::size_t TB = sizeof(T) * 8;
+    static constexpr std::size_t LANES = 1024 / TB;
+    static void delta(const T (&input)[1024], const T (&base)[LANES], T (&output)[1024])
+    { detail::check(A::delta_host(input, base, output, 1), "delta"); }
+    static void undelta(const T (&input)[1024], const T (&base)[LANES], T (&output)[1024])
+    { detail::check(A::undelta_host(input, base, output, 1), "undelta"); }
+    template <std::size_t W>
+    static void undelta_pack(const T (&input)[W ? 1024 * W / TB : 1], const T (&base)[LANES], T (&output)[1024])
+    {
+        static_assert(W <= TB, "BitPackWidth<W>: SupportedBitPackWidth<T>");
+        detail::check(A::undelta_pack_host(W, input, base, output, 1), "undelta_pack");
+    }
+    static void delta_device(const T* d_in, const T* d_bases, T* d_out, std::size_t n_blocks, void* stream = nullptr)
+    { detail::check(A::delta(d_in, d_bases, d_out, n_blocks, stream), "delta_device"); }
+    static void undelta_device(const T* d_in, const T* d_bases, T* d_out, std::size_t n_blocks, void* stream = nullptr)
+    { detail::check(A::undelta(d_in, d_bases, d_out, n_blocks, stream), "undelta_device"); }
+    static void undelta_pack_device(std::size_t width, const T* d_in, const T* d_bases, T* d_out, std::size_t n_blocks,
+                                    void* stream = nullptr)
+    { detail::check(A::undelta_pack((unsigned)width, d_in, d_bases, d_out, n_blocks, stream), "undelta_pack_device"); }
+};
+
+// transpose.rs:4-7,29-36
+constexpr std::size_t transpose(std::size_t idx)
+{
+    return (idx % 16) * 64 + FL_ORDER[(idx / 16) % 8] * 8 + idx / 128;
+}
+template <typename T> struct Transpose : FastLanes<T> {
+    using A = detail::Abi<T>;
+    static void transpose(const T (&input)[1024], T (&output)[1024])
+    { detail::check(A::transpose_host(input, output, 1), "transpose"); }
+    static void untranspose(const T (&input)[1024], T (&output)[1024])
+    { detail::check(A::untranspose_host(input, output, 1), "untranspose"); }
+    static void transpose_device(const T* d_in, T* d_out, std::size_t n_blocks, void* stream = nullptr)
+    { detail::check(A::transpose(d_in, d_out, n_blocks, stream), "transpose_device"); }
+    static void untranspose_device(const T* d_in, T* d_out, std::size_t n_blocks, void* stream = nullptr)
+    { detail::check(A::untranspose(d_in, d_out, n_blocks, stream), "untranspose_device"); }
+};
+
+}  // namespace fastlanes

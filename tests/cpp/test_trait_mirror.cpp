@@ -1,0 +1,143 @@
+// The reference's own unit tests, written against the C++ trait
+// mirror (include/fastlanes_amd.hpp) so they read like the Rust originals.  Needs a GPU
+// at run time (no CPU path exists); built on CPU as a compile/link check.
+//   g++ -std=c++17 -I include tests/cpp/test_trait_mirror.cpp -L fastlanes_amd -lfastlanes_amd
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "fastlanes_amd.hpp"
+
+using namespace fastlanes;
+
+static int failures = 0;
+#define EXPECT(cond) do { if (!(cond)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #cond); ++failures; } } while (0)
+
+// lib.rs:53-59
+static void test_ordering_is_own_inverse() { for (int i = 0; i < 8; ++i) EXPECT(FL_ORDER[FL_ORDER[i]] == (size_t)i); }
+
+// lib.rs:71-96 / README.md:14-47
+static void pack_u16_into_u3_no_unsafe()
+{
+    constexpr size_t WIDTH = 3;
+    static uint16_t values[1024], packed[128 * WIDTH / sizeof(uint16_t)], unpacked[1024];
+    for (int i = 0; i < 1024; ++i) values[i] = (uint16_t)(i % (1 << WIDTH));
+    BitPacking<uint16_t>::pack<WIDTH>(values, packed);
+    BitPacking<uint16_t>::unpack<WIDTH>(packed, unpacked);
+    EXPECT(std::memcmp(values, unpacked, sizeof values) == 0);
+    for (int i = 0; i < 1024; i += 37) EXPECT(BitPacking<uint16_t>::unpack_single<WIDTH>(packed, i) == values[i]);
+    // the unchecked_ forms of the README
+    std::vector<uint16_t> p2(192), u2(1024);
+    BitPacking<uint16_t>::unchecked_pack(WIDTH, values, 1024, p2.data(), p2.size());
+    BitPacking<uint16_t>::unchecked_unpack(WIDTH, p2.data(), p2.size(), u2.data(), u2.size());
+    EXPECT(std::memcmp(values, u2.data(), sizeof values) == 0);
+    EXPECT(BitPacking<uint16_t>::unchecked_unpack_single(WIDTH, p2.data(), p2.size(), 14) == values[14]);
+    // KAT-2
+    EXPECT(packed[0] == 0x0000 && packed[1] == 0x9249 && packed[2] == 0x2492 && packed[3] == 0xB6DB);
+}
+
+// bitpacking.rs:248-256
+static void test_unchecked_pack()
+{
+    std::vector<uint32_t> input(1024), packed(320), output(1024);
+    for (int i = 0; i < 1024; ++i) input[i] = i;
+    BitPacking<uint32_t>::unchecked_pack(10, input.data(), 1024, packed.data(), 320);
+    BitPacking<uint32_t>::unchecked_unpack(10, packed.data(), 320, output.data(), 1024);
+    EXPECT(input == output);
+    EXPECT(packed[0] == 0x10020000u && packed[319] == 0xFFF7FBFEu);   // KAT-3
+}
+
+// bitpacking.rs:258-271
+static void test_unpack_single()
+{
+    static uint32_t values[1024], packed[512];
+    for (int i = 0; i < 1024; ++i) values[i] = i;
+    BitPacking<uint32_t>::pack<16>(values, packed);
+    for (int i = 0; i < 1024; i += 53) {
+        EXPECT(BitPacking<uint32_t>::unpack_single<16>(packed, i) == values[i]);
+        EXPECT(BitPacking<uint32_t>::unchecked_unpack_single(16, packed, 512, i) == values[i]);
+    }
+}
+
+// delta.rs:80-107
+static void test_delta()
+{
+    constexpr size_t W = 15;
+    static uint16_t values[1024], transposed[1024], deltas[1024], packed[128 * W / 2], unpacked[1024], undelta[1024];
+    static uint16_t zero[64] = {0};
+    for (int i = 0; i < 1024; ++i) values[i] = (uint16_t)(i / 8);
+    Transpose<uint16_t>::transpose(values, transposed);
+    Delta<uint16_t>::delta(transposed, zero, deltas);
+    BitPacking<uint16_t>::pack<W>(deltas, packed);
+    Delta<uint16_t>::undelta_pack<W>(packed, zero, unpacked);          // fused kernel
+    EXPECT(std::memcmp(transposed, unpacked, sizeof unpacked) == 0);
+    BitPacking<uint16_t>::unpack<W>(packed, unpacked);                 // unfused
+    Delta<uint16_t>::undelta(unpacked, zero, undelta);
+    EXPECT(std::memcmp(transposed, undelta, sizeof undelta) == 0);
+    static uint16_t back[1024];
+    Transpose<uint16_t>::untranspose(transposed, back);
+    EXPECT(std::memcmp(values, back, sizeof back) == 0);
+    for (int i = 0; i < 1024; i += 101) EXPECT(transposed[i] == values[transpose(i)]);
+}
+
+// ffor.rs:66-88
+static void test_ffor()
+{
+    constexpr size_t W = 15;
+    static uint16_t values[1024], packed[128 * W / 2], unpacked[1024];
+    for (int i = 0; i < 1024; ++i) values[i] = (uint16_t)(i % (1 << W));
+    FoR<uint16_t>::for_pack<W>(values, 10, packed);
+    BitPacking<uint16_t>::unpack<W>(packed, unpacked);
+    for (int i = 0; i < 1024; ++i) EXPECT((uint16_t)((values[i] - 10) & ((1 << W) - 1)) == unpacked[i]);
+    FoR<uint16_t>::unfor_pack<W>(packed, 10, unpacked);
+    for (int i = 0; i < 1024; ++i) EXPECT((uint16_t)(((values[i] - 10) & 0x7FFF) + 10) == unpacked[i]);
+}
+
+// the reference panics (bitpacking.rs:93 unreachable!, :152 assert!)
+static void test_panics()
+{
+    std::vector<uint32_t> in(1024), out(1024);
+    bool threw = false;
+    try { BitPacking<uint32_t>::unchecked_pack(33, in.data(), 1024, out.data(), 1024); } catch (const Error& e) { threw = e.status == FL_ERR_WIDTH; }
+    EXPECT(threw);
+    threw = false;
+    static uint32_t packed[96];
+    try { (void)BitPacking<uint32_t>::unpack_single<3>(packed, 1024); } catch (const Error& e) { threw = e.status == FL_ERR_INDEX; }
+    EXPECT(threw);
+}
+
+// u64 W=17 KAT-5 and u8
+static void test_wide_and_narrow()
+{
+    static uint64_t v[1024], pk[272], un[1024];
+    for (uint64_t i = 0; i < 1024; ++i) v[i] = (i * 2654435761ull) & 0x1FFFF;
+    BitPacking<uint64_t>::pack<17>(v, pk);
+    EXPECT(pk[0] == 0x4C06C401B1000000ull && pk[1] == 0x198CAAC4A46379B1ull);
+    BitPacking<uint64_t>::unpack<17>(pk, un);
+    EXPECT(std::memcmp(v, un, sizeof v) == 0);
+    static uint8_t v8[1024], p8[1024], u8_[1024];
+    for (int i = 0; i < 1024; ++i) v8[i] = (uint8_t)i;
+    BitPacking<uint8_t>::pack<8>(v8, p8);
+    EXPECT(std::memcmp(v8, p8, 1024) == 0);   // KAT-6: the copy path is the identity for u8
+    BitPacking<uint8_t>::unpack<8>(p8, u8_);
+    EXPECT(std::memcmp(v8, u8_, 1024) == 0);
+}
+
+int main()
+{
+    try {
+        test_ordering_is_own_inverse();
+        pack_u16_into_u3_no_unsafe();
+        test_unchecked_pack();
+        test_unpack_single();
+        test_delta();
+        test_ffor();
+        test_panics();
+        test_wide_and_narrow();
+    } catch (const std::exception& e) {
+        std::printf("EXCEPTION %s\n", e.what());
+        return 2;
+    }
+    std::printf(failures ? "FAILED (%d)\n" : "ok\n", failures);
+    return failures ? 1 : 0;
+}

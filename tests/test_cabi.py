@@ -86,3 +86,26 @@ def test_product_never_touches_the_oracle():
                             "touches" in stripped or "never" in stripped.lower()), (f, line)
     header = open(os.path.join(ROOT, "include", "fastlanes_amd.h")).read()
     assert "fl_oracle" not in header
+
+
+def test_cpp_trait_mirror_builds_and_fails_loudly_without_gpu(lib):
+    """include/fastlanes_amd.hpp + tests/cpp/test_trait_mirror.cpp compile and link against the
+    C ABI; with no GPU the reference's tests cannot silently pass on some CPU path."""
+    import subprocess
+    import torch
+    exe = build_cpp_test()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    if not torch.cuda.is_available():
+        assert r.returncode == 2 and "HIP runtime error" in r.stdout, (r.returncode, r.stdout)
+
+
+def build_cpp_test():
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "test_trait_mirror")
+    src = exe + ".cpp"
+    hdr = os.path.join(ROOT, "include", "fastlanes_amd.hpp")
+    if not os.path.exists(exe) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(exe):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), src,
+                               "-L", os.path.join(ROOT, "fastlanes_amd"), "-lfastlanes_amd",
+                               "-Wl,-rpath,$ORIGIN/../../fastlanes_amd", "-o", exe])
+    return exe

@@ -262,3 +262,12 @@ def test_config4_fused_delta_u32_w12_10M_blocks(fl, oracle):
         want = oracle.undelta_pack("u32", 12, to_np(pk[b * 384:(b + 1) * 384], "u32"),
                                    to_np(bases[b * 32:(b + 1) * 32], "u32"))
         assert np.array_equal(got, want), b
+
+
+def test_cpp_trait_mirror_reference_tests(fl):
+    """The reference's unit tests written against include/fastlanes_amd.hpp (C++ mirror of the
+    traits), run on the GPU through the host tier."""
+    import subprocess
+    from test_cabi import build_cpp_test
+    r = subprocess.run([build_cpp_test()], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout, r.stderr)
