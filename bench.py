@@ -32,6 +32,8 @@ WORKLOADS = {
     "u32_w12_undelta_pack": ("u32", 12, "undelta_pack", 128 * 12 + 128 + 128 * 32),
     "u32_w7_pack": ("u32", 7, "pack", 128 * 7 + 128 * 32),
     "u16_w3_unpack": ("u16", 3, "unpack", 128 * 3 + 128 * 16),
+    # BASELINE.json configs[4]: width[b] = 1 + b % 32; bytes per block averaged over the 32 widths
+    "u32_mixed_unpack": ("u32", None, "unpack_mixed", 128 * 16.5 + 128 * 32),
 }
 
 
@@ -116,15 +118,29 @@ def main():
     n = args.blocks
     tdt = {"u8": torch.uint8, "u16": torch.uint16, "u32": torch.uint32, "u64": torch.uint64}[ty]
     esz = {"u8": 1, "u16": 2, "u32": 4, "u64": 8}[ty]
-    pl_bytes = 128 * width
     un_bytes = 1024 * esz
-    in_bytes, out_bytes = (un_bytes, pl_bytes) if op == "pack" else (pl_bytes, un_bytes)
-    src = rand_u8(n * in_bytes, 1234 + rank, dev).view(tdt)
-    dst = torch.empty(n * out_bytes // esz, dtype=tdt, device=dev)
+    plan = None
+    if op == "unpack_mixed":
+        import numpy as np
+        if args.blocks == 10_000_000:
+            n = 9_765_625 // world   # 10 B integers in total, sharded by block range
+        widths = (1 + (np.arange(n, dtype=np.int64) + rank * n) % 32).astype(np.uint8)
+        plan = fl.MixedWidthPlan(ty, widths)
+        src = rand_u8(plan.packed_bytes, 1234 + rank, dev).view(tdt)
+        dst = torch.empty(n * 1024, dtype=tdt, device=dev)
+        in_bytes, out_bytes = plan.packed_bytes / n, un_bytes
+        bytes_per_block = in_bytes + out_bytes
+    else:
+        pl_bytes = 128 * width
+        in_bytes, out_bytes = (un_bytes, pl_bytes) if op == "pack" else (pl_bytes, un_bytes)
+        src = rand_u8(n * in_bytes, 1234 + rank, dev).view(tdt)
+        dst = torch.empty(n * out_bytes // esz, dtype=tdt, device=dev)
     bases = rand_u8(n * 128, 99 + rank, dev).view(tdt) if op == "undelta_pack" else None
 
     def step():
-        if op == "unpack":
+        if op == "unpack_mixed":
+            plan.unpack(src, output=dst)
+        elif op == "unpack":
             fl.BitPacking.unpack(width, src, output=dst)
         elif op == "pack":
             fl.BitPacking.pack(width, src, output=dst)
@@ -160,7 +176,7 @@ def main():
     # ---- checks sampled blocks of what was just timed against the oracle, outside the timed region
     check = None
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and op != "unpack_mixed":
         import numpy as np
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from oracle_lib import load_oracle
@@ -206,7 +222,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if op == "unpack_mixed" and args.blocks == 10_000_000 else "weak",
             "vs_baseline": None,
             "dtype": ty,
             "data": "synthetic (uniform random packed bits, generated on device; inputs resident in HBM)",

@@ -4,10 +4,10 @@ names.  The compute lives in libfastlanes_amd.so (hand-written gfx950 HIP
 kernels, C ABI in include/fastlanes_amd.h); this package is the thin host-side
 mirror of the reference interface.  No CPU fallback exists."""
 from ._lib import LIB_PATH, exported_symbols, load  # noqa: F401
-from .codec import (BitPacking, Delta, FastLanesError, FoR, Transpose,  # noqa: F401
-                    packed_len)
+from .codec import (BitPacking, Delta, FastLanesError, FoR, MixedWidthPlan,  # noqa: F401
+                    Transpose, packed_len)
 
 FL_ORDER = (0, 4, 2, 6, 1, 5, 3, 7)  # lib.rs:22
 
-__all__ = ["BitPacking", "FoR", "Delta", "Transpose", "FastLanesError", "packed_len",
+__all__ = ["BitPacking", "FoR", "Delta", "Transpose", "FastLanesError", "packed_len", "MixedWidthPlan",
            "FL_ORDER", "load", "exported_symbols", "LIB_PATH"]

@@ -33,6 +33,8 @@ def _signatures(ty):
         "undelta_pack": [_U, _P, _P, _P, _Z, _P],
         "transpose": [_P, _P, _Z, _P],
         "untranspose": [_P, _P, _Z, _P],
+        "unpack_mixed": [_P, _P, _P, _P],
+        "pack_mixed": [_P, _P, _P, _P],
     }
     host = {
         "pack_host": [_U, _P, _P, _Z],
@@ -52,7 +54,9 @@ def _signatures(ty):
 
 def exported_symbols():
     """Every symbol include/fastlanes_amd.h declares."""
-    names = ["fl_version", "fl_status_string", "fl_last_hip_error", "fl_packed_len"]
+    names = ["fl_version", "fl_status_string", "fl_last_hip_error", "fl_packed_len",
+             "fl_mixed_plan_create", "fl_mixed_plan_destroy", "fl_mixed_plan_n_blocks",
+             "fl_mixed_plan_packed_bytes", "fl_mixed_plan_offsets"]
     for ty in TYPES:
         names += [f"fl_{ty}_{m}" for m in _signatures(ty)]
     return names
@@ -77,6 +81,16 @@ def load():
     lib.fl_last_hip_error.restype = ctypes.c_int
     lib.fl_packed_len.restype = ctypes.c_size_t
     lib.fl_packed_len.argtypes = [_U, _U]
+    lib.fl_mixed_plan_create.restype = ctypes.c_int
+    lib.fl_mixed_plan_create.argtypes = [_U, _P, _Z, ctypes.POINTER(_P)]
+    lib.fl_mixed_plan_destroy.restype = None
+    lib.fl_mixed_plan_destroy.argtypes = [_P]
+    lib.fl_mixed_plan_n_blocks.restype = ctypes.c_size_t
+    lib.fl_mixed_plan_n_blocks.argtypes = [_P]
+    lib.fl_mixed_plan_packed_bytes.restype = ctypes.c_uint64
+    lib.fl_mixed_plan_packed_bytes.argtypes = [_P]
+    lib.fl_mixed_plan_offsets.restype = _P
+    lib.fl_mixed_plan_offsets.argtypes = [_P]
     for ty in TYPES:
         for m, argtypes in _signatures(ty).items():
             fn = getattr(lib, f"fl_{ty}_{m}")

@@ -301,3 +301,64 @@ class Transpose:
     def untranspose(input, output=None):
         """Transpose::untranspose (transpose.rs:6,17-22)."""
         return Transpose._go("untranspose", input, output)
+
+
+class MixedWidthPlan:
+    """A column whose blocks each have their own width (BASELINE.json config 5): the
+    reference's caller loop `for b: T::unchecked_unpack(widths[b], ..)` (bitpacking.rs:109-129)
+    as one call.  Built once from the host `widths` array; packed blocks lie back to back at
+    byte offsets = exclusive prefix sum of 128*widths[b]."""
+
+    def __init__(self, ty, widths, device=None):
+        import torch
+        self.ty = ty
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        w = np.ascontiguousarray(widths, dtype=np.uint8)
+        self._plan = ctypes.c_void_p()
+        lib = _lib.load()
+        with torch.cuda.device(self.device):
+            _check(lib.fl_mixed_plan_create(_lib.BITS[ty], w.ctypes.data, w.size, ctypes.byref(self._plan)),
+                   "fl_mixed_plan_create")
+        self.n_blocks = int(lib.fl_mixed_plan_n_blocks(self._plan))
+        self.packed_bytes = int(lib.fl_mixed_plan_packed_bytes(self._plan))
+
+    def close(self):
+        if getattr(self, "_plan", None):
+            _lib.load().fl_mixed_plan_destroy(self._plan)
+            self._plan = None
+
+    __del__ = close
+
+    def _torch_dtype(self):
+        import torch
+        return {"u8": torch.uint8, "u16": torch.uint16, "u32": torch.uint32, "u64": torch.uint64}[self.ty]
+
+    def unpack(self, packed, output=None):
+        import torch
+        src = _Arg(packed, self.ty)
+        esz = _lib.BITS[self.ty] // 8
+        if src.n * esz != self.packed_bytes:
+            raise ValueError("packed column has the wrong size for this plan")
+        out = _Arg(output, self.ty) if output is not None else _Arg(
+            torch.empty(self.n_blocks * 1024, dtype=self._torch_dtype(), device=self.device), self.ty)
+        if out.n != self.n_blocks * 1024:
+            raise ValueError("Output buffer must be of size 1024 per block")
+        with torch.cuda.device(self.device):
+            _check(getattr(_lib.load(), f"fl_{self.ty}_unpack_mixed")(self._plan, src.ptr, out.ptr, _stream(out)),
+                   f"fl_{self.ty}_unpack_mixed")
+        return out.x
+
+    def pack(self, input, output=None):
+        import torch
+        src = _Arg(input, self.ty)
+        esz = _lib.BITS[self.ty] // 8
+        if src.n != self.n_blocks * 1024:
+            raise ValueError("Input buffer must be of size 1024 per block")
+        out = _Arg(output, self.ty) if output is not None else _Arg(
+            torch.empty(self.packed_bytes // esz, dtype=self._torch_dtype(), device=self.device), self.ty)
+        if out.n * esz != self.packed_bytes:
+            raise ValueError("packed column has the wrong size for this plan")
+        with torch.cuda.device(self.device):
+            _check(getattr(_lib.load(), f"fl_{self.ty}_pack_mixed")(self._plan, src.ptr, out.ptr, _stream(src)),
+                   f"fl_{self.ty}_pack_mixed")
+        return out.x

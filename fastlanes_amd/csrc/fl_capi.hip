@@ -5,6 +5,10 @@
 #include "../../include/fastlanes_amd.h"
 #include "fl_kernels.hpp"
 #include "fl_misc.hpp"
+#include "fl_mixed.hpp"
+
+#include <new>
+#include <vector>
 
 namespace {
 
@@ -120,7 +124,114 @@ template <typename T> size_t plen(unsigned w) { return (size_t)1024 * w / Elem<T
 
 }  // namespace
 
+// ---------------------------------------------------------------------------
+// mixed-width plan
+// ---------------------------------------------------------------------------
+struct fl_mixed_plan {
+    unsigned type_bits = 0;
+    size_t n_blocks = 0;
+    uint64_t packed_bytes = 0;
+    uint32_t* d_ids = nullptr;       // block ids bucketed by width, ascending inside a bucket
+    uint64_t* d_offsets = nullptr;   // byte offset of every block in the packed column
+    size_t bucket_start[66] = {0};   // ids[bucket_start[w] .. bucket_start[w+1]) have width w
+    bool window_unpack[65] = {false};
+    bool window_pack[65] = {false};
+};
+
+namespace {
+
+template <typename T>
+int run_mixed(bool pack, const fl_mixed_plan* p, const void* packed, void* unpacked, void* stream)
+{
+    if (!p) return FL_ERR_NULL;
+    if (p->type_bits != (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
+    if (p->n_blocks == 0) return FL_OK;
+    if (!unpacked || (p->packed_bytes && !packed)) return FL_ERR_NULL;
+    if (misaligned(packed) || misaligned(unpacked)) return FL_ERR_ALIGN;
+    const MixedTable<T>& tab = pack ? mixed_table_impl<T, true>() : mixed_table_impl<T, false>();
+    for (unsigned w = 0; w <= (unsigned)Elem<T>::BITS; ++w) {
+        const size_t m = p->bucket_start[w + 1] - p->bucket_start[w];
+        if (m == 0) continue;
+        MixedArgs a;
+        a.packed = static_cast<const char*>(packed);
+        a.unpacked = static_cast<char*>(unpacked);
+        a.ids = p->d_ids + p->bucket_start[w];
+        a.offsets = p->d_offsets;
+        a.m = m;
+        a.tiles_per_xcd = 0;
+        const bool window = pack ? p->window_pack[w] : p->window_unpack[w];
+        hipError_t e = tab.fn[w][window ? 1 : 0](a, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return hip_fail(e);
+    }
+    return FL_OK;
+}
+
+}  // namespace
+
 extern "C" {
+
+int fl_mixed_plan_create(unsigned type_bits, const uint8_t* widths, size_t n_blocks, fl_mixed_plan** plan)
+{
+    if (!plan || (n_blocks && !widths)) return FL_ERR_NULL;
+    *plan = nullptr;
+    if (type_bits != 8 && type_bits != 16 && type_bits != 32 && type_bits != 64) return FL_ERR_WIDTH;
+    if (n_blocks > 0xFFFFFFFFull) return FL_ERR_INDEX;
+    size_t count[66] = {0};
+    for (size_t b = 0; b < n_blocks; ++b) {
+        if (widths[b] > type_bits) return FL_ERR_WIDTH;   // bitpacking.rs:93 unreachable!()
+        ++count[widths[b] + 1];
+    }
+    fl_mixed_plan* p = new (std::nothrow) fl_mixed_plan;
+    if (!p) return FL_ERR_HIP;
+    p->type_bits = type_bits;
+    p->n_blocks = n_blocks;
+    for (unsigned w = 0; w <= 64; ++w) p->bucket_start[w + 1] = p->bucket_start[w] + count[w + 1];
+    std::vector<uint32_t> ids(n_blocks);
+    std::vector<uint64_t> off(n_blocks);
+    {
+        size_t cursor[66];
+        for (unsigned w = 0; w <= 65; ++w) cursor[w] = p->bucket_start[w];
+        uint64_t o = 0;
+        for (size_t b = 0; b < n_blocks; ++b) {
+            off[b] = o;
+            o += 128ull * widths[b];
+            ids[cursor[widths[b]]++] = (uint32_t)b;
+        }
+        p->packed_bytes = o;
+    }
+    const uint64_t block_bytes = 128ull * type_bits;
+    for (unsigned w = 0; w <= type_bits; ++w) {
+        const size_t s0 = p->bucket_start[w], m = p->bucket_start[w + 1] - s0;
+        bool wu = true, wp = true;
+        for (size_t t = 0; t * 32 < m; ++t) {
+            const uint64_t first = ids[s0 + t * 32], last = ids[s0 + (t * 32 + 31 < m ? t * 32 + 31 : m - 1)];
+            if ((last - first + 1) * block_bytes > 0xFFFFFFFFull) wu = false;
+            if (off[last] + 128ull * w - off[first] > 0xFFFFFFFFull) wp = false;
+        }
+        p->window_unpack[w] = wu;
+        p->window_pack[w] = wp;
+    }
+    if (n_blocks) {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->d_ids), n_blocks * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_offsets), n_blocks * sizeof(uint64_t));
+        if (e == hipSuccess) e = hipMemcpy(p->d_ids, ids.data(), n_blocks * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(p->d_offsets, off.data(), n_blocks * sizeof(uint64_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { fl_mixed_plan_destroy(p); return hip_fail(e); }
+    }
+    *plan = p;
+    return FL_OK;
+}
+
+void fl_mixed_plan_destroy(fl_mixed_plan* p)
+{
+    if (!p) return;
+    if (p->d_ids) (void)hipFree(p->d_ids);
+    if (p->d_offsets) (void)hipFree(p->d_offsets);
+    delete p;
+}
+size_t fl_mixed_plan_n_blocks(const fl_mixed_plan* p) { return p ? p->n_blocks : 0; }
+uint64_t fl_mixed_plan_packed_bytes(const fl_mixed_plan* p) { return p ? p->packed_bytes : 0; }
+const uint64_t* fl_mixed_plan_offsets(const fl_mixed_plan* p) { return p ? p->d_offsets : nullptr; }
 
 const char* fl_version(void) { return "fastlanes_amd 0.1.0 (gfx950; wire format of spiraldb/fastlanes 0.1.8)"; }
 
@@ -162,6 +273,8 @@ size_t fl_packed_len(unsigned type_bits, unsigned width)
     { return dev_undelta_pack<T>(w, in, b, out, n, s); }                                                  \
     int fl_##S##_transpose(const T* in, T* out, size_t n, void* s) { return dev_transpose<T>(false, in, out, n, s); } \
     int fl_##S##_untranspose(const T* in, T* out, size_t n, void* s) { return dev_transpose<T>(true, in, out, n, s); } \
+    int fl_##S##_unpack_mixed(const fl_mixed_plan* p, const T* pk, T* out, void* s) { return run_mixed<T>(false, p, pk, out, s); } \
+    int fl_##S##_pack_mixed(const fl_mixed_plan* p, const T* in, T* pk, void* s) { return run_mixed<T>(true, p, pk, const_cast<T*>(in), s); } \
     int fl_##S##_pack_host(unsigned w, const T* in, T* out, size_t n)                                     \
     {                                                                                                     \
         if (w > sizeof(T) * 8) return FL_ERR_WIDTH;                                                       \

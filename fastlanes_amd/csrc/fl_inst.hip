@@ -3,8 +3,10 @@
 // pairs x 5 width-parameterised kernels build in parallel:
 //   0 unpack (store)   1 unfor_pack   2 undelta_pack   3 pack   4 for_pack
 //   5 delta / undelta / transpose / untranspose / unpack_single
+//   6 unpack over a mixed-width plan   7 pack over a mixed-width plan
 #include "fl_kernels.hpp"
 #include "fl_misc.hpp"
+#include "fl_mixed.hpp"
 
 namespace fl {
 using T = FL_T;
@@ -38,7 +40,13 @@ template <> hipError_t unpack_single_launch<T>(const SingleArgs& a, hipStream_t 
 {
     return launch_unpack_single<T>(a, s);
 }
+#elif FL_FAMILY == 6
+static constexpr MixedTable<T> t_mixed_unpack = make_mixed_table<T, false>(Ws{});
+template <> const MixedTable<T>& mixed_table_impl<T, false>() { return t_mixed_unpack; }
+#elif FL_FAMILY == 7
+static constexpr MixedTable<T> t_mixed_pack = make_mixed_table<T, true>(Ws{});
+template <> const MixedTable<T>& mixed_table_impl<T, true>() { return t_mixed_pack; }
 #else
-#error "FL_FAMILY must be 0..5"
+#error "FL_FAMILY must be 0..7"
 #endif
 }  // namespace fl

@@ -73,6 +73,28 @@ int fl_last_hip_error(void);
 /* Elements in one packed block: 1024*width/T (bitpacking.rs:77); 0 if width > T. */
 size_t fl_packed_len(unsigned type_bits, unsigned width);
 
+/*
+ * Mixed-width columns (BASELINE.json config 5): block b has its own width widths[b].
+ * The reference has no multi-block API; this is its caller loop
+ *     for b in blocks { T::unchecked_unpack(widths[b], &packed[off[b]..], &mut out[b*1024..]) }
+ * (bitpacking.rs:109-129; loop shape of benches/bitpacking.rs:90-97) moved on-device.
+ * Packed blocks are laid out back to back: off[b] = sum_{i<b} 128*widths[i] bytes.
+ * A plan is built ONCE per column from the HOST widths array (bucket blocks by width,
+ * prefix-sum the offsets, upload both to the current device); the pack/unpack calls are
+ * then allocation-free and asynchronous like every other device-tier call: one kernel
+ * launch per distinct width on `stream`.  The plan must be used on the device it was
+ * created on and destroyed by the caller.
+ */
+typedef struct fl_mixed_plan fl_mixed_plan;
+int fl_mixed_plan_create(unsigned type_bits, const uint8_t *widths, size_t n_blocks,
+                         fl_mixed_plan **plan);
+void fl_mixed_plan_destroy(fl_mixed_plan *plan);
+size_t fl_mixed_plan_n_blocks(const fl_mixed_plan *plan);
+/* total packed bytes of the column = sum 128*widths[b] */
+uint64_t fl_mixed_plan_packed_bytes(const fl_mixed_plan *plan);
+/* device pointer to the uint64 byte offsets [n_blocks] (owned by the plan) */
+const uint64_t *fl_mixed_plan_offsets(const fl_mixed_plan *plan);
+
 #define FL_DECLARE_TYPE(T, S)                                                                   \
     /* BitPacking::unchecked_pack (bitpacking.rs:30,76-96) -> pack::<W> (:65-74) */             \
     int fl_##S##_pack(unsigned width, const T *in, T *out, size_t n_blocks, void *stream);      \
@@ -104,6 +126,9 @@ size_t fl_packed_len(unsigned type_bits, unsigned width);
     int fl_##S##_transpose(const T *in, T *out, size_t n_blocks, void *stream);                 \
     /* Transpose::untranspose (transpose.rs:6,17-22) */                                         \
     int fl_##S##_untranspose(const T *in, T *out, size_t n_blocks, void *stream);               \
+    /* unchecked_unpack / unchecked_pack over a mixed-width plan (see fl_mixed_plan) */          \
+    int fl_##S##_unpack_mixed(const fl_mixed_plan *plan, const T *packed, T *out, void *stream); \
+    int fl_##S##_pack_mixed(const fl_mixed_plan *plan, const T *in, T *packed, void *stream);    \
     /* ---- host-pointer tier: the trait methods' own slice arguments ---- */                   \
     int fl_##S##_pack_host(unsigned width, const T *in, T *out, size_t n_blocks);               \
     int fl_##S##_unpack_host(unsigned width, const T *in, T *out, size_t n_blocks);             \

@@ -271,3 +271,68 @@ def test_cpp_trait_mirror_reference_tests(fl):
     from test_cabi import build_cpp_test
     r = subprocess.run([build_cpp_test()], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout, r.stderr)
+
+
+# ---------------------------------------------------------------------------
+# mixed-width columns (BASELINE.json config 5)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("ty", TYS)
+def test_mixed_width_plan_vs_oracle(fl, oracle, ty):
+    import torch
+    T = tbits(ty)
+    rng = np.random.default_rng(77 + T)
+    n = 300
+    for widths in ((np.arange(n) % (T + 1)).astype(np.uint8),           # every width incl. 0 and T
+                   rng.integers(0, T + 1, size=n).astype(np.uint8),     # random
+                   np.full(n, 3, dtype=np.uint8)):                      # uniform (one bucket)
+        esz = T // 8
+        total = int(widths.astype(np.int64).sum()) * 128 // esz
+        col = values(ty, total, 900 + T)
+        plan = fl.MixedWidthPlan(ty, widths)
+        assert plan.n_blocks == n and plan.packed_bytes == total * esz
+        got = to_np(plan.unpack(to_dev(col)), ty)
+        want, pos = [], 0
+        for w in widths:
+            k = packed_len(ty, int(w))
+            want.append(oracle.unpack(ty, int(w), col[pos:pos + k]))
+            pos += k
+        want = np.concatenate(want)
+        assert np.array_equal(got, want)
+        # pack back: packing the decoded values reproduces the packed column bit for bit
+        back = to_np(plan.pack(to_dev(want)), ty)
+        assert np.array_equal(back, col)
+        plan.close()
+    with pytest.raises(fl.FastLanesError):                               # bitpacking.rs:93
+        fl.MixedWidthPlan(ty, np.array([T + 1], dtype=np.uint8))
+
+
+def test_config5_u32_mixed_widths_10B_integers(fl, oracle):
+    """u32, width[b] = 1 + b % 32, 9 765 625 blocks (10 B integers): the per-GPU slices of the
+    8-way sharding are exercised on one GPU one after the other; pack(unpack(x)) == x and
+    sampled blocks (first/last of every slice) match the oracle."""
+    import torch
+    from fastlanes_amd.sharding import shard_mixed
+    n = 9_765_625
+    widths = (1 + np.arange(n) % 32).astype(np.uint8)
+    total_bytes = int(widths.astype(np.int64).sum()) * 128
+    assert total_bytes == 20_624_988_800
+    col = _rand_dev(total_bytes, 46).view(torch.uint32)
+    plan = fl.MixedWidthPlan("u32", widths)
+    out = plan.unpack(col)
+    assert torch.equal(plan.pack(out).view(torch.int32), col.view(torch.int32))
+    samples = set()
+    for r in range(8):
+        s, c, b0, nb = shard_mixed(widths, 8, r)
+        samples |= {s, s + c - 1}
+        # a rank's slice decoded on its own (own plan over its widths) equals the same rows of the whole
+        if r in (0, 7):
+            sub = fl.MixedWidthPlan("u32", widths[s:s + c])
+            o2 = sub.unpack(col[b0 // 4:(b0 + nb) // 4])
+            assert torch.equal(o2.view(torch.int32), out[s * 1024:(s + c) * 1024].view(torch.int32))
+            sub.close()
+    off = np.concatenate([[0], np.cumsum(widths.astype(np.int64) * 32)])
+    for b in sorted(samples):
+        w = int(widths[b])
+        pk = to_np(col[off[b]:off[b] + 32 * w], "u32")
+        assert np.array_equal(to_np(out[b * 1024:(b + 1) * 1024], "u32"), oracle.unpack("u32", w, pk)), b
+    plan.close()
