@@ -16,37 +16,116 @@ __host__ __device__ constexpr unsigned tau_inv(unsigned j)
     return (j % 8) * 128 + fl_order((j / 8) % 8) * 16 + j / 64;
 }
 
-// One thread per 16-byte OUTPUT cell; the PER_CELL source elements are gathered
-// from the (L1/L2-resident) input block.  transpose: out[i] = in[tau(i)]
-// (transpose.rs:12-14); untranspose: out[tau(i)] = in[i] <=> out[j] = in[tau_inv(j)]
-// (transpose.rs:19-21).
-template <typename T, bool INVERSE>
-__global__ __launch_bounds__(WG) void k_transpose(StreamArgs a)
+// Per-lane view of the permutation.  Along FL-lane l's row order the transposed positions
+// index(r,l) map to T CONSECUTIVE original positions:
+//     tau(index(r, l)) = lane_base(l) + r,   lane_base(l) = (l%16)*64 + FL_ORDER[l/16]*8
+// (verified against transpose.rs:29-36 for every T, r, l by tests/test_oracle_properties.py).
+// So the cell-column thread that owns lanes n*c .. n*c+n-1 for all T rows (fl_device.hpp)
+// holds, per lane, one contiguous run of T elements = T*sizeof(T) bytes of the original
+// order, and the permutation is a pure in-register regroup -- no LDS, no cross-lane traffic:
+//   transpose   : per lane, gather the run with 16-byte loads, regroup, write the T
+//                 transposed rows as full 128-byte-line stores (TileStore);
+//   untranspose : read the T rows as full-line loads, regroup, write each lane's run with
+//                 16-byte stores (plain write-back stores so L2 merges a run's pieces).
+__host__ __device__ constexpr unsigned lane_base(unsigned l) { return (l % 16) * 64 + fl_order(l / 16) * 8; }
+
+template <typename T> __device__ __forceinline__ uint64_t cell_get(const Cell<T>& c, int e)
 {
-    constexpr int PC = Elem<T>::PER_CELL;
-    constexpr int CPB = Elem<T>::CELLS_PER_BLOCK;
-    const uint64_t g = (uint64_t)blockIdx.x * WG + threadIdx.x;
-    const uint64_t blk = g / CPB;
-    const unsigned cell = (unsigned)(g % CPB);
-    if (blk >= a.n_blocks) return;
-    const T* src = reinterpret_cast<const T*>(a.in) + blk * 1024;
-    T v[PC];
-#pragma unroll
-    for (int e = 0; e < PC; ++e) {
-        const unsigned o = cell * PC + e;
-        v[e] = src[INVERSE ? tau_inv(o) : tau(o)];
-    }
-    u32x4 packed;
-    __builtin_memcpy(&packed, v, 16);
-    a.out[blk * CPB + cell] = packed;
+    if constexpr (sizeof(T) == 8) return c.x[e];
+    else if constexpr (sizeof(T) == 4) return c.x[e];
+    else if constexpr (sizeof(T) == 2) return (c.x[e / 2] >> (16 * (e % 2))) & 0xffffu;
+    else return (c.x[e / 4] >> (8 * (e % 4))) & 0xffu;
+}
+template <typename T> __device__ __forceinline__ void cell_or(Cell<T>& c, int e, uint64_t v)
+{
+    if constexpr (sizeof(T) == 8) c.x[e] = v;
+    else if constexpr (sizeof(T) == 4) c.x[e] = (uint32_t)v;
+    else if constexpr (sizeof(T) == 2) c.x[e / 2] |= (uint32_t)v << (16 * (e % 2));
+    else c.x[e / 4] |= (uint32_t)v << (8 * (e % 4));
 }
 
 template <typename T, bool INVERSE>
-hipError_t launch_transpose(const StreamArgs& a, hipStream_t s)
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, PackPolicy<T>::MAXW)))
+void k_transpose(StreamArgs a)
 {
-    if (a.n_blocks == 0) return hipSuccess;
-    const uint64_t threads = a.n_blocks * Elem<T>::CELLS_PER_BLOCK;
-    hipLaunchKernelGGL((k_transpose<T, INVERSE>), dim3((unsigned)((threads + WG - 1) / WG)), dim3(WG), 0, s, a);
+    constexpr int TB = Elem<T>::BITS;
+    constexpr int N = Elem<T>::PER_CELL;                 // FL lanes per thread
+    constexpr int E = sizeof(T);
+    constexpr int RUN_BYTES = TB * E;                    // one lane's run: 8 B (u8) .. 512 B (u64)
+    constexpr int PIECE = RUN_BYTES < 16 ? RUN_BYTES : 16;
+    constexpr int PIECES = RUN_BYTES / PIECE;
+    constexpr int PER_PIECE = PIECE / E;                 // elements per piece
+    typedef uint32_t piece_t __attribute__((ext_vector_type(PIECE / 4)));
+    uint64_t tile;
+    if (!tile_of_workgroup(a, tile)) return;
+    const unsigned tid = threadIdx.x;
+    const uint64_t blk = tile * BLOCKS_PER_WG + (tid >> 3);
+    const unsigned c = tid & 7u;
+    if (blk >= a.n_blocks) return;
+    const char* in_blk = reinterpret_cast<const char*>(a.in) + blk * (uint64_t)(1024 * E);
+    char* out_blk = reinterpret_cast<char*>(a.out) + blk * (uint64_t)(1024 * E);
+    Cell<T> rows[TB];
+
+    if constexpr (!INVERSE) {
+        // original order -> transposed: out[index(r,l)] = in[lane_base(l) + r]   (transpose.rs:12-14)
+        static_for<TB>([&](auto R) { rows[decltype(R)::value] = Cell<T>::zero(); });
+        static_for<N>([&](auto EE) {
+            constexpr int e = decltype(EE)::value;
+            const char* run = in_blk + (uint64_t)lane_base(N * c + e) * E;
+            piece_t p[PIECES];
+            static_for<PIECES>([&](auto K) { p[decltype(K)::value] = *reinterpret_cast<const piece_t*>(run + PIECE * decltype(K)::value); });
+            static_for<TB>([&](auto R) {
+                constexpr int r = decltype(R)::value;
+                constexpr int k = r / PER_PIECE, j = r % PER_PIECE;
+                uint64_t v;
+                if constexpr (E == 8) v = (uint64_t)p[k][2 * j] | ((uint64_t)p[k][2 * j + 1] << 32);
+                else if constexpr (E == 4) v = p[k][j];
+                else if constexpr (E == 2) v = (p[k][j / 2] >> (16 * (j % 2))) & 0xffffu;
+                else v = (p[k][j / 4] >> (8 * (j % 4))) & 0xffu;
+                cell_or<T>(rows[r], e, v);
+            });
+        });
+        const TileStore<Elem<T>::CELLS_PER_BLOCK * 16> st(a.out, tile, a.n_blocks, tid);
+        static_for<TB>([&](auto R) { st.store(Elem<T>::row_cell(decltype(R)::value), rows[decltype(R)::value]); });
+    } else {
+        // transposed -> original order: out[lane_base(l) + r] = in[index(r,l)]   (transpose.rs:19-21)
+        const u32x4* src = reinterpret_cast<const u32x4*>(in_blk) + c;
+        static_for<TB>([&](auto R) {
+            rows[decltype(R)::value] = load_cell<T, true>(src + Elem<T>::row_cell(decltype(R)::value));
+        });
+        static_for<N>([&](auto EE) {
+            constexpr int e = decltype(EE)::value;
+            char* run = out_blk + (uint64_t)lane_base(N * c + e) * E;
+            static_for<PIECES>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                piece_t p;
+                static_for<PIECE / 4>([&](auto D) {
+                    constexpr int d = decltype(D)::value;
+                    uint32_t w = 0;
+                    if constexpr (E == 8) {
+                        const uint64_t v = cell_get<T>(rows[k * PER_PIECE + d / 2], e);
+                        w = (uint32_t)(v >> (32 * (d % 2)));
+                    } else {
+                        static_for<4 / (E < 4 ? E : 4)>([&](auto J) {
+                            constexpr int j = decltype(J)::value;
+                            w |= (uint32_t)cell_get<T>(rows[k * PER_PIECE + d * (4 / E) + j], e) << (8 * E * j);
+                        });
+                    }
+                    p[d] = w;
+                });
+                *reinterpret_cast<piece_t*>(run + PIECE * k) = p;
+            });
+        });
+    }
+}
+
+template <typename T, bool INVERSE>
+hipError_t launch_transpose(const StreamArgs& a0, hipStream_t s)
+{
+    if (a0.n_blocks == 0) return hipSuccess;
+    StreamArgs a = a0;
+    const unsigned grid = plan_grid(a);
+    hipLaunchKernelGGL((k_transpose<T, INVERSE>), dim3(grid), dim3(WG), 0, s, a);
     return hipGetLastError();
 }
 

@@ -1,4 +1,4 @@
 mkdir -p gpurun_out
 R=/root/repo/gpurun_out
 timeout 900 python -m pytest tests -m gpu -x -q > $R/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -5 $R/pytest_gpu.log
-timeout 600 python bench.py --workload u32_mixed_unpack --steps 10 > $R/bench_mixed.json 2> $R/bench_mixed.err; echo "bench rc=$?"; cat $R/bench_mixed.json; tail -3 $R/bench_mixed.err
+timeout 900 python tools/sweep.py --cases quick --json $R/sweep_quick.json 2>&1 | grep -v amdgpu.ids | tee $R/sweep_quick.txt

@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Throughput sweep over the kernel families (HIP-event timing, random data, HBM-resident).
+    python tools/sweep.py [--gb 24] [--reps 7] [--cases all|quick]
+Prints one line per (op, type, width): ms, GB/s (algorithmic bytes), fraction of
+the 8 TB/s HBM peak, G ints/s."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fastlanes_amd as fl  # noqa: E402
+
+ESZ = {"u8": 1, "u16": 2, "u32": 4, "u64": 8}
+TDT = {"u8": torch.uint8, "u16": torch.uint16, "u32": torch.uint32, "u64": torch.uint64}
+dev = torch.device("cuda:0")
+
+
+def rnd(nbytes, seed):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    return torch.randint(-2**63, 2**63 - 1, ((nbytes + 7) // 8,), dtype=torch.int64, device=dev, generator=g).view(torch.uint8)[:nbytes]
+
+
+def bytes_per_block(op, ty, w):
+    T = ESZ[ty] * 8
+    if op in ("pack", "unpack", "for_pack", "unfor_pack"):
+        return 128 * w + 128 * T
+    if op == "undelta_pack":
+        return 128 * w + 128 + 128 * T
+    if op in ("delta", "undelta"):
+        return 2 * 128 * T + 128
+    return 2 * 128 * T  # transpose / untranspose
+
+
+def run(op, ty, w, gb, reps):
+    T = ESZ[ty] * 8
+    bpb = bytes_per_block(op, ty, w)
+    n = max(32, int(gb * 1e9 / bpb))
+    un = lambda s: rnd(n * 128 * T, s).view(TDT[ty])
+    pk = lambda s: rnd(n * 128 * w, s).view(TDT[ty])
+    bases = rnd(n * 128, 3).view(TDT[ty])
+    refs = rnd(n * ESZ[ty], 4).view(TDT[ty])
+    if op == "pack":
+        src, dst = un(1), torch.empty(n * 128 * w // ESZ[ty], dtype=TDT[ty], device=dev)
+        f = lambda: fl.BitPacking.pack(w, src, output=dst)
+    elif op == "unpack":
+        src, dst = pk(1), torch.empty(n * 1024, dtype=TDT[ty], device=dev)
+        f = lambda: fl.BitPacking.unpack(w, src, output=dst)
+    elif op == "for_pack":
+        src, dst = un(1), torch.empty(n * 128 * w // ESZ[ty], dtype=TDT[ty], device=dev)
+        f = lambda: fl.FoR.for_pack(w, src, refs, output=dst)
+    elif op == "unfor_pack":
+        src, dst = pk(1), torch.empty(n * 1024, dtype=TDT[ty], device=dev)
+        f = lambda: fl.FoR.unfor_pack(w, src, refs, output=dst)
+    elif op == "undelta_pack":
+        src, dst = pk(1), torch.empty(n * 1024, dtype=TDT[ty], device=dev)
+        f = lambda: fl.Delta.undelta_pack(w, src, bases, output=dst)
+    elif op in ("delta", "undelta"):
+        src, dst = un(1), torch.empty(n * 1024, dtype=TDT[ty], device=dev)
+        g = getattr(fl.Delta, op)
+        f = lambda: g(src, bases, output=dst)
+    else:
+        src, dst = un(1), torch.empty(n * 1024, dtype=TDT[ty], device=dev)
+        g = getattr(fl.Transpose, op)
+        f = lambda: g(src, output=dst)
+    for _ in range(2):
+        f()
+    torch.cuda.synchronize()
+    ms = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); f(); b.record(); b.synchronize()
+        ms.append(a.elapsed_time(b))
+    ms.sort()
+    med = ms[len(ms) // 2]
+    gbps = n * bpb / med / 1e6
+    return {"op": op, "ty": ty, "w": w, "n_blocks": n, "ms": round(med, 4), "GBps": round(gbps, 1),
+            "frac": round(gbps / 8000, 4), "Gints": round(n * 1024 / med / 1e6, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gb", type=float, default=24.0)
+    ap.add_argument("--reps", type=int, default=7)
+    ap.add_argument("--cases", default="quick")
+    ap.add_argument("--json", default=None)
+    args = ap.parse_args()
+    cases = []
+    if args.cases == "quick":
+        cases = [("unpack", "u32", 7), ("pack", "u32", 7), ("unfor_pack", "u32", 7), ("for_pack", "u32", 7),
+                 ("undelta_pack", "u32", 12), ("unpack", "u64", 17), ("pack", "u64", 17),
+                 ("unpack", "u16", 3), ("pack", "u16", 3), ("unpack", "u8", 3), ("pack", "u8", 3),
+                 ("undelta_pack", "u16", 9), ("undelta_pack", "u64", 20), ("undelta_pack", "u8", 4)]
+        for ty in ("u8", "u16", "u32", "u64"):
+            cases += [(op, ty, 0) for op in ("delta", "undelta", "transpose", "untranspose")]
+    elif args.cases == "widths":
+        for ty in ("u8", "u16", "u32", "u64"):
+            T = ESZ[ty] * 8
+            for w in sorted({1, 2, 3, T // 4, T // 2, T - 1, T}):
+                cases += [("unpack", ty, w), ("pack", ty, w)]
+    out = []
+    for op, ty, w in cases:
+        r = run(op, ty, w, args.gb, args.reps)
+        out.append(r)
+        print(f"{op:13s} {ty:4s} W={w:<3d} n={r['n_blocks']:>9d} {r['ms']:9.4f} ms {r['GBps']:8.1f} GB/s {r['frac']:.3f} {r['Gints']:8.1f} Gint/s", flush=True)
+        torch.cuda.empty_cache()
+    if args.json:
+        json.dump(out, open(args.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
