@@ -33,6 +33,8 @@ def _signatures(ty):
         "undelta_pack": [_U, _P, _P, _P, _Z, _P],
         "transpose": [_P, _P, _Z, _P],
         "untranspose": [_P, _P, _Z, _P],
+        "undelta_pack_untranspose": [_U, _P, _P, _P, _Z, _P],
+        "transpose_delta_pack": [_U, _P, _P, _P, _Z, _P],
         "unpack_mixed": [_P, _P, _P, _P],
         "pack_mixed": [_P, _P, _P, _P],
     }

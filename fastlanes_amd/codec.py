@@ -281,6 +281,33 @@ class Delta:
         return Delta._go("undelta_pack", width, input, base, output, lambda ty: packed_len(ty, width))
 
 
+    # ---- extensions: the compositions delta.rs:88-100 performs, in one pass ----
+    @staticmethod
+    def undelta_pack_untranspose(width, input, base, output=None):
+        """== Transpose.untranspose(Delta.undelta_pack(width, input, base)): decodes straight to
+        the ORIGINAL element order.  Device tier only."""
+        if not _is_torch(input):
+            raise TypeError("undelta_pack_untranspose is a device-tier extension (pass CUDA tensors)")
+        return Delta._go("undelta_pack_untranspose", width, input, base, output, lambda ty: packed_len(ty, width))
+
+    @staticmethod
+    def transpose_delta_pack(width, input, base, output=None):
+        """== BitPacking.pack(width, Delta.delta(Transpose.transpose(input), base)): encodes straight
+        from the ORIGINAL element order.  Device tier only."""
+        if not _is_torch(input):
+            raise TypeError("transpose_delta_pack is a device-tier extension (pass CUDA tensors)")
+        src = _Arg(input)
+        ty = src.ty
+        if width > _lib.BITS[ty]:
+            raise FastLanesError(1, f"fl_{ty}_transpose_delta_pack")
+        n = _blocks(src.n, 1024, "transpose_delta_pack input")
+        b = _Arg(base, ty)
+        if b.n != n * (1024 // _lib.BITS[ty]):
+            raise ValueError("base must hold LANES elements per block")
+        out = _Arg(output, ty) if output is not None else _Arg(_empty_like(src, n * packed_len(ty, width), ty), ty)
+        return _run("transpose_delta_pack", ty, width, src, out, n, aux=b)
+
+
 class Transpose:
     """transpose.rs:4-7"""
 

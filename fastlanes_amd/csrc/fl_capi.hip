@@ -45,7 +45,7 @@ int run_stream(stream_launch_t fn, const T* in, T* out, const void* aux, size_t 
 template <typename T> int dev_pack(unsigned w, const T* in, T* out, size_t n, void* s)
 {
     if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
-    return run_stream<T>(pack_table_impl<T, false>().fn[w], in, out, nullptr, 0, n, true, w != 0, false, s);
+    return run_stream<T>(pack_table_impl<T, PACK_PLAIN>().fn[w], in, out, nullptr, 0, n, true, w != 0, false, s);
 }
 template <typename T> int dev_unpack(unsigned w, const T* in, T* out, size_t n, void* s)
 {
@@ -56,7 +56,7 @@ template <typename T>
 int dev_for_pack(unsigned w, const T* in, const T* refs, size_t stride, T* out, size_t n, void* s)
 {
     if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
-    return run_stream<T>(pack_table_impl<T, true>().fn[w], in, out, refs, stride ? 1 : 0, n, true, w != 0, true, s);
+    return run_stream<T>(pack_table_impl<T, PACK_FOR>().fn[w], in, out, refs, stride ? 1 : 0, n, true, w != 0, true, s);
 }
 template <typename T>
 int dev_unfor_pack(unsigned w, const T* in, const T* refs, size_t stride, T* out, size_t n, void* s)
@@ -70,6 +70,20 @@ int dev_undelta_pack(unsigned w, const T* in, const T* bases, T* out, size_t n, 
     if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
     if (n && misaligned(bases)) return FL_ERR_ALIGN;
     return run_stream<T>(unpack_table_impl<T, BODY_UNDELTA>().fn[w], in, out, bases, 0, n, w != 0, true, true, s);
+}
+template <typename T>
+int dev_undelta_pack_untranspose(unsigned w, const T* in, const T* bases, T* out, size_t n, void* s)
+{
+    if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
+    if (n && misaligned(bases)) return FL_ERR_ALIGN;
+    return run_stream<T>(unpack_table_impl<T, BODY_UNDELTA_UNTRANSPOSE>().fn[w], in, out, bases, 0, n, w != 0, true, true, s);
+}
+template <typename T>
+int dev_transpose_delta_pack(unsigned w, const T* in, const T* bases, T* out, size_t n, void* s)
+{
+    if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
+    if (n && misaligned(bases)) return FL_ERR_ALIGN;
+    return run_stream<T>(pack_table_impl<T, PACK_TRANSPOSE_DELTA>().fn[w], in, out, bases, 0, n, true, w != 0, true, s);
 }
 template <typename T> int dev_delta(bool inverse, const T* in, const T* bases, T* out, size_t n, void* s)
 {
@@ -271,6 +285,10 @@ size_t fl_packed_len(unsigned type_bits, unsigned width)
     int fl_##S##_undelta(const T* in, const T* b, T* out, size_t n, void* s) { return dev_delta<T>(true, in, b, out, n, s); } \
     int fl_##S##_undelta_pack(unsigned w, const T* in, const T* b, T* out, size_t n, void* s)             \
     { return dev_undelta_pack<T>(w, in, b, out, n, s); }                                                  \
+    int fl_##S##_undelta_pack_untranspose(unsigned w, const T* in, const T* b, T* out, size_t n, void* s) \
+    { return dev_undelta_pack_untranspose<T>(w, in, b, out, n, s); }                                      \
+    int fl_##S##_transpose_delta_pack(unsigned w, const T* in, const T* b, T* out, size_t n, void* s)     \
+    { return dev_transpose_delta_pack<T>(w, in, b, out, n, s); }                                          \
     int fl_##S##_transpose(const T* in, T* out, size_t n, void* s) { return dev_transpose<T>(false, in, out, n, s); } \
     int fl_##S##_untranspose(const T* in, T* out, size_t n, void* s) { return dev_transpose<T>(true, in, out, n, s); } \
     int fl_##S##_unpack_mixed(const fl_mixed_plan* p, const T* pk, T* out, void* s) { return run_mixed<T>(false, p, pk, out, s); } \

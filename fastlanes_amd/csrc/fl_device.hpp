@@ -177,6 +177,104 @@ __device__ __forceinline__ void store_cell(u32x4* p, const Cell<T>& c)
 }
 
 // ---------------------------------------------------------------------------
+// The FastLanes transpose (transpose.rs:9-36) seen from a cell-column thread.
+// Along FL-lane l's row order the transposed positions index(r,l) map to T CONSECUTIVE
+// original positions:
+//     tau(index(r, l)) = lane_base(l) + r,   lane_base(l) = (l%16)*64 + FL_ORDER[l/16]*8
+// (checked against transpose.rs:29-36 for every T, r, l in tests/test_oracle_properties.py).
+// The thread that owns lanes n*c .. n*c+n-1 for all T rows therefore holds, per lane, one
+// contiguous RUN of T elements (T*sizeof(T) bytes: 8 B for u8 .. 512 B for u64) of the
+// original order, and the permutation is a pure in-register regroup: no LDS, no cross-lane
+// traffic.  load_lane_runs gathers the runs (16-byte loads) into row cells; store_lane_runs
+// scatters row cells back as runs (16-byte write-back stores, so L2 merges a run's pieces).
+// ---------------------------------------------------------------------------
+__host__ __device__ constexpr unsigned lane_base(unsigned l) { return (l % 16) * 64 + fl_order(l / 16) * 8; }
+
+template <typename T> __device__ __forceinline__ uint64_t cell_get(const Cell<T>& c, int e)
+{
+    if constexpr (sizeof(T) == 8) return c.x[e];
+    else if constexpr (sizeof(T) == 4) return c.x[e];
+    else if constexpr (sizeof(T) == 2) return (c.x[e / 2] >> (16 * (e % 2))) & 0xffffu;
+    else return (c.x[e / 4] >> (8 * (e % 4))) & 0xffu;
+}
+template <typename T> __device__ __forceinline__ void cell_or(Cell<T>& c, int e, uint64_t v)
+{
+    if constexpr (sizeof(T) == 8) c.x[e] = v;
+    else if constexpr (sizeof(T) == 4) c.x[e] = (uint32_t)v;
+    else if constexpr (sizeof(T) == 2) c.x[e / 2] |= (uint32_t)v << (16 * (e % 2));
+    else c.x[e / 4] |= (uint32_t)v << (8 * (e % 4));
+}
+
+template <typename T> struct LaneRun {
+    static constexpr int TB = Elem<T>::BITS;
+    static constexpr int N = Elem<T>::PER_CELL;          // FL lanes per thread
+    static constexpr int E = sizeof(T);
+    static constexpr int RUN_BYTES = TB * E;
+    static constexpr int PIECE = RUN_BYTES < 16 ? RUN_BYTES : 16;
+    static constexpr int PIECES = RUN_BYTES / PIECE;
+    static constexpr int PER_PIECE = PIECE / E;          // elements per piece
+    typedef uint32_t piece_t __attribute__((ext_vector_type(PIECE / 4)));
+};
+
+// rows[r] (column c of a TRANSPOSED block) <- original-order block at `blk`
+template <typename T>
+__device__ __forceinline__ void load_lane_runs(const char* blk, unsigned c, Cell<T>* rows)
+{
+    using L = LaneRun<T>;
+    using piece_t = typename L::piece_t;
+    static_for<L::TB>([&](auto R) { rows[decltype(R)::value] = Cell<T>::zero(); });
+    static_for<L::N>([&](auto EE) {
+        constexpr int e = decltype(EE)::value;
+        const char* run = blk + (uint64_t)lane_base(L::N * c + e) * L::E;
+        piece_t p[L::PIECES];
+        static_for<L::PIECES>([&](auto K) {
+            p[decltype(K)::value] = *reinterpret_cast<const piece_t*>(run + L::PIECE * decltype(K)::value);
+        });
+        static_for<L::TB>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            constexpr int k = r / L::PER_PIECE, j = r % L::PER_PIECE;
+            uint64_t v;
+            if constexpr (L::E == 8) v = (uint64_t)p[k][2 * j] | ((uint64_t)p[k][2 * j + 1] << 32);
+            else if constexpr (L::E == 4) v = p[k][j];
+            else if constexpr (L::E == 2) v = (p[k][j / 2] >> (16 * (j % 2))) & 0xffffu;
+            else v = (p[k][j / 4] >> (8 * (j % 4))) & 0xffu;
+            cell_or<T>(rows[r], e, v);
+        });
+    });
+}
+
+// original-order block at `blk` <- rows[r] (column c of a TRANSPOSED block)
+template <typename T>
+__device__ __forceinline__ void store_lane_runs(char* blk, unsigned c, const Cell<T>* rows)
+{
+    using L = LaneRun<T>;
+    using piece_t = typename L::piece_t;
+    static_for<L::N>([&](auto EE) {
+        constexpr int e = decltype(EE)::value;
+        char* run = blk + (uint64_t)lane_base(L::N * c + e) * L::E;
+        static_for<L::PIECES>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            piece_t p;
+            static_for<L::PIECE / 4>([&](auto D) {
+                constexpr int d = decltype(D)::value;
+                uint32_t w = 0;
+                if constexpr (L::E == 8) {
+                    const uint64_t v = cell_get<T>(rows[k * L::PER_PIECE + d / 2], e);
+                    w = (uint32_t)(v >> (32 * (d % 2)));
+                } else {
+                    static_for<4 / (L::E < 4 ? L::E : 4)>([&](auto J) {
+                        constexpr int j = decltype(J)::value;
+                        w |= (uint32_t)cell_get<T>(rows[k * L::PER_PIECE + d * (4 / L::E) + j], e) << (8 * L::E * j);
+                    });
+                }
+                p[d] = w;
+            });
+            *reinterpret_cast<piece_t*>(run + L::PIECE * k) = p;
+        });
+    });
+}
+
+// ---------------------------------------------------------------------------
 // unpack_rows: the unpack! macro (macros.rs:100-174) on one cell column.
 //   in[w]   : packed word-row w of this column (W cells, all in registers)
 //   f(R, c) : called for R = integral_constant<int,row>, row = 0..T-1 in order

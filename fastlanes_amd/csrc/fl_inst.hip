@@ -4,6 +4,7 @@
 //   0 unpack (store)   1 unfor_pack   2 undelta_pack   3 pack   4 for_pack
 //   5 delta / undelta / transpose / untranspose / unpack_single
 //   6 unpack over a mixed-width plan   7 pack over a mixed-width plan
+//   8 undelta_pack+untranspose (fused decode to original order)   9 transpose+delta+pack (fused encode)
 #include "fl_kernels.hpp"
 #include "fl_misc.hpp"
 #include "fl_mixed.hpp"
@@ -22,11 +23,11 @@ template <> const WidthTable<T>& unpack_table_impl<T, BODY_ADD_REF>() { return t
 static constexpr WidthTable<T> t_undelta = make_unpack_table<T, BODY_UNDELTA>(Ws{});
 template <> const WidthTable<T>& unpack_table_impl<T, BODY_UNDELTA>() { return t_undelta; }
 #elif FL_FAMILY == 3
-static constexpr WidthTable<T> t_pack = make_pack_table<T, false>(Ws{});
-template <> const WidthTable<T>& pack_table_impl<T, false>() { return t_pack; }
+static constexpr WidthTable<T> t_pack = make_pack_table<T, PACK_PLAIN>(Ws{});
+template <> const WidthTable<T>& pack_table_impl<T, PACK_PLAIN>() { return t_pack; }
 #elif FL_FAMILY == 4
-static constexpr WidthTable<T> t_forpack = make_pack_table<T, true>(Ws{});
-template <> const WidthTable<T>& pack_table_impl<T, true>() { return t_forpack; }
+static constexpr WidthTable<T> t_forpack = make_pack_table<T, PACK_FOR>(Ws{});
+template <> const WidthTable<T>& pack_table_impl<T, PACK_FOR>() { return t_forpack; }
 #elif FL_FAMILY == 5
 template <> stream_launch_t delta_launcher<T>(bool inverse)
 {
@@ -46,7 +47,13 @@ template <> const MixedTable<T>& mixed_table_impl<T, false>() { return t_mixed_u
 #elif FL_FAMILY == 7
 static constexpr MixedTable<T> t_mixed_pack = make_mixed_table<T, true>(Ws{});
 template <> const MixedTable<T>& mixed_table_impl<T, true>() { return t_mixed_pack; }
+#elif FL_FAMILY == 8
+static constexpr WidthTable<T> t_undelta_untr = make_unpack_table<T, BODY_UNDELTA_UNTRANSPOSE>(Ws{});
+template <> const WidthTable<T>& unpack_table_impl<T, BODY_UNDELTA_UNTRANSPOSE>() { return t_undelta_untr; }
+#elif FL_FAMILY == 9
+static constexpr WidthTable<T> t_tr_delta_pack = make_pack_table<T, PACK_TRANSPOSE_DELTA>(Ws{});
+template <> const WidthTable<T>& pack_table_impl<T, PACK_TRANSPOSE_DELTA>() { return t_tr_delta_pack; }
 #else
-#error "FL_FAMILY must be 0..7"
+#error "FL_FAMILY must be 0..9"
 #endif
 }  // namespace fl

@@ -14,7 +14,14 @@ namespace fl {
 constexpr int WG = 256;             // 4 wavefronts; 32 blocks ("one tile") per workgroup
 constexpr int BLOCKS_PER_WG = WG / 8;
 
-enum UnpackBody { BODY_STORE = 0, BODY_ADD_REF = 1, BODY_UNDELTA = 2 };
+enum UnpackBody { BODY_STORE = 0, BODY_ADD_REF = 1, BODY_UNDELTA = 2,
+                  // extension: undelta_pack fused with untranspose -- the decoded block is
+                  // written in ORIGINAL order (= Transpose::untranspose(Delta::undelta_pack(..)), delta.rs:88-100)
+                  BODY_UNDELTA_UNTRANSPOSE = 3 };
+enum PackMode { PACK_PLAIN = 0, PACK_FOR = 1,
+                // extension: pack(delta(transpose(v), base)) in one pass (the encode half of
+                // delta.rs:88-95): reads the ORIGINAL-order block
+                PACK_TRANSPOSE_DELTA = 2 };
 
 // Kernel argument block shared by all streaming kernels.
 struct StreamArgs {
@@ -105,7 +112,7 @@ void k_unpack(StreamArgs a)
         unpack_rows<T, W>(in, [&](auto R, const Cell<T>& v) {
             st.store(Elem<T>::row_cell(decltype(R)::value), v.add(ref));        // ffor.rs:46-48
         });
-    } else {
+    } else if constexpr (BODY == BODY_UNDELTA) {
         // base[lane] for this column's lanes = cell c of the block's 128-byte base row
         const u32x4* bases = static_cast<const u32x4*>(a.aux);
         Cell<T> prev = load_cell<T, false>(bases + blk * 8 + c);                // delta.rs:56
@@ -113,11 +120,20 @@ void k_unpack(StreamArgs a)
             prev = v.add(prev);                                                 // delta.rs:58-60
             st.store(Elem<T>::row_cell(decltype(R)::value), prev);
         });
+    } else {
+        const u32x4* bases = static_cast<const u32x4*>(a.aux);
+        Cell<T> prev = load_cell<T, false>(bases + blk * 8 + c);
+        Cell<T> rows[Elem<T>::BITS];
+        unpack_rows<T, W>(in, [&](auto R, const Cell<T>& v) {
+            prev = v.add(prev);
+            rows[decltype(R)::value] = prev;
+        });
+        store_lane_runs<T>(reinterpret_cast<char*>(a.out) + blk * (uint64_t)(1024 * sizeof(T)), c, rows);
     }
 }
 
 // pack / for_pack  (bitpacking.rs:65-74, ffor.rs:24-36): T cell-rows -> W cell-rows.
-template <typename T, int W, bool FOR>
+template <typename T, int W, int MODE>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, PackPolicy<T>::MAXW)))
 void k_pack(StreamArgs a)
 {
@@ -133,17 +149,27 @@ void k_pack(StreamArgs a)
 
     const u32x4* un = a.in + blk * (uint64_t)Elem<T>::CELLS_PER_BLOCK + c;
     Cell<T> ref = Cell<T>::zero();
-    if constexpr (FOR) ref = Cell<T>::splat(static_cast<const T*>(a.aux)[blk * a.aux_stride]);
+    if constexpr (MODE == PACK_FOR) ref = Cell<T>::splat(static_cast<const T*>(a.aux)[blk * a.aux_stride]);
 
     // Issue all T row loads up front (they are independent), then combine.
     Cell<T> rows[TB];
-    static_for<TB>([&](auto R) {
-        rows[decltype(R)::value] = load_cell<T, NTL>(un + Elem<T>::row_cell(decltype(R)::value));
-    });
+    if constexpr (MODE == PACK_TRANSPOSE_DELTA) {
+        load_lane_runs<T>(reinterpret_cast<const char*>(a.in) + blk * (uint64_t)(1024 * sizeof(T)), c, rows);   // transpose.rs:12-14
+        Cell<T> prev = load_cell<T, false>(static_cast<const u32x4*>(a.aux) + blk * 8 + c);
+        static_for<TB>([&](auto R) {                                            // delta.rs:26-31
+            const Cell<T> next = rows[decltype(R)::value];
+            rows[decltype(R)::value] = next.sub(prev);
+            prev = next;
+        });
+    } else {
+        static_for<TB>([&](auto R) {
+            rows[decltype(R)::value] = load_cell<T, NTL>(un + Elem<T>::row_cell(decltype(R)::value));
+        });
+    }
     const TileStore<(W ? W : 1) * 128> st(a.out, tile, a.n_blocks, tid);
     pack_rows<T, W>(
         [&](auto R) {
-            if constexpr (FOR) return rows[decltype(R)::value].sub(ref);        // ffor.rs:32-34
+            if constexpr (MODE == PACK_FOR) return rows[decltype(R)::value].sub(ref);   // ffor.rs:32-34
             else return rows[decltype(R)::value];                               // bitpacking.rs:70-72
         },
         [&](auto Wd, const Cell<T>& v) { st.store(8 * decltype(Wd)::value, v); });
@@ -202,13 +228,13 @@ hipError_t launch_unpack(const StreamArgs& a0, hipStream_t s)
     hipLaunchKernelGGL((k_unpack<T, W, BODY>), dim3(grid), dim3(WG), 0, s, a);
     return hipGetLastError();
 }
-template <typename T, int W, bool FOR>
+template <typename T, int W, int MODE>
 hipError_t launch_pack(const StreamArgs& a0, hipStream_t s)
 {
     if (a0.n_blocks == 0 || W == 0) return hipSuccess;
     StreamArgs a = a0;
     const unsigned grid = plan_grid(a);
-    hipLaunchKernelGGL((k_pack<T, W, FOR>), dim3(grid), dim3(WG), 0, s, a);
+    hipLaunchKernelGGL((k_pack<T, W, MODE>), dim3(grid), dim3(WG), 0, s, a);
     return hipGetLastError();
 }
 template <typename T, bool INVERSE>
@@ -229,15 +255,15 @@ constexpr WidthTable<T> make_unpack_table(std::integer_sequence<int, Ws...>)
 {
     return WidthTable<T>{{&launch_unpack<T, Ws, BODY>...}};
 }
-template <typename T, bool FOR, int... Ws>
+template <typename T, int MODE, int... Ws>
 constexpr WidthTable<T> make_pack_table(std::integer_sequence<int, Ws...>)
 {
-    return WidthTable<T>{{&launch_pack<T, Ws, FOR>...}};
+    return WidthTable<T>{{&launch_pack<T, Ws, MODE>...}};
 }
 
 // Specialised once per (element type, family) in fl_inst.hip
 template <typename T, int BODY> const WidthTable<T>& unpack_table_impl();
-template <typename T, bool FOR> const WidthTable<T>& pack_table_impl();
+template <typename T, int MODE> const WidthTable<T>& pack_table_impl();
 template <typename T> stream_launch_t delta_launcher(bool inverse);
 
 }  // namespace fl

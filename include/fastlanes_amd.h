@@ -122,6 +122,16 @@ const uint64_t *fl_mixed_plan_offsets(const fl_mixed_plan *plan);
     /* Delta::undelta_pack::<W> (delta.rs:11-16,47-63); output stays in transposed order */     \
     int fl_##S##_undelta_pack(unsigned width, const T *in, const T *bases, T *out,              \
                               size_t n_blocks, void *stream);                                   \
+    /* EXTENSIONS beyond the reference's methods; defined as the compositions  \
+     * the reference's own test/bench perform (delta.rs:88-100, benches/delta.rs:20-27):               \
+     *   undelta_pack_untranspose(W, pk, bases) == untranspose(undelta_pack::<W>(pk, bases))           \
+     *   transpose_delta_pack(W, v, bases)      == pack::<W>(delta(transpose(v), bases))               \
+     * i.e. decode straight to ORIGINAL order / encode straight from it, saving one 2x(1024*T/8)-byte  \
+     * round trip per block. */                                                                       \
+    int fl_##S##_undelta_pack_untranspose(unsigned width, const T *in, const T *bases, T *out,  \
+                                          size_t n_blocks, void *stream);                       \
+    int fl_##S##_transpose_delta_pack(unsigned width, const T *in, const T *bases, T *out,      \
+                                      size_t n_blocks, void *stream);                           \
     /* Transpose::transpose (transpose.rs:5,11-15) */                                           \
     int fl_##S##_transpose(const T *in, T *out, size_t n_blocks, void *stream);                 \
     /* Transpose::untranspose (transpose.rs:6,17-22) */                                         \

@@ -336,3 +336,32 @@ def test_config5_u32_mixed_widths_10B_integers(fl, oracle):
         pk = to_np(col[off[b]:off[b] + 32 * w], "u32")
         assert np.array_equal(to_np(out[b * 1024:(b + 1) * 1024], "u32"), oracle.unpack("u32", w, pk)), b
     plan.close()
+
+
+# ---------------------------------------------------------------------------
+# extensions: fused decode to / encode from the ORIGINAL order.
+# Defined as compositions of reference functions, so the oracle composition is the spec.
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("ty", TYS)
+def test_fused_transpose_extensions_vs_oracle_composition(fl, oracle, ty):
+    import torch
+    T = tbits(ty)
+    n = 37
+    for w in range(T + 1):
+        seed = 11000 + 64 * T + w
+        pk = values(ty, n * packed_len(ty, w), seed)
+        bases = values(ty, n * lanes(ty), seed + 1)
+        v = values(ty, n * 1024, seed + 2)
+        # decode: untranspose(undelta_pack(pk, bases))
+        got = to_np(fl.Delta.undelta_pack_untranspose(w, to_dev(pk), to_dev(bases)), ty)
+        want = oracle.batch("untranspose", ty, None, oracle.batch("undelta_pack", ty, w, pk, aux=bases, n_blocks=n))
+        assert np.array_equal(got, want), (ty, w, "undelta_pack_untranspose")
+        # encode: pack(delta(transpose(v), bases))
+        got = to_np(fl.Delta.transpose_delta_pack(w, to_dev(v), to_dev(bases)), ty)
+        want = oracle.batch("pack", ty, w, oracle.batch("delta", ty, None, oracle.batch("transpose", ty, None, v), aux=bases))
+        assert np.array_equal(got, want), (ty, w, "transpose_delta_pack")
+    # full-width round trip: decode(encode(v)) == v in the original order
+    v = values(ty, n * 1024, 5)
+    bases = values(ty, n * lanes(ty), 6)
+    enc = fl.Delta.transpose_delta_pack(T, to_dev(v), to_dev(bases))
+    assert np.array_equal(to_np(fl.Delta.undelta_pack_untranspose(T, enc, to_dev(bases)), ty), v)

@@ -28,7 +28,7 @@ def bytes_per_block(op, ty, w):
     T = ESZ[ty] * 8
     if op in ("pack", "unpack", "for_pack", "unfor_pack"):
         return 128 * w + 128 * T
-    if op == "undelta_pack":
+    if op in ("undelta_pack", "undelta_pack_untranspose", "transpose_delta_pack"):
         return 128 * w + 128 + 128 * T
     if op in ("delta", "undelta"):
         return 2 * 128 * T + 128
@@ -58,6 +58,12 @@ def run(op, ty, w, gb, reps):
     elif op == "undelta_pack":
         src, dst = pk(1), torch.empty(n * 1024, dtype=TDT[ty], device=dev)
         f = lambda: fl.Delta.undelta_pack(w, src, bases, output=dst)
+    elif op == "undelta_pack_untranspose":
+        src, dst = pk(1), torch.empty(n * 1024, dtype=TDT[ty], device=dev)
+        f = lambda: fl.Delta.undelta_pack_untranspose(w, src, bases, output=dst)
+    elif op == "transpose_delta_pack":
+        src, dst = un(1), torch.empty(n * 128 * w // ESZ[ty], dtype=TDT[ty], device=dev)
+        f = lambda: fl.Delta.transpose_delta_pack(w, src, bases, output=dst)
     elif op in ("delta", "undelta"):
         src, dst = un(1), torch.empty(n * 1024, dtype=TDT[ty], device=dev)
         g = getattr(fl.Delta, op)
@@ -96,6 +102,11 @@ def main():
                  ("undelta_pack", "u16", 9), ("undelta_pack", "u64", 20), ("undelta_pack", "u8", 4)]
         for ty in ("u8", "u16", "u32", "u64"):
             cases += [(op, ty, 0) for op in ("delta", "undelta", "transpose", "untranspose")]
+    elif args.cases == "fused":
+        cases = [("undelta_pack", "u32", 12), ("undelta_pack_untranspose", "u32", 12), ("transpose_delta_pack", "u32", 12),
+                 ("undelta_pack_untranspose", "u64", 20), ("transpose_delta_pack", "u64", 20),
+                 ("undelta_pack_untranspose", "u16", 9), ("transpose_delta_pack", "u16", 9),
+                 ("undelta_pack_untranspose", "u8", 4), ("transpose_delta_pack", "u8", 4)]
     elif args.cases == "widths":
         for ty in ("u8", "u16", "u32", "u64"):
             T = ESZ[ty] * 8
