@@ -35,6 +35,8 @@ def _signatures(ty):
         "untranspose": [_P, _P, _Z, _P],
         "undelta_pack_untranspose": [_U, _P, _P, _P, _Z, _P],
         "transpose_delta_pack": [_U, _P, _P, _P, _Z, _P],
+        "unpack_block_sums": [_U, _P, _Z, _P, _P],
+        "block_min_max": [_P, _Z, _P, _P, _P],
         "unpack_mixed": [_P, _P, _P, _P],
         "pack_mixed": [_P, _P, _P, _P],
     }

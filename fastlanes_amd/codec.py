@@ -202,6 +202,40 @@ class BitPacking:
 
     unchecked_unpack_single = unpack_single
 
+    # ---- extensions -------------------------------------------------------
+    @staticmethod
+    def unpack_block_sums(width, packed, n_blocks=None):
+        """sums[b] = sum(BitPacking.unpack(width, block b)) as wrapping uint64, without
+        materialising the values.  Device tier only; returns a CUDA int64 tensor (bit pattern
+        of the uint64 sums)."""
+        import torch
+        src = _Arg(packed)
+        ty = src.ty
+        if width > _lib.BITS[ty]:
+            raise FastLanesError(1, f"fl_{ty}_unpack_block_sums")
+        n = _blocks(src.n, packed_len(ty, width), "unpack_block_sums input")
+        if n is None:
+            n = n_blocks or 0
+        out = torch.empty(n, dtype=torch.int64, device=src.x.device)
+        with torch.cuda.device(src.x.device):
+            _check(getattr(_lib.load(), f"fl_{ty}_unpack_block_sums")(width, src.ptr, n, out.data_ptr(), _stream(src)),
+                   f"fl_{ty}_unpack_block_sums")
+        return out
+
+    @staticmethod
+    def block_min_max(values):
+        """(mins, maxs) per 1024-value block of an unpacked column.  Device tier only."""
+        import torch
+        src = _Arg(values)
+        ty = src.ty
+        n = _blocks(src.n, 1024, "block_min_max input")
+        mins = torch.empty(n, dtype=src.x.dtype, device=src.x.device)
+        maxs = torch.empty(n, dtype=src.x.dtype, device=src.x.device)
+        with torch.cuda.device(src.x.device):
+            _check(getattr(_lib.load(), f"fl_{ty}_block_min_max")(src.ptr, n, mins.data_ptr(), maxs.data_ptr(), _stream(src)),
+                   f"fl_{ty}_block_min_max")
+        return mins, maxs
+
 
 class FoR:
     """ffor.rs:4-18.  `reference` is a scalar, or (device tier) a per-block CUDA tensor."""

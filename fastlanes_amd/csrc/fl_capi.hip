@@ -6,6 +6,7 @@
 #include "fl_kernels.hpp"
 #include "fl_misc.hpp"
 #include "fl_mixed.hpp"
+#include "fl_consume.hpp"
 
 #include <new>
 #include <vector>
@@ -84,6 +85,27 @@ int dev_transpose_delta_pack(unsigned w, const T* in, const T* bases, T* out, si
     if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
     if (n && misaligned(bases)) return FL_ERR_ALIGN;
     return run_stream<T>(pack_table_impl<T, PACK_TRANSPOSE_DELTA>().fn[w], in, out, bases, 0, n, true, w != 0, true, s);
+}
+template <typename T>
+int dev_unpack_block_sums(unsigned w, const T* in, size_t n, uint64_t* sums, void* s)
+{
+    if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
+    if (n == 0) return FL_OK;
+    if (!sums || (w != 0 && !in)) return FL_ERR_NULL;
+    if (misaligned(in)) return FL_ERR_ALIGN;
+    ReduceArgs a{reinterpret_cast<const u32x4*>(in), sums, nullptr, n, 0};
+    hipError_t e = sum_table_impl<T>().fn[w](a, static_cast<hipStream_t>(s));
+    return e == hipSuccess ? FL_OK : hip_fail(e);
+}
+template <typename T>
+int dev_block_min_max(const T* in, size_t n, T* mins, T* maxs, void* s)
+{
+    if (n == 0) return FL_OK;
+    if (!in || !mins || !maxs) return FL_ERR_NULL;
+    if (misaligned(in)) return FL_ERR_ALIGN;
+    ReduceArgs a{reinterpret_cast<const u32x4*>(in), mins, maxs, n, 0};
+    hipError_t e = min_max_launcher<T>()(a, static_cast<hipStream_t>(s));
+    return e == hipSuccess ? FL_OK : hip_fail(e);
 }
 template <typename T> int dev_delta(bool inverse, const T* in, const T* bases, T* out, size_t n, void* s)
 {
@@ -289,6 +311,10 @@ size_t fl_packed_len(unsigned type_bits, unsigned width)
     { return dev_undelta_pack_untranspose<T>(w, in, b, out, n, s); }                                      \
     int fl_##S##_transpose_delta_pack(unsigned w, const T* in, const T* b, T* out, size_t n, void* s)     \
     { return dev_transpose_delta_pack<T>(w, in, b, out, n, s); }                                          \
+    int fl_##S##_unpack_block_sums(unsigned w, const T* in, size_t n, uint64_t* sums, void* s)           \
+    { return dev_unpack_block_sums<T>(w, in, n, sums, s); }                                               \
+    int fl_##S##_block_min_max(const T* in, size_t n, T* mins, T* maxs, void* s)                          \
+    { return dev_block_min_max<T>(in, n, mins, maxs, s); }                                                \
     int fl_##S##_transpose(const T* in, T* out, size_t n, void* s) { return dev_transpose<T>(false, in, out, n, s); } \
     int fl_##S##_untranspose(const T* in, T* out, size_t n, void* s) { return dev_transpose<T>(true, in, out, n, s); } \
     int fl_##S##_unpack_mixed(const fl_mixed_plan* p, const T* pk, T* out, void* s) { return run_mixed<T>(false, p, pk, out, s); } \

@@ -1,0 +1,154 @@
+// fl_consume.hpp -- fused consumers / producers' helpers around the codec.
+// EXTENSIONS: the reference has no such functions; each is defined as a plain reduction over
+// what the reference functions produce, so the oracle composition is the specification.
+//   unpack_block_sums<W> : s[b] = sum_{i<1024} unpack::<W>(packed_b)[i]   (wrapping u64)
+//                          -- the read-bound regime: 128*W bytes in, 8 bytes out per block.
+//   block_min_max        : mn[b], mx[b] over the 1024 values of unpacked block b -- what an
+//                          encoder needs to pick FoR's reference (min) and the width
+//                          (bits(max - min)) before calling for_pack::<W> (ffor.rs:24-36).
+#pragma once
+#include "fl_kernels.hpp"
+
+namespace fl {
+
+struct ReduceArgs {
+    const u32x4* in;
+    void* out0;            // sums (uint64 per block) or mins (T per block)
+    void* out1;            // maxs (T per block) or unused
+    uint64_t n_blocks;
+    uint64_t tiles_per_xcd;
+};
+
+__device__ __forceinline__ bool tile_of_workgroup(const ReduceArgs& a, uint64_t& tile)
+{
+    const uint64_t n_tiles = (a.n_blocks + BLOCKS_PER_WG - 1) / BLOCKS_PER_WG;
+    tile = (uint64_t)(blockIdx.x & 7u) * a.tiles_per_xcd + (blockIdx.x >> 3);
+    return tile < n_tiles;
+}
+
+// sum of the elements of one cell, as u64
+template <typename T> __device__ __forceinline__ uint64_t cell_hsum(const Cell<T>& c)
+{
+    if constexpr (sizeof(T) == 8) return c.x[0] + c.x[1];
+    else if constexpr (sizeof(T) == 4) return (uint64_t)c.x[0] + c.x[1] + c.x[2] + c.x[3];
+    else if constexpr (sizeof(T) == 2) {
+        uint32_t s = 0;
+        for (int i = 0; i < 4; ++i) s += (c.x[i] & 0xffffu) + (c.x[i] >> 16);
+        return s;
+    } else {
+        uint32_t s = 0;
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t p = (c.x[i] & 0x00ff00ffu) + ((c.x[i] >> 8) & 0x00ff00ffu);
+            s += (p & 0xffffu) + (p >> 16);
+        }
+        return s;
+    }
+}
+
+// reduce over the 8 threads (cell columns) of a block
+__device__ __forceinline__ uint64_t group8_sum(uint64_t v)
+{
+    for (int m = 1; m < 8; m <<= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)v, m, 8), hi = __shfl_xor((uint32_t)(v >> 32), m, 8);
+        v += ((uint64_t)hi << 32) | lo;
+    }
+    return v;
+}
+template <typename T> __device__ __forceinline__ T group8_minmax(T v, bool want_max)
+{
+    for (int m = 1; m < 8; m <<= 1) {
+        T o;
+        if constexpr (sizeof(T) == 8) {
+            const uint32_t lo = __shfl_xor((uint32_t)v, m, 8), hi = __shfl_xor((uint32_t)(v >> 32), m, 8);
+            o = ((uint64_t)hi << 32) | lo;
+        } else {
+            o = (T)__shfl_xor((uint32_t)v, m, 8);
+        }
+        v = want_max ? (o > v ? o : v) : (o < v ? o : v);
+    }
+    return v;
+}
+
+template <typename T, int W>
+__global__ __launch_bounds__(WG) void k_unpack_block_sums(ReduceArgs a)
+{
+    uint64_t tile;
+    if (!tile_of_workgroup(a, tile)) return;
+    const unsigned tid = threadIdx.x;
+    const uint64_t blk = tile * BLOCKS_PER_WG + (tid >> 3);
+    const unsigned c = tid & 7u;
+    if (blk >= a.n_blocks) return;     // whole 8-thread groups leave together
+    Cell<T> in[W ? W : 1];
+    const u32x4* pk = a.in + blk * (uint64_t)(8 * W) + c;
+    static_for<W>([&](auto Wd) { in[decltype(Wd)::value] = load_cell<T, true>(pk + 8 * decltype(Wd)::value); });
+    uint64_t acc = 0;
+    unpack_rows<T, W>(in, [&](auto, const Cell<T>& v) { acc += cell_hsum<T>(v); });
+    acc = group8_sum(acc);
+    if (c == 0) static_cast<uint64_t*>(a.out0)[blk] = acc;
+}
+
+template <typename T>
+__global__ __launch_bounds__(WG) void k_block_min_max(ReduceArgs a)
+{
+    constexpr int TB = Elem<T>::BITS;
+    constexpr int N = Elem<T>::PER_CELL;
+    uint64_t tile;
+    if (!tile_of_workgroup(a, tile)) return;
+    const unsigned tid = threadIdx.x;
+    const uint64_t blk = tile * BLOCKS_PER_WG + (tid >> 3);
+    const unsigned c = tid & 7u;
+    if (blk >= a.n_blocks) return;
+    const u32x4* un = a.in + blk * (uint64_t)Elem<T>::CELLS_PER_BLOCK + c;
+    T mn = (T) ~(T)0, mx = 0;
+    static_for<TB>([&](auto R) {
+        // min/max do not care about the order of values, so rows are read in storage order
+        const Cell<T> v = load_cell<T, true>(un + 8 * decltype(R)::value);
+        static_for<N>([&](auto E) {
+            const T x = (T)cell_get<T>(v, decltype(E)::value);
+            mn = x < mn ? x : mn;
+            mx = x > mx ? x : mx;
+        });
+    });
+    mn = group8_minmax<T>(mn, false);
+    mx = group8_minmax<T>(mx, true);
+    if (c == 0) {
+        static_cast<T*>(a.out0)[blk] = mn;
+        static_cast<T*>(a.out1)[blk] = mx;
+    }
+}
+
+typedef hipError_t (*reduce_launch_t)(const ReduceArgs&, hipStream_t);
+
+inline unsigned plan_grid(ReduceArgs& a)
+{
+    const uint64_t n_tiles = (a.n_blocks + BLOCKS_PER_WG - 1) / BLOCKS_PER_WG;
+    a.tiles_per_xcd = (n_tiles + 7) / 8;
+    return (unsigned)(a.tiles_per_xcd * 8);
+}
+template <typename T, int W> hipError_t launch_unpack_block_sums(const ReduceArgs& a0, hipStream_t s)
+{
+    if (a0.n_blocks == 0) return hipSuccess;
+    ReduceArgs a = a0;
+    const unsigned grid = plan_grid(a);
+    hipLaunchKernelGGL((k_unpack_block_sums<T, W>), dim3(grid), dim3(WG), 0, s, a);
+    return hipGetLastError();
+}
+template <typename T> hipError_t launch_block_min_max(const ReduceArgs& a0, hipStream_t s)
+{
+    if (a0.n_blocks == 0) return hipSuccess;
+    ReduceArgs a = a0;
+    const unsigned grid = plan_grid(a);
+    hipLaunchKernelGGL((k_block_min_max<T>), dim3(grid), dim3(WG), 0, s, a);
+    return hipGetLastError();
+}
+
+template <typename T> struct ReduceTable { reduce_launch_t fn[Elem<T>::BITS + 1]; };
+template <typename T, int... Ws>
+constexpr ReduceTable<T> make_sum_table(std::integer_sequence<int, Ws...>)
+{
+    return ReduceTable<T>{{&launch_unpack_block_sums<T, Ws>...}};
+}
+template <typename T> const ReduceTable<T>& sum_table_impl();
+template <typename T> reduce_launch_t min_max_launcher();
+
+}  // namespace fl

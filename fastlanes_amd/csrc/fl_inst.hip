@@ -4,10 +4,12 @@
 //   0 unpack (store)   1 unfor_pack   2 undelta_pack   3 pack   4 for_pack
 //   5 delta / undelta / transpose / untranspose / unpack_single
 //   6 unpack over a mixed-width plan   7 pack over a mixed-width plan
+//   10 fused consumers: unpack_block_sums, block_min_max
 //   8 undelta_pack+untranspose (fused decode to original order)   9 transpose+delta+pack (fused encode)
 #include "fl_kernels.hpp"
 #include "fl_misc.hpp"
 #include "fl_mixed.hpp"
+#include "fl_consume.hpp"
 
 namespace fl {
 using T = FL_T;
@@ -53,7 +55,11 @@ template <> const WidthTable<T>& unpack_table_impl<T, BODY_UNDELTA_UNTRANSPOSE>(
 #elif FL_FAMILY == 9
 static constexpr WidthTable<T> t_tr_delta_pack = make_pack_table<T, PACK_TRANSPOSE_DELTA>(Ws{});
 template <> const WidthTable<T>& pack_table_impl<T, PACK_TRANSPOSE_DELTA>() { return t_tr_delta_pack; }
+#elif FL_FAMILY == 10
+static constexpr ReduceTable<T> t_sums = make_sum_table<T>(Ws{});
+template <> const ReduceTable<T>& sum_table_impl<T>() { return t_sums; }
+template <> reduce_launch_t min_max_launcher<T>() { return &launch_block_min_max<T>; }
 #else
-#error "FL_FAMILY must be 0..9"
+#error "FL_FAMILY must be 0..10"
 #endif
 }  // namespace fl

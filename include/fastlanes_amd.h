@@ -132,6 +132,14 @@ const uint64_t *fl_mixed_plan_offsets(const fl_mixed_plan *plan);
                                           size_t n_blocks, void *stream);                       \
     int fl_##S##_transpose_delta_pack(unsigned width, const T *in, const T *bases, T *out,      \
                                       size_t n_blocks, void *stream);                           \
+    /* EXTENSIONS, reductions over what the reference functions produce:           \
+     *   unpack_block_sums: sums[b] = sum of the 1024 values unpack::<W> yields for block b           \
+     *                      (wrapping uint64) without materialising them: 128*W bytes in, 8 out.       \
+     *   block_min_max:     mins[b], maxs[b] over unpacked block b -- an encoder's inputs for FoR's    \
+     *                      reference and width before for_pack::<W> (ffor.rs:24-36). */              \
+    int fl_##S##_unpack_block_sums(unsigned width, const T *in, size_t n_blocks, uint64_t *sums,  \
+                                   void *stream);                                               \
+    int fl_##S##_block_min_max(const T *in, size_t n_blocks, T *mins, T *maxs, void *stream);    \
     /* Transpose::transpose (transpose.rs:5,11-15) */                                           \
     int fl_##S##_transpose(const T *in, T *out, size_t n_blocks, void *stream);                 \
     /* Transpose::untranspose (transpose.rs:6,17-22) */                                         \

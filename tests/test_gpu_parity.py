@@ -365,3 +365,30 @@ def test_fused_transpose_extensions_vs_oracle_composition(fl, oracle, ty):
     bases = values(ty, n * lanes(ty), 6)
     enc = fl.Delta.transpose_delta_pack(T, to_dev(v), to_dev(bases))
     assert np.array_equal(to_np(fl.Delta.undelta_pack_untranspose(T, enc, to_dev(bases)), ty), v)
+
+
+@pytest.mark.parametrize("ty", TYS)
+def test_fused_consumers_vs_oracle(fl, oracle, ty):
+    """unpack_block_sums / block_min_max (extensions): reductions of the oracle's outputs."""
+    T = tbits(ty)
+    n = 37
+    for w in range(T + 1):
+        pk = values(ty, n * packed_len(ty, w), 13000 + 64 * T + w)
+        got = fl.BitPacking.unpack_block_sums(w, to_dev(pk), n_blocks=n).cpu().numpy().view(np.uint64)
+        un = oracle.batch("unpack", ty, w, pk, n_blocks=n).reshape(n, 1024)
+        with np.errstate(over="ignore"):
+            want = un.astype(np.uint64).sum(axis=1, dtype=np.uint64)
+        assert np.array_equal(got, want), (ty, w)
+    v = values(ty, n * 1024, 77 + T)
+    v[5 * 1024:6 * 1024] = v[5 * 1024]          # a constant block
+    v[7 * 1024 + 1023] = np.iinfo(TYPES[ty][0]).max
+    v[9 * 1024] = 0
+    mins, maxs = fl.BitPacking.block_min_max(to_dev(v))
+    assert np.array_equal(to_np(mins, ty), v.reshape(n, 1024).min(axis=1))
+    assert np.array_equal(to_np(maxs, ty), v.reshape(n, 1024).max(axis=1))
+    # the encoder loop these feed: FoR reference = min, width = bits(max - min)
+    ref = to_np(mins, ty)
+    span = (to_np(maxs, ty) - ref).astype(np.uint64)
+    w = int(max(int(x).bit_length() for x in span))
+    pk = fl.FoR.for_pack(w, to_dev(v), mins)
+    assert np.array_equal(to_np(fl.FoR.unfor_pack(w, pk, mins), ty), v)

@@ -30,6 +30,10 @@ def bytes_per_block(op, ty, w):
         return 128 * w + 128 * T
     if op in ("undelta_pack", "undelta_pack_untranspose", "transpose_delta_pack"):
         return 128 * w + 128 + 128 * T
+    if op == "unpack_block_sums":
+        return 128 * w + 8
+    if op == "block_min_max":
+        return 128 * T + 2 * ESZ[ty]
     if op in ("delta", "undelta"):
         return 2 * 128 * T + 128
     return 2 * 128 * T  # transpose / untranspose
@@ -58,6 +62,12 @@ def run(op, ty, w, gb, reps):
     elif op == "undelta_pack":
         src, dst = pk(1), torch.empty(n * 1024, dtype=TDT[ty], device=dev)
         f = lambda: fl.Delta.undelta_pack(w, src, bases, output=dst)
+    elif op == "unpack_block_sums":
+        src = pk(1)
+        f = lambda: fl.BitPacking.unpack_block_sums(w, src)
+    elif op == "block_min_max":
+        src = un(1)
+        f = lambda: fl.BitPacking.block_min_max(src)
     elif op == "undelta_pack_untranspose":
         src, dst = pk(1), torch.empty(n * 1024, dtype=TDT[ty], device=dev)
         f = lambda: fl.Delta.undelta_pack_untranspose(w, src, bases, output=dst)
@@ -102,6 +112,10 @@ def main():
                  ("undelta_pack", "u16", 9), ("undelta_pack", "u64", 20), ("undelta_pack", "u8", 4)]
         for ty in ("u8", "u16", "u32", "u64"):
             cases += [(op, ty, 0) for op in ("delta", "undelta", "transpose", "untranspose")]
+    elif args.cases == "consume":
+        cases = [("unpack_block_sums", "u32", 7), ("unpack_block_sums", "u32", 20), ("unpack_block_sums", "u64", 17),
+                 ("unpack_block_sums", "u16", 3), ("unpack_block_sums", "u8", 3),
+                 ("block_min_max", "u32", 0), ("block_min_max", "u64", 0), ("block_min_max", "u16", 0), ("block_min_max", "u8", 0)]
     elif args.cases == "fused":
         cases = [("undelta_pack", "u32", 12), ("undelta_pack_untranspose", "u32", 12), ("transpose_delta_pack", "u32", 12),
                  ("undelta_pack_untranspose", "u64", 20), ("transpose_delta_pack", "u64", 20),
