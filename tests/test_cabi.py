@@ -109,3 +109,11 @@ def build_cpp_test():
                                "-L", os.path.join(ROOT, "fastlanes_amd"), "-lfastlanes_amd",
                                "-Wl,-rpath,$ORIGIN/../../fastlanes_amd", "-o", exe])
     return exe
+
+
+def test_functor_api_example_builds():
+    """examples/fused_dict_decode.hip (a user-written fused kernel on fl_device.hpp, the
+    counterpart of the reference's exported unpack! macro) cross-compiles for gfx950."""
+    import __graft_entry__ as ge
+    so = ge.build_examples()
+    assert hasattr(ctypes.CDLL(so), "example_dict_unpack_u32_w8")

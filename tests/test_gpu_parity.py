@@ -392,3 +392,24 @@ def test_fused_consumers_vs_oracle(fl, oracle, ty):
     w = int(max(int(x).bit_length() for x in span))
     pk = fl.FoR.for_pack(w, to_dev(v), mins)
     assert np.array_equal(to_np(fl.FoR.unfor_pack(w, pk, mins), ty), v)
+
+
+def test_functor_api_user_kernel_dict_decode(fl, oracle):
+    """A user-written fused kernel (examples/fused_dict_decode.hip) built on the device functor
+    API: out[idx] = dict[code] spliced into the unpack loop, vs dict[oracle.unpack(..)]."""
+    import ctypes
+    import torch
+    import __graft_entry__ as ge
+    lib = ctypes.CDLL(ge.build_examples())
+    lib.example_dict_unpack_u32_w8.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p]
+    n = 70
+    pk = values("u32", n * 256, 21)
+    dic = values("u32", 256, 22)
+    dpk, ddic = to_dev(pk), to_dev(dic)
+    out = torch.empty(n * 1024, dtype=torch.uint32, device="cuda:0")
+    rc = lib.example_dict_unpack_u32_w8(dpk.data_ptr(), ddic.data_ptr(), out.data_ptr(), n,
+                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    want = dic[oracle.batch("unpack", "u32", 8, pk)]
+    assert np.array_equal(to_np(out, "u32"), want)
