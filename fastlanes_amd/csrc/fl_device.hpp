@@ -185,8 +185,9 @@ __device__ __forceinline__ void store_cell(u32x4* p, const Cell<T>& c)
 // The thread that owns lanes n*c .. n*c+n-1 for all T rows therefore holds, per lane, one
 // contiguous RUN of T elements (T*sizeof(T) bytes: 8 B for u8 .. 512 B for u64) of the
 // original order, and the permutation is a pure in-register regroup: no LDS, no cross-lane
-// traffic.  load_lane_runs gathers the runs (16-byte loads) into row cells; store_lane_runs
-// scatters row cells back as runs (16-byte write-back stores, so L2 merges a run's pieces).
+// traffic.  load_lane_runs gathers the runs (16-byte loads) into row cells;
+// store_lane_runs_lines writes row cells back as runs (after an 8-thread piece exchange
+// through LDS so that every store covers a full line).
 // ---------------------------------------------------------------------------
 __host__ __device__ constexpr unsigned lane_base(unsigned l) { return (l % 16) * 64 + fl_order(l / 16) * 8; }
 
@@ -243,34 +244,94 @@ __device__ __forceinline__ void load_lane_runs(const char* blk, unsigned c, Cell
     });
 }
 
-// original-order block at `blk` <- rows[r] (column c of a TRANSPOSED block)
-template <typename T>
-__device__ __forceinline__ void store_lane_runs(char* blk, unsigned c, const Cell<T>* rows)
+// store_lane_runs_lines: original-order block <- rows[r] (column c of a TRANSPOSED block),
+// the inverse of load_lane_runs, with every global store a FULL 128-byte line.  The 8 threads of a block first exchange 16-byte pieces through a private
+// 1152-byte LDS region (8 line slots, 144-byte stride => conflict-free ds_write_b128 /
+// ds_read_b128), one "phase" of 8 output lines at a time (sizeof(T) phases per block), then
+// thread c' stores piece c' of each line through `st` (a TileStore over the original-order
+// block).  Only lanes of the same wavefront touch a region: LDS operations of one wave execute
+// in order, so a compiler-level fence is all the synchronisation needed (no s_barrier).
+template <typename T> struct RunExchange {
+    static constexpr int E = sizeof(T);
+    static constexpr int PHASES = E;          // 8E lines per block, 8 per phase
+    static constexpr int LS = 144;            // padded line stride in LDS
+    static constexpr int BLOCK_BYTES = 8 * LS;
+    static constexpr int WAVE_BYTES = 8 * BLOCK_BYTES;
+};
+
+__device__ __forceinline__ void wave_lds_fence()
 {
-    using L = LaneRun<T>;
-    using piece_t = typename L::piece_t;
-    static_for<L::N>([&](auto EE) {
-        constexpr int e = decltype(EE)::value;
-        char* run = blk + (uint64_t)lane_base(L::N * c + e) * L::E;
-        static_for<L::PIECES>([&](auto K) {
-            constexpr int k = decltype(K)::value;
-            piece_t p;
-            static_for<L::PIECE / 4>([&](auto D) {
-                constexpr int d = decltype(D)::value;
-                uint32_t w = 0;
-                if constexpr (L::E == 8) {
-                    const uint64_t v = cell_get<T>(rows[k * L::PER_PIECE + d / 2], e);
-                    w = (uint32_t)(v >> (32 * (d % 2)));
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <typename T, typename Store>
+__device__ __forceinline__ void store_lane_runs_lines(char* lds_blk, unsigned c, const Cell<T>* rows, const Store& st)
+{
+    using X = RunExchange<T>;
+    constexpr int E = X::E;
+    static_for<X::PHASES>([&](auto P) {
+        constexpr int p = decltype(P)::value;
+        if constexpr (E >= 4) {
+            // u32: phase = lane e, the lane's 128-byte run is one line.  u64: phase = (lane e, quarter q)
+            constexpr int e = (E == 4) ? p : p / 4;
+            constexpr int q = (E == 8) ? p % 4 : 0;
+            constexpr int RPP = 16 / E;                       // rows per 16-byte piece
+            static_for<8>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                constexpr int r0 = q * (128 / E) + k * RPP;
+                u32x4 piece;
+                if constexpr (E == 4) {
+                    static_for<4>([&](auto D) { piece[decltype(D)::value] = (uint32_t)cell_get<T>(rows[r0 + decltype(D)::value], e); });
                 } else {
-                    static_for<4 / (L::E < 4 ? L::E : 4)>([&](auto J) {
-                        constexpr int j = decltype(J)::value;
-                        w |= (uint32_t)cell_get<T>(rows[k * L::PER_PIECE + d * (4 / L::E) + j], e) << (8 * L::E * j);
-                    });
+                    const uint64_t a = cell_get<T>(rows[r0], e), b = cell_get<T>(rows[r0 + 1], e);
+                    piece[0] = (uint32_t)a; piece[1] = (uint32_t)(a >> 32); piece[2] = (uint32_t)b; piece[3] = (uint32_t)(b >> 32);
                 }
-                p[d] = w;
+                *reinterpret_cast<u32x4*>(lds_blk + c * X::LS + 16 * k) = piece;
             });
-            *reinterpret_cast<piece_t*>(run + L::PIECE * k) = p;
+        } else if constexpr (E == 2) {
+            // 4 lanes per phase, 32-byte runs: line (l%16), quarter offset FL_ORDER[l/16]*16 bytes
+            static_for<4>([&](auto EP) {
+                constexpr int ep = decltype(EP)::value;
+                constexpr int e = 4 * p + ep;
+                static_for<2>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    u32x4 piece;
+                    static_for<4>([&](auto D) {
+                        constexpr int d = decltype(D)::value;
+                        piece[d] = (uint32_t)cell_get<T>(rows[8 * j + 2 * d], e) | ((uint32_t)cell_get<T>(rows[8 * j + 2 * d + 1], e) << 16);
+                    });
+                    *reinterpret_cast<u32x4*>(lds_blk + (4 * (c & 1u) + ep) * X::LS + fl_order(c >> 1) * 16 + 16 * j) = piece;
+                });
+            });
+        } else {
+            // u8: one phase; lane e's 8-byte run sits in line e/2 at (e%2)*64 + FL_ORDER[c]*8
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            static_for<16>([&](auto EE) {
+                constexpr int e = decltype(EE)::value;
+                u32x2 piece;
+                static_for<2>([&](auto D) {
+                    constexpr int d = decltype(D)::value;
+                    uint32_t w = 0;
+                    static_for<4>([&](auto J) { w |= (uint32_t)cell_get<T>(rows[4 * d + decltype(J)::value], e) << (8 * decltype(J)::value); });
+                    piece[d] = w;
+                });
+                *reinterpret_cast<u32x2*>(lds_blk + (e / 2) * X::LS + (e % 2) * 64 + fl_order(c) * 8) = piece;
+            });
+        }
+        wave_lds_fence();
+        static_for<8>([&](auto S) {
+            constexpr int s = decltype(S)::value;
+            const u32x4 piece = *reinterpret_cast<const u32x4*>(lds_blk + s * X::LS + 16 * c);
+            // byte address of this slot's line inside the original-order block
+            constexpr unsigned line =
+                E == 8 ? (unsigned)((2 * s + p / 4) * 512 + 128 * (p % 4)) :
+                E == 4 ? (unsigned)(((4 * s + p) % 16) * 256 + ((4 * s + p) / 16) * 128) :
+                E == 2 ? (unsigned)((8 * (s / 4) + 4 * p + s % 4) * 128) :
+                         (unsigned)(s * 128);
+            st.store(line / 16, __builtin_bit_cast(Cell<T>, piece));   // st already adds this thread's 16*c
         });
+        wave_lds_fence();
     });
 }
 

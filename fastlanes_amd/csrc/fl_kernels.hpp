@@ -128,7 +128,8 @@ void k_unpack(StreamArgs a)
             prev = v.add(prev);
             rows[decltype(R)::value] = prev;
         });
-        store_lane_runs<T>(reinterpret_cast<char*>(a.out) + blk * (uint64_t)(1024 * sizeof(T)), c, rows);
+        __shared__ __attribute__((aligned(16))) char lds[(WG / 64) * RunExchange<T>::WAVE_BYTES];
+        store_lane_runs_lines<T>(lds + (tid >> 3) * RunExchange<T>::BLOCK_BYTES, c, rows, st);
     }
 }
 

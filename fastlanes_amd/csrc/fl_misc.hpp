@@ -43,7 +43,9 @@ void k_transpose(StreamArgs a)
         static_for<TB>([&](auto R) {
             rows[decltype(R)::value] = load_cell<T, true>(src + Elem<T>::row_cell(decltype(R)::value));
         });
-        store_lane_runs<T>(out_blk, c, rows);
+        const TileStore<Elem<T>::CELLS_PER_BLOCK * 16> st(a.out, tile, a.n_blocks, tid);
+        __shared__ __attribute__((aligned(16))) char lds[(WG / 64) * RunExchange<T>::WAVE_BYTES];
+        store_lane_runs_lines<T>(lds + (tid >> 3) * RunExchange<T>::BLOCK_BYTES, c, rows, st);
     }
 }
 
