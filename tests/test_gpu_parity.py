@@ -413,3 +413,75 @@ def test_functor_api_user_kernel_dict_decode(fl, oracle):
     torch.cuda.synchronize()
     want = dic[oracle.batch("unpack", "u32", 8, pk)]
     assert np.array_equal(to_np(out, "u32"), want)
+
+
+# ---------------------------------------------------------------------------
+# several tiles per XCD slot (n_blocks > 256) for every kernel family, and launch plumbing
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("ty", TYS)
+def test_many_tiles_all_families(fl, oracle, ty):
+    T = tbits(ty)
+    n = 1000 + T  # 32+ tiles -> tiles_per_xcd = 4..5, ragged last tile
+    v = values(ty, n * 1024, 31 + T)
+    refs = values(ty, n, 32 + T)
+    bases = values(ty, n * lanes(ty), 33 + T)
+    dv, drefs, dbases = to_dev(v), to_dev(refs), to_dev(bases)
+    for w in sorted({1, T // 2 + 1, T - 1}):
+        pk = values(ty, n * packed_len(ty, w), 34 + T + w)
+        dpk = to_dev(pk)
+        assert np.array_equal(to_np(fl.BitPacking.pack(w, dv), ty), oracle.batch("pack", ty, w, v))
+        assert np.array_equal(to_np(fl.BitPacking.unpack(w, dpk), ty), oracle.batch("unpack", ty, w, pk))
+        assert np.array_equal(to_np(fl.FoR.for_pack(w, dv, drefs), ty), oracle.batch("for_pack", ty, w, v, aux=refs))
+        assert np.array_equal(to_np(fl.FoR.unfor_pack(w, dpk, drefs), ty), oracle.batch("unfor_pack", ty, w, pk, aux=refs))
+        ud = oracle.batch("undelta_pack", ty, w, pk, aux=bases)
+        assert np.array_equal(to_np(fl.Delta.undelta_pack(w, dpk, dbases), ty), ud)
+        assert np.array_equal(to_np(fl.Delta.undelta_pack_untranspose(w, dpk, dbases), ty),
+                              oracle.batch("untranspose", ty, None, ud))
+        with np.errstate(over="ignore"):
+            sums = oracle.batch("unpack", ty, w, pk).reshape(n, 1024).astype(np.uint64).sum(axis=1, dtype=np.uint64)
+        assert np.array_equal(fl.BitPacking.unpack_block_sums(w, dpk).cpu().numpy().view(np.uint64), sums)
+    assert np.array_equal(to_np(fl.Delta.delta(dv, dbases), ty), oracle.batch("delta", ty, None, v, aux=bases))
+    assert np.array_equal(to_np(fl.Delta.undelta(dv, dbases), ty), oracle.batch("undelta", ty, None, v, aux=bases))
+    assert np.array_equal(to_np(fl.Transpose.transpose(dv), ty), oracle.batch("transpose", ty, None, v))
+    assert np.array_equal(to_np(fl.Transpose.untranspose(dv), ty), oracle.batch("untranspose", ty, None, v))
+    mins, maxs = fl.BitPacking.block_min_max(dv)
+    assert np.array_equal(to_np(mins, ty), v.reshape(n, 1024).min(axis=1))
+    assert np.array_equal(to_np(maxs, ty), v.reshape(n, 1024).max(axis=1))
+
+
+def test_streams_and_graph_capture(fl, oracle):
+    """Device-tier calls are asynchronous on the caller's stream, allocate nothing and never
+    synchronise, so they run on side streams and capture into a HIP graph (replayed twice)."""
+    import torch
+    n = 300
+    pk = values("u32", n * 224, 55)
+    dpk = to_dev(pk)
+    want = oracle.batch("unpack", "u32", 7, pk)
+    out = torch.zeros(n * 1024, dtype=torch.uint32, device="cuda:0")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fl.BitPacking.unpack(7, dpk, output=out)
+    side.synchronize()
+    assert np.array_equal(to_np(out, "u32"), want)
+    widths = (1 + np.arange(n) % 32).astype(np.uint8)
+    plan = fl.MixedWidthPlan("u32", widths)
+    col = values("u32", plan.packed_bytes // 4, 56)
+    dcol = to_dev(col)
+    mixed_out = torch.zeros(n * 1024, dtype=torch.uint32, device="cuda:0")
+    out.zero_()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fl.BitPacking.unpack(7, dpk, output=out)
+        plan.unpack(dcol, output=mixed_out)          # 32 launches, one per width
+    for _ in range(2):
+        out.zero_(); mixed_out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(to_np(out, "u32"), want)
+        pos, wantm = 0, []
+        for w in widths:
+            wantm.append(oracle.unpack("u32", int(w), col[pos:pos + 32 * int(w)]))
+            pos += 32 * int(w)
+        assert np.array_equal(to_np(mixed_out, "u32"), np.concatenate(wantm))
+    plan.close()
