@@ -122,9 +122,12 @@ def main():
     plan = None
     if op == "unpack_mixed":
         import numpy as np
+        first = rank * n
         if args.blocks == 10_000_000:
-            n = 9_765_625 // world   # 10 B integers in total, sharded by block range
-        widths = (1 + (np.arange(n, dtype=np.int64) + rank * n) % 32).astype(np.uint8)
+            # BASELINE.json configs[4]: 10 B integers = 9 765 625 blocks in total, sharded by block range
+            from fastlanes_amd.sharding import block_range
+            first, n = block_range(9_765_625, world, rank)
+        widths = (1 + (np.arange(n, dtype=np.int64) + first) % 32).astype(np.uint8)
         plan = fl.MixedWidthPlan(ty, widths)
         src = rand_u8(plan.packed_bytes, 1234 + rank, dev).view(tdt)
         dst = torch.empty(n * 1024, dtype=tdt, device=dev)
@@ -200,6 +203,8 @@ def main():
 
     if rank == 0:
         ints = n * 1024 * world
+        if op == "unpack_mixed" and args.blocks == 10_000_000:
+            ints = 9_765_625 * 1024    # strong scaling: the whole column, however it is sharded
         value = ints * args.steps / elapsed / 1e9
         avg_kernel_s = sum(kern_ms) / len(kern_ms) / 1e3
         achieved = n * bytes_per_block / avg_kernel_s / 1e9

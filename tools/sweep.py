@@ -97,6 +97,18 @@ def run(op, ty, w, gb, reps):
             "frac": round(gbps / 8000, 4), "Gints": round(n * 1024 / med / 1e6, 1)}
 
 
+def host_tier(reps=3):
+    """PCIe-inclusive rate of the host-pointer tier (numpy in -> numpy out, staged through HBM)."""
+    import time
+    import numpy as np
+    n = 65536
+    pk = np.random.default_rng(1).integers(0, 2**32, size=n * 224, dtype=np.uint32)
+    fl.BitPacking.unpack(7, pk)
+    best = min((lambda t0: (fl.BitPacking.unpack(7, pk), time.perf_counter() - t0)[1])(time.perf_counter()) for _ in range(reps))
+    print(f"host tier unpack u32 W=7 n={n}: {best * 1e3:.2f} ms  {n * 1024 / best / 1e9:.2f} Gint/s "
+          f"({n * 4992 / best / 1e9:.2f} GB/s over PCIe incl. hipMalloc/hipFree and pageable copies)", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gb", type=float, default=24.0)
@@ -130,6 +142,9 @@ def main():
             T = ESZ[ty] * 8
             for w in sorted({1, 2, 3, T // 4, T // 2, T - 1, T}):
                 cases += [("unpack", ty, w), ("pack", ty, w)]
+    if args.cases == "host":
+        host_tier()
+        return
     out = []
     for op, ty, w in cases:
         r = run(op, ty, w, args.gb, args.reps)
