@@ -65,12 +65,16 @@ def cpu_baseline(args, ty, width, op):
     from datagen import values
     from oracle_lib import lanes, load_native_oracle, packed_len
     o, cflags = load_native_oracle()
-    n = 131072  # blocks: 134 M integers; u32 W=7: 117 MB in + 537 MB out (DRAM-resident)
+    n = 524288  # blocks: 537 M integers; u32 W=7: 470 MB in + 2.1 GB out (DRAM-resident)
     pl = packed_len(ty, width)
-    src = values(ty, n * (1024 if op == "pack" else pl), 7, bits=None)
-    aux = values(ty, n * lanes(ty), 8) if op == "undelta_pack" else None
-    out = np.zeros(n * (pl if op == "pack" else 1024), dtype=src.dtype)
     cores = os.cpu_count() or 1
+    npdt = values(ty, 1, 0).dtype
+    esz = npdt.itemsize
+    in_elems, out_elems = (1024, pl) if op == "pack" else (pl, 1024)
+    # random input / output pages first-touched by the thread that will stream them (NUMA placement)
+    src = o.parallel_fill(np.empty(n * in_elems, dtype=npdt), in_elems * esz, n, 7, cores)
+    out = o.parallel_fill(np.empty(n * out_elems, dtype=npdt), out_elems * esz, n, 9, cores)
+    aux = o.parallel_fill(np.empty(n * lanes(ty), dtype=npdt), 128, n, 8, cores) if op == "undelta_pack" else None
     res = {}
     for label, nt in (("single_thread", 1), ("all_cores", cores)):
         o.fast(op, ty, width, src, aux=aux, n_blocks=n, nthreads=nt, out=out)  # warm (page faults)

@@ -28,6 +28,43 @@ unsigned fl_oracle_transpose_index(unsigned idx)
     return lane * 64 + fl_oracle_FL_ORDER[order] * 8 + row;
 }
 
+typedef struct { uint64_t *p; size_t w0, w1; uint64_t seed; } fill_job_t;
+
+static void *fill_worker(void *arg)
+{
+    fill_job_t *j = (fill_job_t *)arg;
+    for (size_t i = j->w0; i < j->w1; ++i) {
+        uint64_t z = j->seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        j->p[i] = z ^ (z >> 31);
+    }
+    return NULL;
+}
+
+int fl_oracle_parallel_fill(void *base, size_t bytes_per_block, size_t n_blocks, uint64_t seed,
+                            unsigned nthreads)
+{
+    if (bytes_per_block % 8) return 1;
+    if (nthreads == 0) nthreads = 1;
+    if (nthreads > 1024) nthreads = 1024;
+    if (nthreads > n_blocks) nthreads = n_blocks ? (unsigned)n_blocks : 1;
+    fill_job_t jobs[1024];
+    pthread_t tids[1024];
+    const size_t wpb = bytes_per_block / 8;
+    for (unsigned t = 0; t < nthreads; ++t) {
+        jobs[t].p = (uint64_t *)base;
+        jobs[t].w0 = (n_blocks * t / nthreads) * wpb;
+        jobs[t].w1 = (n_blocks * (t + 1) / nthreads) * wpb;
+        jobs[t].seed = seed;
+    }
+    if (nthreads == 1) { fill_worker(&jobs[0]); return 0; }
+    for (unsigned t = 0; t < nthreads; ++t)
+        if (pthread_create(&tids[t], NULL, fill_worker, &jobs[t]) != 0) return 3;
+    for (unsigned t = 0; t < nthreads; ++t) pthread_join(tids[t], NULL);
+    return 0;
+}
+
 /* What the spliced unpack! body does with each (idx, elem). */
 enum { FL_BODY_STORE = 0, FL_BODY_ADD_REF = 1, FL_BODY_UNDELTA = 2 };
 

@@ -46,6 +46,12 @@ unsigned fl_oracle_index(unsigned row, unsigned lane);
 /* transpose.rs:29-36 */
 unsigned fl_oracle_transpose_index(unsigned idx);
 
+/* CPU-baseline helper: fill n_blocks * bytes_per_block bytes at base with splitmix64 output,
+ * using the SAME contiguous block-range-per-thread partition as the fl_oracle_fast_* functions,
+ * so that every page is first touched (NUMA-placed) by the thread that will stream it. */
+int fl_oracle_parallel_fill(void *base, size_t bytes_per_block, size_t n_blocks, uint64_t seed,
+                            unsigned nthreads);
+
 #define FL_ORACLE_DECL(T, S)                                                              \
     int fl_oracle_pack_##S(unsigned width, const T *in, T *out);                          \
     int fl_oracle_unpack_##S(unsigned width, const T *in, T *out);                        \

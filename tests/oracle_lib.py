@@ -188,6 +188,14 @@ class Oracle:
             return out
         raise KeyError(op)
 
+    def parallel_fill(self, arr, bytes_per_block, n_blocks, seed, nthreads):
+        """First-touch `arr` with random bits using the fast family's thread partition."""
+        rc = self.lib.fl_oracle_parallel_fill(self._p(arr), ctypes.c_size_t(bytes_per_block),
+                                              ctypes.c_size_t(n_blocks), ctypes.c_uint64(seed), ctypes.c_uint(nthreads))
+        if rc:
+            raise ValueError(f"oracle fill rc={rc}")
+        return arr
+
     # ---- fast family (CPU baseline only) -------------------------------------
     def fast(self, op, ty, w, data, aux=None, n_blocks=None, nthreads=1, out=None):
         dt = TYPES[ty][0]
