@@ -185,9 +185,9 @@ __device__ __forceinline__ void store_cell(u32x4* p, const Cell<T>& c)
 // The thread that owns lanes n*c .. n*c+n-1 for all T rows therefore holds, per lane, one
 // contiguous RUN of T elements (T*sizeof(T) bytes: 8 B for u8 .. 512 B for u64) of the
 // original order, and the permutation is a pure in-register regroup: no LDS, no cross-lane
-// traffic.  load_lane_runs gathers the runs (16-byte loads) into row cells;
-// store_lane_runs_lines writes row cells back as runs (after an 8-thread piece exchange
-// through LDS so that every store covers a full line).
+// traffic.  So that the run-side global accesses are full 128-byte lines too, the 8 threads
+// of a block exchange 16-byte pieces through a wave-private LDS region
+// (store_lane_runs_lines / load_lane_runs_lines below).
 // ---------------------------------------------------------------------------
 __host__ __device__ constexpr unsigned lane_base(unsigned l) { return (l % 16) * 64 + fl_order(l / 16) * 8; }
 
@@ -216,33 +216,6 @@ template <typename T> struct LaneRun {
     static constexpr int PER_PIECE = PIECE / E;          // elements per piece
     typedef uint32_t piece_t __attribute__((ext_vector_type(PIECE / 4)));
 };
-
-// rows[r] (column c of a TRANSPOSED block) <- original-order block at `blk`
-template <typename T>
-__device__ __forceinline__ void load_lane_runs(const char* blk, unsigned c, Cell<T>* rows)
-{
-    using L = LaneRun<T>;
-    using piece_t = typename L::piece_t;
-    static_for<L::TB>([&](auto R) { rows[decltype(R)::value] = Cell<T>::zero(); });
-    static_for<L::N>([&](auto EE) {
-        constexpr int e = decltype(EE)::value;
-        const char* run = blk + (uint64_t)lane_base(L::N * c + e) * L::E;
-        piece_t p[L::PIECES];
-        static_for<L::PIECES>([&](auto K) {
-            p[decltype(K)::value] = *reinterpret_cast<const piece_t*>(run + L::PIECE * decltype(K)::value);
-        });
-        static_for<L::TB>([&](auto R) {
-            constexpr int r = decltype(R)::value;
-            constexpr int k = r / L::PER_PIECE, j = r % L::PER_PIECE;
-            uint64_t v;
-            if constexpr (L::E == 8) v = (uint64_t)p[k][2 * j] | ((uint64_t)p[k][2 * j + 1] << 32);
-            else if constexpr (L::E == 4) v = p[k][j];
-            else if constexpr (L::E == 2) v = (p[k][j / 2] >> (16 * (j % 2))) & 0xffffu;
-            else v = (p[k][j / 4] >> (8 * (j % 4))) & 0xffu;
-            cell_or<T>(rows[r], e, v);
-        });
-    });
-}
 
 // store_lane_runs_lines: original-order block <- rows[r] (column c of a TRANSPOSED block),
 // the inverse of load_lane_runs, with every global store a FULL 128-byte line.  The 8 threads of a block first exchange 16-byte pieces through a private
@@ -331,6 +304,81 @@ __device__ __forceinline__ void store_lane_runs_lines(char* lds_blk, unsigned c,
                          (unsigned)(s * 128);
             st.store(line / 16, __builtin_bit_cast(Cell<T>, piece));   // st already adds this thread's 16*c
         });
+        wave_lds_fence();
+    });
+}
+
+// load_lane_runs_lines: the mirror image -- rows[r] (column c of the TRANSPOSED block) <- the
+// original-order block, reading it with FULL-line loads (thread c' fetches piece c' of each
+// line; all 8*sizeof(T) loads are issued up front) and handing every thread its own lanes'
+// runs through the same wave-private LDS exchange.
+template <typename T>
+__device__ __forceinline__ void load_lane_runs_lines(char* lds_blk, unsigned c, const u32x4* blk_cells, Cell<T>* rows)
+{
+    using X = RunExchange<T>;
+    constexpr int E = X::E;
+    constexpr int TB = Elem<T>::BITS;
+    u32x4 lines[X::PHASES][8];
+    static_for<X::PHASES>([&](auto P) {
+        constexpr int p = decltype(P)::value;
+        static_for<8>([&](auto S) {
+            constexpr int s = decltype(S)::value;
+            constexpr unsigned line =
+                E == 8 ? (unsigned)((2 * s + p / 4) * 512 + 128 * (p % 4)) :
+                E == 4 ? (unsigned)(((4 * s + p) % 16) * 256 + ((4 * s + p) / 16) * 128) :
+                E == 2 ? (unsigned)((8 * (s / 4) + 4 * p + s % 4) * 128) :
+                         (unsigned)(s * 128);
+            lines[p][s] = __builtin_nontemporal_load(blk_cells + line / 16 + c);
+        });
+    });
+    static_for<TB>([&](auto R) { rows[decltype(R)::value] = Cell<T>::zero(); });
+    static_for<X::PHASES>([&](auto P) {
+        constexpr int p = decltype(P)::value;
+        static_for<8>([&](auto S) {
+            *reinterpret_cast<u32x4*>(lds_blk + decltype(S)::value * X::LS + 16 * c) = lines[p][decltype(S)::value];
+        });
+        wave_lds_fence();
+        if constexpr (E >= 4) {
+            constexpr int e = (E == 4) ? p : p / 4;
+            constexpr int q = (E == 8) ? p % 4 : 0;
+            constexpr int RPP = 16 / E;
+            static_for<8>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                constexpr int r0 = q * (128 / E) + k * RPP;
+                const u32x4 piece = *reinterpret_cast<const u32x4*>(lds_blk + c * X::LS + 16 * k);
+                if constexpr (E == 4) {
+                    static_for<4>([&](auto D) { cell_or<T>(rows[r0 + decltype(D)::value], e, piece[decltype(D)::value]); });
+                } else {
+                    cell_or<T>(rows[r0], e, (uint64_t)piece[0] | ((uint64_t)piece[1] << 32));
+                    cell_or<T>(rows[r0 + 1], e, (uint64_t)piece[2] | ((uint64_t)piece[3] << 32));
+                }
+            });
+        } else if constexpr (E == 2) {
+            static_for<4>([&](auto EP) {
+                constexpr int ep = decltype(EP)::value;
+                constexpr int e = 4 * p + ep;
+                static_for<2>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    const u32x4 piece = *reinterpret_cast<const u32x4*>(
+                        lds_blk + (4 * (c & 1u) + ep) * X::LS + fl_order(c >> 1) * 16 + 16 * j);
+                    static_for<4>([&](auto D) {
+                        constexpr int d = decltype(D)::value;
+                        cell_or<T>(rows[8 * j + 2 * d], e, piece[d] & 0xffffu);
+                        cell_or<T>(rows[8 * j + 2 * d + 1], e, piece[d] >> 16);
+                    });
+                });
+            });
+        } else {
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            static_for<16>([&](auto EE) {
+                constexpr int e = decltype(EE)::value;
+                const u32x2 piece = *reinterpret_cast<const u32x2*>(lds_blk + (e / 2) * X::LS + (e % 2) * 64 + fl_order(c) * 8);
+                static_for<8>([&](auto R) {
+                    constexpr int r = decltype(R)::value;
+                    cell_or<T>(rows[r], e, (piece[r / 4] >> (8 * (r % 4))) & 0xffu);
+                });
+            });
+        }
         wave_lds_fence();
     });
 }

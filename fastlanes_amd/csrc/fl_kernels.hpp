@@ -155,7 +155,9 @@ void k_pack(StreamArgs a)
     // Issue all T row loads up front (they are independent), then combine.
     Cell<T> rows[TB];
     if constexpr (MODE == PACK_TRANSPOSE_DELTA) {
-        load_lane_runs<T>(reinterpret_cast<const char*>(a.in) + blk * (uint64_t)(1024 * sizeof(T)), c, rows);   // transpose.rs:12-14
+        __shared__ __attribute__((aligned(16))) char lds[(WG / 64) * RunExchange<T>::WAVE_BYTES];
+        load_lane_runs_lines<T>(lds + (tid >> 3) * RunExchange<T>::BLOCK_BYTES, c,
+                                a.in + blk * (uint64_t)Elem<T>::CELLS_PER_BLOCK, rows);                   // transpose.rs:12-14
         Cell<T> prev = load_cell<T, false>(static_cast<const u32x4*>(a.aux) + blk * 8 + c);
         static_for<TB>([&](auto R) {                                            // delta.rs:26-31
             const Cell<T> next = rows[decltype(R)::value];

@@ -34,7 +34,9 @@ void k_transpose(StreamArgs a)
     Cell<T> rows[TB];
     if constexpr (!INVERSE) {
         // original order -> transposed: out[index(r,l)] = in[lane_base(l) + r]   (transpose.rs:12-14)
-        load_lane_runs<T>(in_blk, c, rows);
+        __shared__ __attribute__((aligned(16))) char lds_in[(WG / 64) * RunExchange<T>::WAVE_BYTES];
+        load_lane_runs_lines<T>(lds_in + (tid >> 3) * RunExchange<T>::BLOCK_BYTES, c,
+                                reinterpret_cast<const u32x4*>(in_blk), rows);
         const TileStore<Elem<T>::CELLS_PER_BLOCK * 16> st(a.out, tile, a.n_blocks, tid);
         static_for<TB>([&](auto R) { st.store(Elem<T>::row_cell(decltype(R)::value), rows[decltype(R)::value]); });
     } else {

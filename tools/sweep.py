@@ -127,7 +127,9 @@ def main():
     elif args.cases == "orig":
         cases = [(op, ty, 0) for ty in ("u8", "u16", "u32", "u64") for op in ("transpose", "untranspose")]
         cases += [("undelta_pack_untranspose", "u32", 12), ("undelta_pack_untranspose", "u64", 20),
-                  ("undelta_pack_untranspose", "u16", 9), ("undelta_pack_untranspose", "u8", 4)]
+                  ("undelta_pack_untranspose", "u16", 9), ("undelta_pack_untranspose", "u8", 4),
+                  ("transpose_delta_pack", "u32", 12), ("transpose_delta_pack", "u64", 20),
+                  ("transpose_delta_pack", "u16", 9), ("transpose_delta_pack", "u8", 4)]
     elif args.cases == "consume":
         cases = [("unpack_block_sums", "u32", 7), ("unpack_block_sums", "u32", 20), ("unpack_block_sums", "u64", 17),
                  ("unpack_block_sums", "u16", 3), ("unpack_block_sums", "u8", 3),
