@@ -8,6 +8,7 @@
 #include "fl_mixed.hpp"
 #include "fl_consume.hpp"
 
+#include <algorithm>
 #include <new>
 #include <vector>
 
@@ -167,11 +168,12 @@ struct fl_mixed_plan {
     unsigned type_bits = 0;
     size_t n_blocks = 0;
     uint64_t packed_bytes = 0;
-    uint32_t* d_ids = nullptr;       // block ids bucketed by width, ascending inside a bucket
-    uint64_t* d_offsets = nullptr;   // byte offset of every block in the packed column
-    size_t bucket_start[66] = {0};   // ids[bucket_start[w] .. bucket_start[w+1]) have width w
-    bool window_unpack[65] = {false};
-    bool window_pack[65] = {false};
+    uint64_t n_tiles = 0;
+    MixedEntry* d_entries = nullptr; // (block, packed offset) bucketed by width, ascending inside a bucket
+    uint64_t* d_offsets = nullptr;   // byte offset of every block in the packed column, natural order
+    MixedTile* d_tiles = nullptr;    // one descriptor per tile of <= 32 same-width blocks
+    bool window_unpack = false;      // every tile's span fits a 32-bit store window
+    bool window_pack = false;
 };
 
 namespace {
@@ -184,22 +186,16 @@ int run_mixed(bool pack, const fl_mixed_plan* p, const void* packed, void* unpac
     if (p->n_blocks == 0) return FL_OK;
     if (!unpacked || (p->packed_bytes && !packed)) return FL_ERR_NULL;
     if (misaligned(packed) || misaligned(unpacked)) return FL_ERR_ALIGN;
-    const MixedTable<T>& tab = pack ? mixed_table_impl<T, true>() : mixed_table_impl<T, false>();
-    for (unsigned w = 0; w <= (unsigned)Elem<T>::BITS; ++w) {
-        const size_t m = p->bucket_start[w + 1] - p->bucket_start[w];
-        if (m == 0) continue;
-        MixedArgs a;
-        a.packed = static_cast<const char*>(packed);
-        a.unpacked = static_cast<char*>(unpacked);
-        a.ids = p->d_ids + p->bucket_start[w];
-        a.offsets = p->d_offsets;
-        a.m = m;
-        a.tiles_per_xcd = 0;
-        const bool window = pack ? p->window_pack[w] : p->window_unpack[w];
-        hipError_t e = tab.fn[w][window ? 1 : 0](a, static_cast<hipStream_t>(stream));
-        if (e != hipSuccess) return hip_fail(e);
-    }
-    return FL_OK;
+    MixedArgs a;
+    a.packed = static_cast<const char*>(packed);
+    a.unpacked = static_cast<char*>(unpacked);
+    a.entries = p->d_entries;
+    a.tiles = p->d_tiles;
+    a.n_tiles = p->n_tiles;
+    a.tiles_per_xcd = 0;
+    const bool window = pack ? p->window_pack : p->window_unpack;
+    hipError_t e = (pack ? mixed_pack_launcher<T>(window) : mixed_unpack_launcher<T>(window))(a, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? FL_OK : hip_fail(e);
 }
 
 }  // namespace
@@ -221,12 +217,13 @@ int fl_mixed_plan_create(unsigned type_bits, const uint8_t* widths, size_t n_blo
     if (!p) return FL_ERR_HIP;
     p->type_bits = type_bits;
     p->n_blocks = n_blocks;
-    for (unsigned w = 0; w <= 64; ++w) p->bucket_start[w + 1] = p->bucket_start[w] + count[w + 1];
+    size_t bucket_start[67] = {0};
+    for (unsigned w = 0; w <= 64; ++w) bucket_start[w + 1] = bucket_start[w] + count[w + 1];
     std::vector<uint32_t> ids(n_blocks);
     std::vector<uint64_t> off(n_blocks);
     {
         size_t cursor[66];
-        for (unsigned w = 0; w <= 65; ++w) cursor[w] = p->bucket_start[w];
+        for (unsigned w = 0; w <= 64; ++w) cursor[w] = bucket_start[w];
         uint64_t o = 0;
         for (size_t b = 0; b < n_blocks; ++b) {
             off[b] = o;
@@ -235,23 +232,38 @@ int fl_mixed_plan_create(unsigned type_bits, const uint8_t* widths, size_t n_blo
         }
         p->packed_bytes = o;
     }
+    // tiles: 32 same-width blocks each, buckets in width order; check the store windows
     const uint64_t block_bytes = 128ull * type_bits;
+    std::vector<MixedEntry> entries(n_blocks);
+    for (size_t i = 0; i < n_blocks; ++i) entries[i] = MixedEntry{ids[i], off[ids[i]]};
+    std::vector<MixedTile> tiles;
+    tiles.reserve(n_blocks / 32 + 66);
+    bool wu = true, wp = true;
     for (unsigned w = 0; w <= type_bits; ++w) {
-        const size_t s0 = p->bucket_start[w], m = p->bucket_start[w + 1] - s0;
-        bool wu = true, wp = true;
+        const size_t s0 = bucket_start[w], m = bucket_start[w + 1] - s0;
         for (size_t t = 0; t * 32 < m; ++t) {
-            const uint64_t first = ids[s0 + t * 32], last = ids[s0 + (t * 32 + 31 < m ? t * 32 + 31 : m - 1)];
+            const unsigned cnt = (unsigned)(m - t * 32 < 32 ? m - t * 32 : 32);
+            const uint64_t first = ids[s0 + t * 32], last = ids[s0 + t * 32 + cnt - 1];
+            tiles.push_back(MixedTile{(uint32_t)(s0 + t * 32), cnt | (w << 8), first, off[first], 0});
             if ((last - first + 1) * block_bytes > 0xFFFFFFFFull) wu = false;
             if (off[last] + 128ull * w - off[first] > 0xFFFFFFFFull) wp = false;
         }
-        p->window_unpack[w] = wu;
-        p->window_pack[w] = wp;
     }
+    // Launch order = column order: tiles are sorted by their first block, so neighbouring
+    // workgroups (and each XCD's contiguous share of the tile list) cover the same region of
+    // the column whatever their widths -- the global traffic stays a dense sweep.  (Bucket
+    // order, i.e. one width after the other, measured 20-25 % slower on interleaved widths.)
+    std::sort(tiles.begin(), tiles.end(), [](const MixedTile& x, const MixedTile& y) { return x.first_blk < y.first_blk; });
+    p->n_tiles = tiles.size();
+    p->window_unpack = wu;
+    p->window_pack = wp;
     if (n_blocks) {
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->d_ids), n_blocks * sizeof(uint32_t));
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->d_entries), n_blocks * sizeof(MixedEntry));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_offsets), n_blocks * sizeof(uint64_t));
-        if (e == hipSuccess) e = hipMemcpy(p->d_ids, ids.data(), n_blocks * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_tiles), tiles.size() * sizeof(MixedTile));
+        if (e == hipSuccess) e = hipMemcpy(p->d_entries, entries.data(), n_blocks * sizeof(MixedEntry), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(p->d_offsets, off.data(), n_blocks * sizeof(uint64_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(p->d_tiles, tiles.data(), tiles.size() * sizeof(MixedTile), hipMemcpyHostToDevice);
         if (e != hipSuccess) { fl_mixed_plan_destroy(p); return hip_fail(e); }
     }
     *plan = p;
@@ -261,8 +273,9 @@ int fl_mixed_plan_create(unsigned type_bits, const uint8_t* widths, size_t n_blo
 void fl_mixed_plan_destroy(fl_mixed_plan* p)
 {
     if (!p) return;
-    if (p->d_ids) (void)hipFree(p->d_ids);
+    if (p->d_entries) (void)hipFree(p->d_entries);
     if (p->d_offsets) (void)hipFree(p->d_offsets);
+    if (p->d_tiles) (void)hipFree(p->d_tiles);
     delete p;
 }
 size_t fl_mixed_plan_n_blocks(const fl_mixed_plan* p) { return p ? p->n_blocks : 0; }

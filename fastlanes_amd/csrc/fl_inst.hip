@@ -3,7 +3,7 @@
 // pairs x 5 width-parameterised kernels build in parallel:
 //   0 unpack (store)   1 unfor_pack   2 undelta_pack   3 pack   4 for_pack
 //   5 delta / undelta / transpose / untranspose / unpack_single
-//   6 unpack over a mixed-width plan   7 pack over a mixed-width plan
+//   6 unpack / 7 pack over a mixed-width plan (one launch, per-tile width dispatch)
 //   10 fused consumers: unpack_block_sums, block_min_max
 //   8 undelta_pack+untranspose (fused decode to original order)   9 transpose+delta+pack (fused encode)
 #include "fl_kernels.hpp"
@@ -44,11 +44,15 @@ template <> hipError_t unpack_single_launch<T>(const SingleArgs& a, hipStream_t 
     return launch_unpack_single<T>(a, s);
 }
 #elif FL_FAMILY == 6
-static constexpr MixedTable<T> t_mixed_unpack = make_mixed_table<T, false>(Ws{});
-template <> const MixedTable<T>& mixed_table_impl<T, false>() { return t_mixed_unpack; }
+template <> mixed_launch_t mixed_unpack_launcher<T>(bool window)
+{
+    return window ? &launch_mixed<T, false, true> : &launch_mixed<T, false, false>;
+}
 #elif FL_FAMILY == 7
-static constexpr MixedTable<T> t_mixed_pack = make_mixed_table<T, true>(Ws{});
-template <> const MixedTable<T>& mixed_table_impl<T, true>() { return t_mixed_pack; }
+template <> mixed_launch_t mixed_pack_launcher<T>(bool window)
+{
+    return window ? &launch_mixed<T, true, true> : &launch_mixed<T, true, false>;
+}
 #elif FL_FAMILY == 8
 static constexpr WidthTable<T> t_undelta_untr = make_unpack_table<T, BODY_UNDELTA_UNTRANSPOSE>(Ws{});
 template <> const WidthTable<T>& unpack_table_impl<T, BODY_UNDELTA_UNTRANSPOSE>() { return t_undelta_untr; }

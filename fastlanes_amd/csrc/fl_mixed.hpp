@@ -1,34 +1,43 @@
 // fl_mixed.hpp -- mixed-width columns: every block has its own width (BASELINE.json
 // config 5).  The reference has no multi-block API; its callers loop
 // `unchecked_unpack(width_of(block), ..)` over blocks (bitpacking.rs:109-129).  Here the
-// blocks are bucketed by width once (fl_mixed_plan: ids sorted by width, byte offsets =
-// exclusive prefix sum of 128*W) and each bucket is one launch of the same per-(T,W)
-// column kernels, reading/writing blocks through the id/offset indirection, so every
-// launch stays wave-uniform in W.
+// blocks are bucketed by width once (fl_mixed_plan: (block, packed offset) entries sorted by
+// width, offsets = exclusive prefix sum of 128*W; tiles of <= 32 same-width blocks, the tile
+// list sorted by column position) and the whole column is ONE launch: every workgroup reads
+// its tile descriptor (wave-uniform) and branches into the per-(T,W) column code -- the
+// device-side form of the reference's `match width { #(W => Self::unpack::<W>(..))* }`
+// (bitpacking.rs:115-128).
 #pragma once
 #include "fl_kernels.hpp"
 
 namespace fl {
 
+// One entry per block, in bucket order: where the block lives on both sides.
+struct MixedEntry {
+    uint64_t blk;          // block index in the column (unpacked side: blk * 1024 elements)
+    uint64_t packed_off;   // byte offset of the block in the packed column
+};
+// One descriptor per tile of <= 32 same-width blocks (read with scalar loads: wave-uniform).
+struct MixedTile {
+    uint32_t first_entry;
+    uint32_t count_width;  // count | width << 8
+    uint64_t first_blk;    // = entries[first_entry].blk        (lowest address of the tile)
+    uint64_t first_off;    // = entries[first_entry].packed_off
+    uint64_t pad_;
+};
+
 struct MixedArgs {
-    const char* packed;        // packed column base (bytes)
-    char* unpacked;            // unpacked column base (bytes)
-    const uint32_t* ids;       // this bucket's block ids, ascending
-    const uint64_t* offsets;   // byte offset of every block of the column in `packed`
-    uint64_t m;                // blocks in this bucket
+    const char* packed;          // packed column base (bytes)
+    char* unpacked;              // unpacked column base (bytes)
+    const MixedEntry* entries;   // [n_blocks], buckets in width order, ascending blk inside a bucket
+    const MixedTile* tiles;      // [n_tiles]
+    uint64_t n_tiles;
     uint64_t tiles_per_xcd;
 };
 
-__device__ __forceinline__ bool tile_of_workgroup(const MixedArgs& a, uint64_t& tile)
-{
-    const uint64_t n_tiles = (a.m + BLOCKS_PER_WG - 1) / BLOCKS_PER_WG;
-    tile = (uint64_t)(blockIdx.x & 7u) * a.tiles_per_xcd + (blockIdx.x >> 3);
-    return tile < n_tiles;
-}
-
 // Streaming-store window over the span of one tile's blocks (they are ascending, so the
-// first entry is the lowest address).  WINDOW=false: the span does not fit a 32-bit buffer
-// offset (pathologically sparse bucket) -> plain non-temporal global stores.
+// first entry is the lowest address).  WINDOW=false: some tile's span does not fit a 32-bit
+// buffer offset (pathologically sparse bucket) -> plain non-temporal global stores.
 template <bool WINDOW> struct SpanStore {
     __amdgpu_buffer_rsrc_t rs;
     char* base;
@@ -49,74 +58,75 @@ template <bool WINDOW> struct SpanStore {
 };
 
 template <typename T, int W, bool WINDOW>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, UnpackPolicy<T, W>::MAXW)))
-void k_unpack_mixed(MixedArgs a)
+__device__ __forceinline__ void unpack_mixed_tile(const MixedArgs& a, const MixedTile& t, const MixedEntry& e, unsigned c)
 {
     constexpr bool NTL = UnpackPolicy<T, W>::NT_LOAD;
     constexpr unsigned BLOCK_BYTES = Elem<T>::CELLS_PER_BLOCK * 16;
-    uint64_t tile;
-    if (!tile_of_workgroup(a, tile)) return;
-    const unsigned tid = threadIdx.x;
-    const uint64_t e = tile * BLOCKS_PER_WG + (tid >> 3);
-    const unsigned c = tid & 7u;
-    if (e >= a.m) return;
-    const uint64_t first = a.ids[tile * BLOCKS_PER_WG];   // wave-uniform
-    const uint64_t blk = a.ids[e];
     Cell<T> in[W ? W : 1];
-    const u32x4* pk = reinterpret_cast<const u32x4*>(a.packed + a.offsets[blk]) + c;
+    const u32x4* pk = reinterpret_cast<const u32x4*>(a.packed + e.packed_off) + c;
     static_for<W>([&](auto Wd) { in[decltype(Wd)::value] = load_cell<T, NTL>(pk + 8 * decltype(Wd)::value); });
-    const SpanStore<WINDOW> st(a.unpacked + first * BLOCK_BYTES, a.unpacked + blk * BLOCK_BYTES + c * 16);
+    const SpanStore<WINDOW> st(a.unpacked + t.first_blk * BLOCK_BYTES, a.unpacked + e.blk * BLOCK_BYTES + c * 16);
     unpack_rows<T, W>(in, [&](auto R, const Cell<T>& v) { st.store(16 * Elem<T>::row_cell(decltype(R)::value), v); });
 }
 
 template <typename T, int W, bool WINDOW>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, PackPolicy<T>::MAXW)))
-void k_pack_mixed(MixedArgs a)
+__device__ __forceinline__ void pack_mixed_tile(const MixedArgs& a, const MixedTile& t, const MixedEntry& e, unsigned c)
 {
     constexpr int TB = Elem<T>::BITS;
     constexpr unsigned BLOCK_BYTES = Elem<T>::CELLS_PER_BLOCK * 16;
-    uint64_t tile;
-    if (!tile_of_workgroup(a, tile)) return;
-    const unsigned tid = threadIdx.x;
-    const uint64_t e = tile * BLOCKS_PER_WG + (tid >> 3);
-    const unsigned c = tid & 7u;
-    if (e >= a.m) return;
     if constexpr (W == 0) return;
-    const uint64_t first = a.ids[tile * BLOCKS_PER_WG];
-    const uint64_t blk = a.ids[e];
-    const u32x4* un = reinterpret_cast<const u32x4*>(a.unpacked + blk * BLOCK_BYTES) + c;
+    const u32x4* un = reinterpret_cast<const u32x4*>(a.unpacked + e.blk * BLOCK_BYTES) + c;
     Cell<T> rows[TB];
     static_for<TB>([&](auto R) {
         rows[decltype(R)::value] = load_cell<T, true>(un + Elem<T>::row_cell(decltype(R)::value));
     });
     char* pk = const_cast<char*>(a.packed);
-    const SpanStore<WINDOW> st(pk + a.offsets[first], pk + a.offsets[blk] + c * 16);
+    const SpanStore<WINDOW> st(pk + t.first_off, pk + e.packed_off + c * 16);
     pack_rows<T, W>([&](auto R) { return rows[decltype(R)::value]; },
                     [&](auto Wd, const Cell<T>& v) { st.store(128 * decltype(Wd)::value, v); });
 }
 
+template <typename T, bool PACK, bool WINDOW, int... Ws>
+__device__ __forceinline__ void dispatch_width(unsigned w, const MixedArgs& a, const MixedTile& t, const MixedEntry& e,
+                                               unsigned c, std::integer_sequence<int, Ws...>)
+{
+    // wave-uniform chain of compares: exactly one body runs per workgroup
+    (void)((w == (unsigned)Ws
+                ? ((PACK ? pack_mixed_tile<T, Ws, WINDOW>(a, t, e, c)
+                         : unpack_mixed_tile<T, Ws, WINDOW>(a, t, e, c)), true)
+                : false) || ...);
+}
+
+template <typename T, bool PACK, bool WINDOW>
+__global__ __launch_bounds__(WG)
+__attribute__((amdgpu_waves_per_eu(1, PACK ? PackPolicy<T>::MAXW : UnpackPolicy<T, 0>::MAXW)))
+void k_mixed(MixedArgs a)
+{
+    const uint64_t tile = (uint64_t)(blockIdx.x & 7u) * a.tiles_per_xcd + (blockIdx.x >> 3);
+    if (tile >= a.n_tiles) return;
+    const MixedTile t = a.tiles[tile];                         // wave-uniform (scalar loads)
+    const unsigned count = t.count_width & 0xffu, w = t.count_width >> 8;
+    const unsigned tid = threadIdx.x;
+    const unsigned g = tid >> 3, c = tid & 7u;
+    if (g >= count) return;
+    const MixedEntry e = a.entries[t.first_entry + g];         // one 16-byte load per thread
+    dispatch_width<T, PACK, WINDOW>(w, a, t, e, c, std::make_integer_sequence<int, Elem<T>::BITS + 1>{});
+}
+
 typedef hipError_t (*mixed_launch_t)(const MixedArgs&, hipStream_t);
 
-template <typename T, int W, bool PACK, bool WINDOW>
+template <typename T, bool PACK, bool WINDOW>
 hipError_t launch_mixed(const MixedArgs& a0, hipStream_t s)
 {
-    if (a0.m == 0 || (PACK && W == 0)) return hipSuccess;
+    if (a0.n_tiles == 0) return hipSuccess;
     MixedArgs a = a0;
-    const uint64_t n_tiles = (a.m + BLOCKS_PER_WG - 1) / BLOCKS_PER_WG;
-    a.tiles_per_xcd = (n_tiles + 7) / 8;
-    const unsigned grid = (unsigned)(a.tiles_per_xcd * 8);
-    if constexpr (PACK) hipLaunchKernelGGL((k_pack_mixed<T, W, WINDOW>), dim3(grid), dim3(WG), 0, s, a);
-    else hipLaunchKernelGGL((k_unpack_mixed<T, W, WINDOW>), dim3(grid), dim3(WG), 0, s, a);
+    a.tiles_per_xcd = (a.n_tiles + 7) / 8;
+    hipLaunchKernelGGL((k_mixed<T, PACK, WINDOW>), dim3((unsigned)(a.tiles_per_xcd * 8)), dim3(WG), 0, s, a);
     return hipGetLastError();
 }
 
-// [width][window?]
-template <typename T> struct MixedTable { mixed_launch_t fn[Elem<T>::BITS + 1][2]; };
-template <typename T, bool PACK, int... Ws>
-constexpr MixedTable<T> make_mixed_table(std::integer_sequence<int, Ws...>)
-{
-    return MixedTable<T>{{{&launch_mixed<T, Ws, PACK, false>, &launch_mixed<T, Ws, PACK, true>}...}};
-}
-template <typename T, bool PACK> const MixedTable<T>& mixed_table_impl();
+// specialised in fl_inst.hip (families 6 and 7, separate TUs so they build in parallel)
+template <typename T> mixed_launch_t mixed_unpack_launcher(bool window);
+template <typename T> mixed_launch_t mixed_pack_launcher(bool window);
 
 }  // namespace fl

@@ -80,9 +80,10 @@ size_t fl_packed_len(unsigned type_bits, unsigned width);
  * (bitpacking.rs:109-129; loop shape of benches/bitpacking.rs:90-97) moved on-device.
  * Packed blocks are laid out back to back: off[b] = sum_{i<b} 128*widths[i] bytes.
  * A plan is built ONCE per column from the HOST widths array (bucket blocks by width,
- * prefix-sum the offsets, upload both to the current device); the pack/unpack calls are
- * then allocation-free and asynchronous like every other device-tier call: one kernel
- * launch per distinct width on `stream`.  The plan must be used on the device it was
+ * prefix-sum the offsets, cut the buckets into 32-block tiles, upload to the current
+ * device); the pack/unpack calls are then allocation-free and asynchronous like every other
+ * device-tier call: ONE kernel launch on `stream`, each workgroup dispatching on its tile's
+ * width.  The plan must be used on the device it was
  * created on and destroyed by the caller.
  */
 typedef struct fl_mixed_plan fl_mixed_plan;
