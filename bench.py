@@ -88,7 +88,27 @@ def cpu_baseline(args, ty, width, op):
             best = dt if best is None else min(best, dt)
             reps += 1
         res[label] = n * 1024 / best / 1e9
+    # configs[0] / benches/bitpacking.rs:67-99: the criterion "throughput" shape -- 1024 blocks of
+    # u16 W=3, cache-resident, single thread, reported like criterion's Throughput::Bytes(N*2)
+    crit = {}
+    try:
+        nb = 1024
+        v16 = (np.arange(nb * 1024) % 8).astype(np.uint16)
+        p16 = np.zeros(nb * 192, dtype=np.uint16)
+        u16 = np.zeros(nb * 1024, dtype=np.uint16)
+        for name, fn in (("compress", lambda: o.fast("pack", "u16", 3, v16, n_blocks=nb, out=p16)),
+                         ("decompress", lambda: o.fast("unpack", "u16", 3, p16, n_blocks=nb, out=u16))):
+            fn()
+            best = None
+            for _ in range(200):
+                t0 = time.perf_counter(); fn(); dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            crit[name + "_GBps_of_unpacked_bytes"] = round(nb * 2048 / best / 1e9, 2)
+        crit["ok"] = bool(np.array_equal(u16, v16))
+    except Exception as e:  # the baseline must never take the bench down
+        crit = {"error": str(e)}
     return {
+        "criterion_throughput_shape_u16_w3_1024_blocks_1_thread": crit,
         "value": round(res["all_cores"], 3),
         "unit": "Gint/s",
         "cores": cores,

@@ -212,6 +212,9 @@ def _rand_dev(nbytes, seed):
     return torch.randint(-2**63, 2**63 - 1, (nbytes // 8,), dtype=torch.int64, device="cuda:0", generator=g)
 
 
+SUBSET = 65_536
+
+
 def _sample_blocks(n):
     return sorted({0, 1, 31, 32, n // 2, n - 33, n - 2, n - 1})
 
@@ -230,6 +233,10 @@ def test_config2_u32_w7_10M_blocks(fl, oracle):
     for b in _sample_blocks(n):
         got = to_np(out[b * 1024:(b + 1) * 1024], "u32")
         assert np.array_equal(got, oracle.unpack("u32", 7, to_np(pk[b * 224:(b + 1) * 224], "u32"))), b
+    # a >= 65 536-block subset through the CPU oracle, byte for byte
+    for b0 in (0, n - SUBSET):
+        want = oracle.fast("unpack", "u32", 7, to_np(pk[b0 * 224:(b0 + SUBSET) * 224], "u32"), nthreads=8)
+        assert np.array_equal(to_np(out[b0 * 1024:(b0 + SUBSET) * 1024], "u32"), want)
 
 
 def test_config3_u64_w17_10M_blocks(fl, oracle):
@@ -243,6 +250,11 @@ def test_config3_u64_w17_10M_blocks(fl, oracle):
     for b in _sample_blocks(n):
         got = to_np(out[b * 1024:(b + 1) * 1024], "u64")
         assert np.array_equal(got, oracle.unpack("u64", 17, to_np(pk[b * 272:(b + 1) * 272], "u64"))), b
+    for b0 in (0, n - SUBSET):
+        want = oracle.fast("unpack", "u64", 17, to_np(pk[b0 * 272:(b0 + SUBSET) * 272], "u64"), nthreads=8)
+        assert np.array_equal(to_np(out[b0 * 1024:(b0 + SUBSET) * 1024], "u64"), want)
+        wantp = oracle.fast("pack", "u64", 17, want, nthreads=8)
+        assert np.array_equal(to_np(back[b0 * 272:(b0 + SUBSET) * 272], "u64"), wantp)
 
 
 def test_config4_fused_delta_u32_w12_10M_blocks(fl, oracle):
@@ -262,6 +274,10 @@ def test_config4_fused_delta_u32_w12_10M_blocks(fl, oracle):
         want = oracle.undelta_pack("u32", 12, to_np(pk[b * 384:(b + 1) * 384], "u32"),
                                    to_np(bases[b * 32:(b + 1) * 32], "u32"))
         assert np.array_equal(got, want), b
+    for b0 in (0, n - SUBSET):
+        want = oracle.fast("undelta_pack", "u32", 12, to_np(pk[b0 * 384:(b0 + SUBSET) * 384], "u32"),
+                           aux=to_np(bases[b0 * 32:(b0 + SUBSET) * 32], "u32"), nthreads=8)
+        assert np.array_equal(to_np(fused[b0 * 1024:(b0 + SUBSET) * 1024], "u32"), want)
 
 
 def test_cpp_trait_mirror_reference_tests(fl):
@@ -484,4 +500,24 @@ def test_streams_and_graph_capture(fl, oracle):
             wantm.append(oracle.unpack("u32", int(w), col[pos:pos + 32 * int(w)]))
             pos += 32 * int(w)
         assert np.array_equal(to_np(mixed_out, "u32"), np.concatenate(wantm))
+    plan.close()
+
+
+def test_mixed_plan_sparse_bucket_uses_fallback_stores(fl, oracle):
+    """A bucket whose tile spans more than a 32-bit store window (two width-2 u64 blocks
+    600 000 blocks = 4.9 GB apart) must take the non-windowed store path and stay exact."""
+    import torch
+    n = 600_001
+    widths = np.ones(n, dtype=np.uint8)
+    widths[0] = 2
+    widths[n - 1] = 2
+    plan = fl.MixedWidthPlan("u64", widths)
+    col = _rand_dev(plan.packed_bytes, 47).view(torch.uint64)
+    out = plan.unpack(col)
+    assert torch.equal(plan.pack(out).view(torch.int64), col.view(torch.int64))
+    off = np.concatenate([[0], np.cumsum(widths.astype(np.int64) * 16)])
+    for b in (0, 1, 31, 32, n // 2, n - 2, n - 1):
+        w = int(widths[b])
+        pk = to_np(col[off[b]:off[b] + 16 * w], "u64")
+        assert np.array_equal(to_np(out[b * 1024:(b + 1) * 1024], "u64"), oracle.unpack("u64", w, pk)), b
     plan.close()

@@ -147,6 +147,22 @@ def main():
     if args.cases == "host":
         host_tier()
         return
+    if args.cases == "single":
+        # batched unpack_single (random access): 64 M random indices into a 1 M-block u32 W=7 column
+        n, k = 1_000_000, 64_000_000
+        pk = rnd(n * 896, 1).view(torch.uint32)
+        g = torch.Generator(device=dev); g.manual_seed(5)
+        idx = torch.randint(0, n * 1024, (k,), dtype=torch.int64, device=dev, generator=g)
+        for sorted_idx in (False, True):
+            ii = torch.sort(idx).values if sorted_idx else idx
+            fl.BitPacking.unpack_single(7, pk, ii, n_blocks=n)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); fl.BitPacking.unpack_single(7, pk, ii, n_blocks=n); b.record(); b.synchronize()
+            ms = a.elapsed_time(b)
+            print(f"unpack_single u32 W=7 {k} {'sorted' if sorted_idx else 'random'} indices over {n} blocks: "
+                  f"{ms:.3f} ms  {k / ms / 1e6:.2f} G lookups/s", flush=True)
+        return
     out = []
     for op, ty, w in cases:
         r = run(op, ty, w, args.gb, args.reps)
