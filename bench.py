@@ -46,6 +46,10 @@ def parse():
     ap.add_argument("--workload", default="u32_w7_unpack", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="CPU baseline time budget per leg")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier / max-time "
+                    "reduction (nccl = RCCL; gloo only for plumbing tests)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="plumbing test: put every rank on cuda:0 (use with --backend gloo)")
     return ap.parse_args()
 
 
@@ -128,10 +132,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.single_device:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 
@@ -195,7 +204,7 @@ def main():
     kern_ms = [a.elapsed_time(b) for a, b in evs]
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
