@@ -388,32 +388,55 @@ __device__ __forceinline__ void load_lane_runs_lines(char* lds_blk, unsigned c, 
 //   in[w]   : packed word-row w of this column (W cells, all in registers)
 //   f(R, c) : called for R = integral_constant<int,row>, row = 0..T-1 in order
 // ---------------------------------------------------------------------------
-template <typename T, int W, typename F>
-__device__ __forceinline__ void unpack_rows(const Cell<T>* in, F&& f)
+// One row of the unpack! expansion: the W-bit field of logical row ROW of this column.
+template <typename T, int W, int ROW>
+__device__ __forceinline__ Cell<T> unpack_row(const Cell<T>* in)
 {
     constexpr int TB = Elem<T>::BITS;
     static_assert(W >= 0 && W <= TB, "BitPackWidth<W>: W <= T (bitpacking.rs:8-13)");
-    static_for<TB>([&](auto R) {
-        constexpr int row = decltype(R)::value;
-        if constexpr (W == 0) {
-            f(R, Cell<T>::zero());                       // macros.rs:118-125
-        } else if constexpr (W == TB) {
-            f(R, in[row]);                               // macros.rs:126-132
+    static_assert(ROW >= 0 && ROW < TB, "row out of range");
+    if constexpr (W == 0) {
+        return Cell<T>::zero();                          // macros.rs:118-125
+    } else if constexpr (W == TB) {
+        return in[ROW];                                  // macros.rs:126-132
+    } else {
+        constexpr int curr = (ROW * W) / TB;             // macros.rs:144
+        constexpr int next = ((ROW + 1) * W) / TB;       // macros.rs:145
+        constexpr int shift = (ROW * W) % TB;            // macros.rs:147
+        if constexpr (next > curr) {
+            constexpr int rem = ((ROW + 1) * W) % TB;
+            constexpr int cur = W - rem;
+            Cell<T> v = in[curr].template extract<shift, cur>();       // macros.rs:152
+            if constexpr (next < W && rem > 0)                         // macros.rs:156-161
+                v = v | in[next].template deposit<cur, rem>();
+            return v;
         } else {
-            constexpr int curr = (row * W) / TB;         // macros.rs:144
-            constexpr int next = ((row + 1) * W) / TB;   // macros.rs:145
-            constexpr int shift = (row * W) % TB;        // macros.rs:147
-            if constexpr (next > curr) {
-                constexpr int rem = ((row + 1) * W) % TB;
-                constexpr int cur = W - rem;
-                Cell<T> v = in[curr].template extract<shift, cur>();   // macros.rs:152
-                if constexpr (next < W && rem > 0)                     // macros.rs:156-161
-                    v = v | in[next].template deposit<cur, rem>();
-                f(R, v);
-            } else {
-                f(R, in[curr].template extract<shift, W>());           // macros.rs:164
-            }
+            return in[curr].template extract<shift, W>();              // macros.rs:164
         }
+    }
+}
+
+template <typename T, int W, typename F>
+__device__ __forceinline__ void unpack_rows(const Cell<T>* in, F&& f)
+{
+    static_for<Elem<T>::BITS>([&](auto R) { f(R, unpack_row<T, W, decltype(R)::value>(in)); });
+}
+
+// Same rows, visited in ASCENDING ADDRESS order of the unpacked block instead of row order
+// (cell-row j <-> logical row FL_ORDER[j % (T/8) * (64/T)] * 8 + j / (T/8); FL_ORDER is its own
+// inverse, lib.rs:53-59).  Only for stateless bodies (plain / FoR stores): the reference
+// visits rows in order "in case the kernel has side effects" (macros.rs:119), which a store
+// to a distinct index has not.  Measured +1.5 % on u32 W=7 (profiles/abbench_r01h.txt).
+template <typename T, int W, typename F>
+__device__ __forceinline__ void unpack_rows_by_address(const Cell<T>* in, F&& f)
+{
+    constexpr int TB = Elem<T>::BITS;
+    constexpr int PER_S = TB / 8;
+    static_for<TB>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        constexpr int row = fl_order((j % PER_S) * (8 / PER_S)) * 8 + j / PER_S;
+        static_assert(Elem<T>::row_cell(row) == 8 * j, "address-order row mapping (a row is 8 cells)");
+        f(std::integral_constant<int, row>{}, unpack_row<T, W, row>(in));
     });
 }
 

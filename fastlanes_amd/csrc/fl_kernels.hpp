@@ -103,13 +103,13 @@ void k_unpack(StreamArgs a)
 
     const TileStore<Elem<T>::CELLS_PER_BLOCK * 16> st(a.out, tile, a.n_blocks, tid);
     if constexpr (BODY == BODY_STORE) {
-        unpack_rows<T, W>(in, [&](auto R, const Cell<T>& v) {
+        unpack_rows_by_address<T, W>(in, [&](auto R, const Cell<T>& v) {
             st.store(Elem<T>::row_cell(decltype(R)::value), v);                 // bitpacking.rs:103-105
         });
     } else if constexpr (BODY == BODY_ADD_REF) {
         const T* refs = static_cast<const T*>(a.aux);
         const Cell<T> ref = Cell<T>::splat(refs[blk * a.aux_stride]);
-        unpack_rows<T, W>(in, [&](auto R, const Cell<T>& v) {
+        unpack_rows_by_address<T, W>(in, [&](auto R, const Cell<T>& v) {
             st.store(Elem<T>::row_cell(decltype(R)::value), v.add(ref));        // ffor.rs:46-48
         });
     } else if constexpr (BODY == BODY_UNDELTA) {

@@ -66,7 +66,7 @@ __device__ __forceinline__ void unpack_mixed_tile(const MixedArgs& a, const Mixe
     const u32x4* pk = reinterpret_cast<const u32x4*>(a.packed + e.packed_off) + c;
     static_for<W>([&](auto Wd) { in[decltype(Wd)::value] = load_cell<T, NTL>(pk + 8 * decltype(Wd)::value); });
     const SpanStore<WINDOW> st(a.unpacked + t.first_blk * BLOCK_BYTES, a.unpacked + e.blk * BLOCK_BYTES + c * 16);
-    unpack_rows<T, W>(in, [&](auto R, const Cell<T>& v) { st.store(16 * Elem<T>::row_cell(decltype(R)::value), v); });
+    unpack_rows_by_address<T, W>(in, [&](auto R, const Cell<T>& v) { st.store(16 * Elem<T>::row_cell(decltype(R)::value), v); });
 }
 
 template <typename T, int W, bool WINDOW>

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(WGS) void k_unpack_v(Args a)
 // CHUNK-granular XCD remap + buffer-store cache policy (AUX: 0 plain, 1 sc0, 2 nt, 16 sc1, combos; -1 = global store)
 // blockIdx b runs on XCD b%8 (observed).  Remap so that each XCD owns runs of K consecutive workgroups:
 //   wg = (b / (8K)) * 8K + (b % 8) * K + (b / 8) % K
-template <typename T, int W, int AUX, int LAUX, int MAXW = 8>
+template <typename T, int W, int AUX, int LAUX, int MAXW = 8, int ORDER = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, MAXW))) void k_unpack_x(Args a, unsigned K)
 {
     constexpr int BPW = 32;
@@ -81,9 +81,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, MAXW))) 
         u32x4* wg_out = a.out + wg * (uint64_t)(BPW * Elem<T>::CELLS_PER_BLOCK);
         auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)wg_out, 0, BPW * Elem<T>::CELLS_PER_BLOCK * 16, 0x00020000);
         const unsigned vo = (tid >> 3) * (Elem<T>::CELLS_PER_BLOCK * 16) + c * 16;
-        unpack_rows<T, W>(in, [&](auto R, const Cell<T>& v) {
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, vo + 16 * Elem<T>::row_cell(decltype(R)::value), 0, AUX);
-        });
+        if constexpr (ORDER == 0) {
+            unpack_rows<T, W>(in, [&](auto R, const Cell<T>& v) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, vo + 16 * Elem<T>::row_cell(decltype(R)::value), 0, AUX);
+            });
+        } else {
+            // ascending address order: cell-row j*sizeof(T) holds logical row (j/8 -> s, j%8 -> FL_ORDER^-1)
+            static_for<Elem<T>::BITS>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                constexpr int per_s = Elem<T>::BITS / 8;                 // rows per s-group
+                constexpr int s_ = j / per_s, f_ = j % per_s;            // f_ = FL_ORDER[o] rank
+                // find o with fl_order(o) == f_-th smallest among o < per_s
+                constexpr int o = fl_order(f_ * (8 / per_s)) ;          // FL_ORDER is self-inverse
+                constexpr int r = o * 8 + s_;
+                const Cell<T> v = unpack_row<T, W, r>(in);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, vo + 16 * Elem<T>::row_cell(r), 0, AUX);
+            });
+        }
     }
 }
 
@@ -219,52 +233,12 @@ int main(int argc, char** argv)
         if (K > 1) n_wg = (n_wg + 8ull * K - 1) / (8ull * K) * (8ull * K);
         vs.push_back({name, by, [=]() { hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), lds, 0, aa, K); }, {}});
     };
-    Args ap{out, in, n};
     addX("unpack u32w7 base", k_unpack_x<uint32_t, 7, -1, -1>, 1, a, bytes, 0);
-    addX("unpack u32w7 G st18", k_unpack_x<uint32_t, 7, 18, -1>, G, a, bytes, 0);
-    addX("unpack u32w7 G st18 occ2(lds)", k_unpack_x<uint32_t, 7, 18, -1>, G, a, bytes, 160 * 1024 / 2 - 1024);
-    addX("unpack u32w7 G st18 maxw1", k_unpack_x<uint32_t, 7, 18, -1, 1>, G, a, bytes, 0);
-    addX("unpack u32w7 G st18 maxw2", k_unpack_x<uint32_t, 7, 18, -1, 2>, G, a, bytes, 0);
-    addX("unpack u32w7 G st18 maxw3", k_unpack_x<uint32_t, 7, 18, -1, 3>, G, a, bytes, 0);
-    addX("unpack u32w7 G st18 maxw4", k_unpack_x<uint32_t, 7, 18, -1, 4>, G, a, bytes, 0);
-    addX("pack u32w7 base", k_pack_x<uint32_t, 7, -1, -1>, 1, ap, bytes, 0);
-    addX("pack u32w7 G st18 ldnt", k_pack_x<uint32_t, 7, 18, 2>, G, ap, bytes, 0);
-    addX("pack u32w7 G st18 ldnt maxw1", k_pack_x<uint32_t, 7, 18, 2, 1>, G, ap, bytes, 0);
-    addX("pack u32w7 G st18 ldnt maxw2", k_pack_x<uint32_t, 7, 18, 2, 2>, G, ap, bytes, 0);
-    addX("pack u32w7 G st18 ldnt maxw3", k_pack_x<uint32_t, 7, 18, 2, 3>, G, ap, bytes, 0);
-    addX("pack u32w7 G st18 ldnt occ2(lds)", k_pack_x<uint32_t, 7, 18, 2>, G, ap, bytes, 160 * 1024 / 2 - 1024);
-    // u64 W=17: 2176 B packed / 8192 B unpacked per block; n/2 blocks fit the same buffers (in: n*896+128M >= n/2*2176)
-    Args a64{in, out, n / 2}, ap64{out, in, n / 2};
-    const double by64 = (double)(n / 2) * 10368;
-    const uint64_t nwg64 = (n / 2 + 31) / 32;
-    const unsigned G64 = (unsigned)((nwg64 + 7) / 8);
-    auto addY = [&](const std::string& name, auto kern, unsigned K, Args aa, double by, uint64_t nwg) {
-        uint64_t n_wg = nwg;
-        if (K > 1) n_wg = (n_wg + 8ull * K - 1) / (8ull * K) * (8ull * K);
-        vs.push_back({name, by, [=]() { hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), 0, 0, aa, K); }, {}});
-    };
-    addY("unpack u64w17 base", k_unpack_x<uint64_t, 17, -1, -1>, 1, a64, by64, nwg64);
-    addY("unpack u64w17 G st18", k_unpack_x<uint64_t, 17, 18, -1>, G64, a64, by64, nwg64);
-    addY("unpack u64w17 G st18 maxw2", k_unpack_x<uint64_t, 17, 18, -1, 2>, G64, a64, by64, nwg64);
-    addY("unpack u64w17 G st18 maxw3", k_unpack_x<uint64_t, 17, 18, -1, 3>, G64, a64, by64, nwg64);
-    addY("pack u64w17 base", k_pack_x<uint64_t, 17, -1, -1>, 1, ap64, by64, nwg64);
-    addY("pack u64w17 G st18 ldnt", k_pack_x<uint64_t, 17, 18, 2>, G64, ap64, by64, nwg64);
-    addY("pack u64w17 G st18 ldnt maxw1", k_pack_x<uint64_t, 17, 18, 2, 1>, G64, ap64, by64, nwg64);
-    // u16 W=3: 384 B packed / 2048 B unpacked; 2n blocks would overflow `in`, use n blocks
-    Args a16{in, out, n};
-    const double by16 = (double)n * 2432;
-    addY("unpack u16w3 base", k_unpack_x<uint16_t, 3, -1, -1>, 1, a16, by16, n_wg0);
-    addY("unpack u16w3 G st18", k_unpack_x<uint16_t, 3, 18, -1>, G, a16, by16, n_wg0);
-    addY("unpack u16w3 G st18 maxw2", k_unpack_x<uint16_t, 3, 18, -1, 2>, G, a16, by16, n_wg0);
-    addY("unpack u16w3 G st18 maxw4", k_unpack_x<uint16_t, 3, 18, -1, 4>, G, a16, by16, n_wg0);
-    // u32 W=31 (heavy loads: 31 packed words) and W=1
-    Args a31{in, out, n / 4};
-    addY("unpack u32w31 base", k_unpack_x<uint32_t, 31, -1, -1>, 1, a31, (double)(n / 4) * (128 * 31 + 4096), (n / 4 + 31) / 32);
-    addY("unpack u32w31 G st18", k_unpack_x<uint32_t, 31, 18, -1>, (unsigned)(((n / 4 + 31) / 32 + 7) / 8), a31, (double)(n / 4) * (128 * 31 + 4096), (n / 4 + 31) / 32);
-    addY("unpack u32w31 G st18 maxw2", k_unpack_x<uint32_t, 31, 18, -1, 2>, (unsigned)(((n / 4 + 31) / 32 + 7) / 8), a31, (double)(n / 4) * (128 * 31 + 4096), (n / 4 + 31) / 32);
-    addY("unpack u32w31 G st18 ldnt maxw2", k_unpack_x<uint32_t, 31, 18, 2, 2>, (unsigned)(((n / 4 + 31) / 32 + 7) / 8), a31, (double)(n / 4) * (128 * 31 + 4096), (n / 4 + 31) / 32);
-    addY("unpack u32w1 base", k_unpack_x<uint32_t, 1, -1, -1>, 1, a, (double)n * (128 + 4096), n_wg0);
-    addY("unpack u32w1 G st18 maxw2", k_unpack_x<uint32_t, 1, 18, -1, 2>, G, a, (double)n * (128 + 4096), n_wg0);
+    addX("G st18 maxw2 row-order", k_unpack_x<uint32_t, 7, 18, -1, 2, 0>, G, a, bytes, 0);
+    addX("G st18 maxw2 addr-order", k_unpack_x<uint32_t, 7, 18, -1, 2, 1>, G, a, bytes, 0);
+    addX("G st18 maxw3 row-order", k_unpack_x<uint32_t, 7, 18, -1, 3, 0>, G, a, bytes, 0);
+    addX("G st18 maxw3 addr-order", k_unpack_x<uint32_t, 7, 18, -1, 3, 1>, G, a, bytes, 0);
+    addX("G st18 maxw2 row-order (again)", k_unpack_x<uint32_t, 7, 18, -1, 2, 0>, G, a, bytes, 0);
     const uint64_t n_thr = n * 8;
     auto addS = [&](const char* name, auto kern, double by) {
         vs.push_back({name, by, [=]() { hipLaunchKernelGGL(kern, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, 0, (const u32x4*)in, out, n_thr, sink); }, {}});
