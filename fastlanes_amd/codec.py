@@ -76,13 +76,20 @@ class _Arg:
             self.n = x.numel()
             self.ptr = x.data_ptr()
         else:
-            a = np.ascontiguousarray(x)
-            if ty is not None and a.dtype != _NP_DTYPE[ty]:
-                a = a.astype(_NP_DTYPE[ty])
+            a = np.asarray(x)
+            if a.dtype.kind not in "ui":
+                raise TypeError(f"expected an unsigned integer array, got dtype {a.dtype}")
+            if ty is not None and a.dtype.itemsize * 8 != _lib.BITS[ty]:
+                raise TypeError(f"expected a {ty} array, got dtype {a.dtype}")
+            if not a.flags["C_CONTIGUOUS"]:
+                raise ValueError("array must be C-contiguous (an output would otherwise be written to a copy)")
+            a = a.view(_NP_DTYPE[_NP[a.dtype.itemsize]])   # signed ints are reinterpreted, never converted
             self.x = a
             self.n = a.size
             self.ptr = a.ctypes.data
         self.ty = ty or _ty_of(x)
+        if self.torch and ty is not None and x.element_size() * 8 != _lib.BITS[ty]:
+            raise TypeError(f"expected a {ty} tensor, got dtype {x.dtype}")
 
 
 def _empty_like(arg, n, ty):

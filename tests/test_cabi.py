@@ -117,3 +117,18 @@ def test_functor_api_example_builds():
     import __graft_entry__ as ge
     so = ge.build_examples()
     assert hasattr(ctypes.CDLL(so), "example_dict_unpack_u32_w8")
+
+
+def test_python_mirror_rejects_mismatched_buffers():
+    """Outputs are never silently converted or copied: wrong element size / non-contiguous
+    arrays raise instead of writing the result into a temporary."""
+    import fastlanes_amd as fl
+    v = np.zeros(1024, dtype=np.uint16)
+    with pytest.raises(TypeError):
+        fl.BitPacking.pack(3, v, output=np.zeros(96, dtype=np.uint32))
+    with pytest.raises(TypeError):
+        fl.BitPacking.pack(3, np.zeros(1024, dtype=np.float32))
+    with pytest.raises(ValueError):
+        fl.BitPacking.pack(3, np.zeros(2048, dtype=np.uint16)[::2])
+    with pytest.raises(TypeError):
+        fl.Delta.delta(v, np.zeros(64, dtype=np.uint8))

@@ -183,6 +183,54 @@ __global__ __launch_bounds__(256) void k_unpack_p(Args a, unsigned wgs_per_xcd)
     }
 }
 
+// The north_star sketch, for the record: a wavefront owns whole blocks (here 2: lanes 0-31 /
+// 32-63 = the 32 FL lanes of block A / B), each lane unpacks its FL lane's 32 values with
+// compile-time shifts from 4-byte loads, the values are scattered to their index(row,lane)
+// position in LDS (ds_write_b32, conflict-free) and read back linearly (ds_read_b128) so the
+// global stores are fully contiguous 1 KiB-per-instruction dwordx4.  Same XCD map, st18, maxw.
+template <int W, int AUX, int MAXW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, MAXW))) void k_unpack_waveblock(Args a, unsigned K)
+{
+    using T = uint32_t;
+    constexpr int BPW = 8;                       // 4 waves x 2 blocks
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4][2 * 1024];
+    const uint64_t b = blockIdx.x;
+    uint64_t wg = b;
+    if (K > 1) { const uint64_t span = 8ull * K; wg = (b / span) * span + (b % 8) * K + (b / 8) % K; }
+    const uint64_t n_wg = (a.n_blocks + BPW - 1) / BPW;
+    if (wg >= n_wg) return;
+    const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint64_t blk = wg * BPW + wave * 2 + (lane >> 5);
+    const unsigned l = lane & 31u;
+    if (blk < a.n_blocks) {
+        const uint32_t* pk = reinterpret_cast<const uint32_t*>(a.in) + blk * (uint64_t)(32 * W) + l;
+        uint32_t w[W];
+        static_for<W>([&](auto I) { w[decltype(I)::value] = pk[32 * decltype(I)::value]; });
+        uint32_t* dst = &lds[wave][(lane >> 5) * 1024];
+        static_for<32>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            constexpr int curr = r * W / 32, next = (r + 1) * W / 32, sh = r * W % 32;
+            uint32_t v;
+            if constexpr (next > curr && next < W && ((r + 1) * W % 32) > 0)
+                v = ((w[curr] >> sh) | (w[next] << (32 - sh))) & ((1u << W) - 1u);
+            else
+                v = (w[curr] >> sh) & ((1u << W) - 1u);
+            dst[fl_order(r / 8) * 16 + (r % 8) * 128 + l] = v;
+        });
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // 2 blocks x 4 KiB per wave = 8 x 1 KiB store instructions
+    u32x4* wave_out = a.out + (wg * BPW + wave * 2) * 256ull;
+    const uint64_t rem_blocks = a.n_blocks > wg * BPW + wave * 2 ? a.n_blocks - (wg * BPW + wave * 2) : 0;
+    auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)wave_out, 0, (unsigned)(rem_blocks < 2 ? rem_blocks : 2) * 4096, 0x00020000);
+    static_for<8>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(&lds[wave][(i * 64 + lane) * 4]);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, (i * 64 + lane) * 16, 0, AUX);
+    });
+}
+
 // plain streams with the same per-thread shape: RD cells read, WR cells written per thread
 template <int RD, int WR, bool NT>
 __global__ __launch_bounds__(256) void k_stream(const u32x4* in, u32x4* out, uint64_t n_threads, u32x4* sink)
@@ -233,12 +281,22 @@ int main(int argc, char** argv)
         if (K > 1) n_wg = (n_wg + 8ull * K - 1) / (8ull * K) * (8ull * K);
         vs.push_back({name, by, [=]() { hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), lds, 0, aa, K); }, {}});
     };
-    addX("unpack u32w7 base", k_unpack_x<uint32_t, 7, -1, -1>, 1, a, bytes, 0);
-    addX("G st18 maxw2 row-order", k_unpack_x<uint32_t, 7, 18, -1, 2, 0>, G, a, bytes, 0);
-    addX("G st18 maxw2 addr-order", k_unpack_x<uint32_t, 7, 18, -1, 2, 1>, G, a, bytes, 0);
-    addX("G st18 maxw3 row-order", k_unpack_x<uint32_t, 7, 18, -1, 3, 0>, G, a, bytes, 0);
-    addX("G st18 maxw3 addr-order", k_unpack_x<uint32_t, 7, 18, -1, 3, 1>, G, a, bytes, 0);
-    addX("G st18 maxw2 row-order (again)", k_unpack_x<uint32_t, 7, 18, -1, 2, 0>, G, a, bytes, 0);
+    addX("cell-column base (plain)", k_unpack_x<uint32_t, 7, -1, -1>, 1, a, bytes, 0);
+    addX("cell-column G st18 maxw2 addr-order", k_unpack_x<uint32_t, 7, 18, -1, 2, 1>, G, a, bytes, 0);
+    {
+        const uint64_t n_wg8 = (n + 7) / 8;
+        const unsigned G8 = (unsigned)((n_wg8 + 7) / 8);
+        auto addW = [&](const std::string& name, auto kern, unsigned K) {
+            uint64_t n_wg = n_wg8;
+            if (K > 1) n_wg = (n_wg + 8ull * K - 1) / (8ull * K) * (8ull * K);
+            vs.push_back({name, bytes, [=]() { hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), 0, 0, a, K); }, {}});
+        };
+        addW("wave-per-block+LDS plain K=1 maxw8", k_unpack_waveblock<7, 0, 8>, 1);
+        addW("wave-per-block+LDS G st18 maxw2", k_unpack_waveblock<7, 18, 2>, G8);
+        addW("wave-per-block+LDS G st18 maxw4", k_unpack_waveblock<7, 18, 4>, G8);
+        addW("wave-per-block+LDS G st18 maxw8", k_unpack_waveblock<7, 18, 8>, G8);
+    }
+    addX("cell-column G st18 maxw2 addr-order (again)", k_unpack_x<uint32_t, 7, 18, -1, 2, 1>, G, a, bytes, 0);
     const uint64_t n_thr = n * 8;
     auto addS = [&](const char* name, auto kern, double by) {
         vs.push_back({name, by, [=]() { hipLaunchKernelGGL(kern, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, 0, (const u32x4*)in, out, n_thr, sink); }, {}});
@@ -246,6 +304,27 @@ int main(int argc, char** argv)
     addS("stream 7rd:32wr nt", k_stream<7, 32, true>, bytes);
     addS("stream write-only 32", k_stream<0, 32, false>, (double)n * 4096);
 
+    // the two designs must produce identical bytes (checked on the first and last 16 blocks)
+    {
+        std::vector<uint32_t> ref(2 * 16 * 1024), alt(2 * 16 * 1024);
+        const uint64_t G_ = G;
+        auto grab = [&](std::vector<uint32_t>& h) {
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(h.data(), out, 16 * 4096, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(h.data() + 16 * 1024, (char*)out + (n - 16) * 4096, 16 * 4096, hipMemcpyDeviceToHost));
+        };
+        CK(hipMemset(out, 0xAB, n * 4096));
+        uint64_t n_wg = (n_wg0 + 8ull * G_ - 1) / (8ull * G_) * (8ull * G_);
+        hipLaunchKernelGGL((k_unpack_x<uint32_t, 7, 18, -1, 2, 1>), dim3((unsigned)n_wg), dim3(256), 0, 0, a, (unsigned)G_);
+        grab(ref);
+        CK(hipMemset(out, 0xCD, n * 4096));
+        const uint64_t n_wg8 = (n + 7) / 8;
+        const unsigned G8 = (unsigned)((n_wg8 + 7) / 8);
+        n_wg = (n_wg8 + 8ull * G8 - 1) / (8ull * G8) * (8ull * G8);
+        hipLaunchKernelGGL((k_unpack_waveblock<7, 18, 2>), dim3((unsigned)n_wg), dim3(256), 0, 0, a, G8);
+        grab(alt);
+        printf("wave-per-block+LDS output == cell-column output on sampled blocks: %s\n", ref == alt ? "yes" : "NO");
+    }
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (auto& v : vs) { v.launch(); }
