@@ -53,6 +53,12 @@ template <typename T> struct Abi;
         static constexpr auto undelta_pack = fl_##S##_undelta_pack;                                  \
         static constexpr auto transpose = fl_##S##_transpose;                                        \
         static constexpr auto untranspose = fl_##S##_untranspose;                                    \
+        static constexpr auto undelta_pack_untranspose = fl_##S##_undelta_pack_untranspose;          \
+        static constexpr auto transpose_delta_pack = fl_##S##_transpose_delta_pack;                  \
+        static constexpr auto unpack_block_sums = fl_##S##_unpack_block_sums;                        \
+        static constexpr auto block_min_max = fl_##S##_block_min_max;                                \
+        static constexpr auto unpack_mixed = fl_##S##_unpack_mixed;                                  \
+        static constexpr auto pack_mixed = fl_##S##_pack_mixed;                                      \
         static constexpr auto pack_host = fl_##S##_pack_host;                                        \
         static constexpr auto unpack_host = fl_##S##_unpack_host;                                    \
         static constexpr auto unpack_single_host = fl_##S##_unpack_single_host;                      \
@@ -127,6 +133,12 @@ template <typename T> struct BitPacking : FastLanes<T> {
     { detail::check(A::pack((unsigned)width, d_in, d_out, n_blocks, stream), "pack_device"); }
     static void unpack_device(std::size_t width, const T* d_in, T* d_out, std::size_t n_blocks, void* stream = nullptr)
     { detail::check(A::unpack((unsigned)width, d_in, d_out, n_blocks, stream), "unpack_device"); }
+    // extensions: reductions over what unpack / the unpacked block hold
+    static void unpack_block_sums_device(std::size_t width, const T* d_packed, std::size_t n_blocks, std::uint64_t* d_sums,
+                                         void* stream = nullptr)
+    { detail::check(A::unpack_block_sums((unsigned)width, d_packed, n_blocks, d_sums, stream), "unpack_block_sums_device"); }
+    static void block_min_max_device(const T* d_values, std::size_t n_blocks, T* d_mins, T* d_maxs, void* stream = nullptr)
+    { detail::check(A::block_min_max(d_values, n_blocks, d_mins, d_maxs, stream), "block_min_max_device"); }
     static void unpack_single_device(std::size_t width, const T* d_packed, std::size_t n_blocks, const std::uint64_t* d_indices,
                                      std::size_t n_indices, T* d_out, std::uint32_t* d_err, void* stream = nullptr)
     { detail::check(A::unpack_single((unsigned)width, d_packed, n_blocks, d_indices, n_indices, d_out, d_err, stream), "unpack_single_device"); }
@@ -176,6 +188,13 @@ template <typename T> struct Delta : BitPacking<T> {
     static void undelta_pack_device(std::size_t width, const T* d_in, const T* d_bases, T* d_out, std::size_t n_blocks,
                                     void* stream = nullptr)
     { detail::check(A::undelta_pack((unsigned)width, d_in, d_bases, d_out, n_blocks, stream), "undelta_pack_device"); }
+    // extensions: == untranspose(undelta_pack(..)) / pack(delta(transpose(..)))  (delta.rs:88-100)
+    static void undelta_pack_untranspose_device(std::size_t width, const T* d_in, const T* d_bases, T* d_out,
+                                                std::size_t n_blocks, void* stream = nullptr)
+    { detail::check(A::undelta_pack_untranspose((unsigned)width, d_in, d_bases, d_out, n_blocks, stream), "undelta_pack_untranspose_device"); }
+    static void transpose_delta_pack_device(std::size_t width, const T* d_in, const T* d_bases, T* d_out,
+                                            std::size_t n_blocks, void* stream = nullptr)
+    { detail::check(A::transpose_delta_pack((unsigned)width, d_in, d_bases, d_out, n_blocks, stream), "transpose_delta_pack_device"); }
 };
 
 // transpose.rs:4-7,29-36
@@ -193,6 +212,25 @@ template <typename T> struct Transpose : FastLanes<T> {
     { detail::check(A::transpose(d_in, d_out, n_blocks, stream), "transpose_device"); }
     static void untranspose_device(const T* d_in, T* d_out, std::size_t n_blocks, void* stream = nullptr)
     { detail::check(A::untranspose(d_in, d_out, n_blocks, stream), "untranspose_device"); }
+};
+
+// A column whose blocks each have their own width: the caller loop
+// `for b { T::unchecked_unpack(widths[b], ..) }` (bitpacking.rs:109-129) as one device call.
+template <typename T> class MixedWidthPlan {
+public:
+    MixedWidthPlan(const std::uint8_t* widths, std::size_t n_blocks)
+    { detail::check(fl_mixed_plan_create(sizeof(T) * 8, widths, n_blocks, &plan_), "fl_mixed_plan_create"); }
+    ~MixedWidthPlan() { fl_mixed_plan_destroy(plan_); }
+    MixedWidthPlan(const MixedWidthPlan&) = delete;
+    MixedWidthPlan& operator=(const MixedWidthPlan&) = delete;
+    std::size_t n_blocks() const { return fl_mixed_plan_n_blocks(plan_); }
+    std::uint64_t packed_bytes() const { return fl_mixed_plan_packed_bytes(plan_); }
+    void unpack_device(const T* d_packed, T* d_out, void* stream = nullptr) const
+    { detail::check(detail::Abi<T>::unpack_mixed(plan_, d_packed, d_out, stream), "unpack_mixed"); }
+    void pack_device(const T* d_in, T* d_packed, void* stream = nullptr) const
+    { detail::check(detail::Abi<T>::pack_mixed(plan_, d_in, d_packed, stream), "pack_mixed"); }
+private:
+    fl_mixed_plan* plan_ = nullptr;
 };
 
 }  // namespace fastlanes

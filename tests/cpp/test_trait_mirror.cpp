@@ -1,10 +1,13 @@
 // The reference's own unit tests, written against the C++ trait
 // mirror (include/fastlanes_amd.hpp) so they read like the Rust originals.  Needs a GPU
 // at run time (no CPU path exists); built on CPU as a compile/link check.
-//   g++ -std=c++17 -I include tests/cpp/test_trait_mirror.cpp -L fastlanes_amd -lfastlanes_amd
+//   g++ -std=c++17 -I include -I /opt/rocm/include tests/cpp/test_trait_mirror.cpp -L fastlanes_amd -lfastlanes_amd -L /opt/rocm/lib -lamdhip64
 #include <cstdio>
 #include <cstring>
 #include <vector>
+
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
 
 #include "fastlanes_amd.hpp"
 
@@ -123,6 +126,56 @@ static void test_wide_and_narrow()
     EXPECT(std::memcmp(v8, u8_, 1024) == 0);
 }
 
+// Device tier + extensions through the C++ mirror: the batched form of benches/bitpacking.rs:80-97,
+// fused Delta decode to original order, mixed widths.
+template <typename U> struct DevVec {
+    U* p = nullptr; size_t n;
+    explicit DevVec(size_t n_) : n(n_) { if (hipMalloc((void**)&p, n * sizeof(U)) != hipSuccess) throw std::runtime_error("hipMalloc"); }
+    ~DevVec() { (void)hipFree(p); }
+    void up(const std::vector<U>& h) { (void)hipMemcpy(p, h.data(), n * sizeof(U), hipMemcpyHostToDevice); }
+    std::vector<U> down() const { std::vector<U> h(n); (void)hipMemcpy(h.data(), p, n * sizeof(U), hipMemcpyDeviceToHost); return h; }
+};
+
+static void test_device_tier()
+{
+    const size_t N = 100;   // blocks
+    std::vector<uint32_t> v(N * 1024);
+    for (size_t i = 0; i < v.size(); ++i) v[i] = (uint32_t)((i * 2654435761ull) >> 7) & 0x7F;
+    DevVec<uint32_t> dv(N * 1024), dp(N * 224), du(N * 1024);
+    dv.up(v);
+    BitPacking<uint32_t>::pack_device(7, dv.p, dp.p, N);
+    BitPacking<uint32_t>::unpack_device(7, dp.p, du.p, N);
+    EXPECT(du.down() == v);
+    // per-block sums of the decoded values == sums of the originals
+    DevVec<uint64_t> ds(N);
+    BitPacking<uint32_t>::unpack_block_sums_device(7, dp.p, N, ds.p);
+    auto sums = ds.down();
+    for (size_t b = 0; b < N; ++b) { uint64_t s = 0; for (int i = 0; i < 1024; ++i) s += v[b * 1024 + i]; EXPECT(sums[b] == s); }
+    // fused encode/decode in the ORIGINAL order round-trips (W = 32: lossless for any data)
+    std::vector<uint32_t> bases(N * 32, 12345u);
+    DevVec<uint32_t> db(N * 32), de(N * 1024), dd(N * 1024);
+    db.up(bases);
+    Delta<uint32_t>::transpose_delta_pack_device(32, dv.p, db.p, de.p, N);
+    Delta<uint32_t>::undelta_pack_untranspose_device(32, de.p, db.p, dd.p, N);
+    EXPECT(dd.down() == v);
+    // == the three-step composition of the reference (delta.rs:88-95)
+    DevVec<uint32_t> dt(N * 1024), ddel(N * 1024), dpk(N * 1024);
+    Transpose<uint32_t>::transpose_device(dv.p, dt.p, N);
+    Delta<uint32_t>::delta_device(dt.p, db.p, ddel.p, N);
+    BitPacking<uint32_t>::pack_device(32, ddel.p, dpk.p, N);
+    EXPECT(dpk.down() == de.down());
+    // mixed widths: blocks alternate W = 7 and W = 9 (values fit both)
+    std::vector<uint8_t> widths(N);
+    for (size_t b = 0; b < N; ++b) widths[b] = (b % 2) ? 9 : 7;
+    MixedWidthPlan<uint32_t> plan(widths.data(), N);
+    EXPECT(plan.n_blocks() == N && plan.packed_bytes() == (N / 2) * 128 * (7 + 9));
+    DevVec<uint32_t> dm(plan.packed_bytes() / 4), dmu(N * 1024);
+    plan.pack_device(dv.p, dm.p);
+    plan.unpack_device(dm.p, dmu.p);
+    EXPECT(dmu.down() == v);
+    EXPECT(hipDeviceSynchronize() == hipSuccess);
+}
+
 int main()
 {
     try {
@@ -134,6 +187,7 @@ int main()
         test_ffor();
         test_panics();
         test_wide_and_narrow();
+        test_device_tier();
     } catch (const std::exception& e) {
         std::printf("EXCEPTION %s\n", e.what());
         return 2;

@@ -105,9 +105,11 @@ def build_cpp_test():
     src = exe + ".cpp"
     hdr = os.path.join(ROOT, "include", "fastlanes_amd.hpp")
     if not os.path.exists(exe) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(exe):
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), src,
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                               "-I", "/opt/rocm/include", src,
                                "-L", os.path.join(ROOT, "fastlanes_amd"), "-lfastlanes_amd",
-                               "-Wl,-rpath,$ORIGIN/../../fastlanes_amd", "-o", exe])
+                               "-L", "/opt/rocm/lib", "-lamdhip64",
+                               "-Wl,-rpath,$ORIGIN/../../fastlanes_amd", "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
     return exe
 
 
