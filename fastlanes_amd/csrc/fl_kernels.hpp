@@ -49,7 +49,8 @@ struct StreamArgs {
 constexpr int STORE_AUX = 18;   // nt (2) | sc1 (16)
 
 template <typename T, int W> struct UnpackPolicy {
-    static constexpr int MAXW = 2;
+    static constexpr int MAXW = 2;          // bodies that keep all T rows in registers, and the mixed path
+    static constexpr int MAXW_ROWS = 3;     // stateless row-at-a-time bodies (store / FoR)
     static constexpr bool NT_LOAD = (2 * W >= Elem<T>::BITS);
 };
 template <typename T> struct PackPolicy {
@@ -83,53 +84,133 @@ template <int BLOCK_BYTES> struct TileStore {
     }
 };
 
+// Wave-contiguous streaming stores for whole unpacked rows.  The cell-column mapping gives a
+// store instruction 8 x 128 B (one line of each of the wave's 8 blocks, 4 KiB apart).  Staging
+// 8 address-rows of every block (8 KiB per wave) through LDS turns that into 8 instructions
+// of 1 KiB CONTIGUOUS bytes each (one block per instruction): +1.7..3.4 % on u32 W=7 and a
+// smaller spread between boxes (profiles/abbench_r01k.txt).  ds_write_b128 / ds_read_b128 are
+// both conflict-free (8 lanes x 16 B = one 128-byte row; 64 lanes x 16 B = 1 KiB linear); the
+// exchange is wave-local, so it needs no s_barrier.
+template <typename T> struct WaveRowStore {
+    static constexpr unsigned BLOCK_BYTES = Elem<T>::CELLS_PER_BLOCK * 16;
+    static constexpr int GROUPS = Elem<T>::BITS / 8;       // groups of 8 address-rows (1 KiB per block)
+    static constexpr int WAVE_LDS = 8 * 1024;
+    __amdgpu_buffer_rsrc_t rs;
+    char* lds;
+    unsigned lane;
+    __device__ __forceinline__ WaveRowStore(u32x4* out, uint64_t first_blk, uint64_t n_blocks, char* wave_lds, unsigned lane_)
+    {
+        const uint64_t rem = n_blocks - first_blk;
+        rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(out) + first_blk * BLOCK_BYTES, 0,
+                                               (unsigned)(rem < 8 ? rem : 8) * BLOCK_BYTES, 0x00020000);
+        lds = wave_lds;
+        lane = lane_;
+    }
+    // address-row j of this thread's block (j = 8*group + i): cell of column c
+    template <int I> __device__ __forceinline__ void put(const Cell<T>& v) const
+    {
+        *reinterpret_cast<u32x4*>(lds + (lane >> 3) * 1024 + I * 128 + (lane & 7u) * 16) = __builtin_bit_cast(u32x4, v);
+    }
+    template <int GROUP> __device__ __forceinline__ void flush() const
+    {
+        wave_lds_fence();
+        static_for<8>([&](auto B) {
+            constexpr int b = decltype(B)::value;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(lds + b * 1024 + lane * 16);
+            // blocks past the end of the column fall outside the descriptor and are dropped
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, b * BLOCK_BYTES + GROUP * 1024 + lane * 16, 0, STORE_AUX);
+        });
+        wave_lds_fence();
+    }
+    // logical row stored at address-row j
+    __host__ __device__ static constexpr int row_at(int j)
+    {
+        constexpr int PER_S = Elem<T>::BITS / 8;
+        return fl_order((j % PER_S) * (8 / PER_S)) * 8 + j / PER_S;
+    }
+};
+
 // unpack / unfor_pack / undelta_pack  (bitpacking.rs:98-107, ffor.rs:38-50,
 // delta.rs:47-63): packed W cell-rows -> T cell-rows.
 template <typename T, int W, int BODY>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, UnpackPolicy<T, W>::MAXW)))
+__global__ __launch_bounds__(WG)
+__attribute__((amdgpu_waves_per_eu(1, (BODY == BODY_STORE || BODY == BODY_ADD_REF) ? UnpackPolicy<T, W>::MAXW_ROWS
+                                                                                    : UnpackPolicy<T, W>::MAXW)))
 void k_unpack(StreamArgs a)
 {
     constexpr bool NTL = UnpackPolicy<T, W>::NT_LOAD;
+    constexpr int TB = Elem<T>::BITS;
     uint64_t tile;
     if (!tile_of_workgroup(a, tile)) return;
     const unsigned tid = threadIdx.x;
-    const uint64_t blk = tile * BLOCKS_PER_WG + (tid >> 3);
     const unsigned c = tid & 7u;
-    if (blk >= a.n_blocks) return;
 
-    Cell<T> in[W ? W : 1];
-    const u32x4* pk = a.in + blk * (uint64_t)(8 * W) + c;
-    static_for<W>([&](auto Wd) { in[decltype(Wd)::value] = load_cell<T, NTL>(pk + 8 * decltype(Wd)::value); });
-
-    const TileStore<Elem<T>::CELLS_PER_BLOCK * 16> st(a.out, tile, a.n_blocks, tid);
-    if constexpr (BODY == BODY_STORE) {
-        unpack_rows_by_address<T, W>(in, [&](auto R, const Cell<T>& v) {
-            st.store(Elem<T>::row_cell(decltype(R)::value), v);                 // bitpacking.rs:103-105
-        });
-    } else if constexpr (BODY == BODY_ADD_REF) {
-        const T* refs = static_cast<const T*>(a.aux);
-        const Cell<T> ref = Cell<T>::splat(refs[blk * a.aux_stride]);
-        unpack_rows_by_address<T, W>(in, [&](auto R, const Cell<T>& v) {
-            st.store(Elem<T>::row_cell(decltype(R)::value), v.add(ref));        // ffor.rs:46-48
-        });
-    } else if constexpr (BODY == BODY_UNDELTA) {
-        // base[lane] for this column's lanes = cell c of the block's 128-byte base row
-        const u32x4* bases = static_cast<const u32x4*>(a.aux);
-        Cell<T> prev = load_cell<T, false>(bases + blk * 8 + c);                // delta.rs:56
-        unpack_rows<T, W>(in, [&](auto R, const Cell<T>& v) {
-            prev = v.add(prev);                                                 // delta.rs:58-60
-            st.store(Elem<T>::row_cell(decltype(R)::value), prev);
-        });
-    } else {
+    if constexpr (BODY == BODY_UNDELTA_UNTRANSPOSE) {
+        const uint64_t blk = tile * BLOCKS_PER_WG + (tid >> 3);
+        if (blk >= a.n_blocks) return;
+        Cell<T> in[W ? W : 1];
+        const u32x4* pk = a.in + blk * (uint64_t)(8 * W) + c;
+        static_for<W>([&](auto Wd) { in[decltype(Wd)::value] = load_cell<T, NTL>(pk + 8 * decltype(Wd)::value); });
+        const TileStore<Elem<T>::CELLS_PER_BLOCK * 16> st(a.out, tile, a.n_blocks, tid);
         const u32x4* bases = static_cast<const u32x4*>(a.aux);
         Cell<T> prev = load_cell<T, false>(bases + blk * 8 + c);
-        Cell<T> rows[Elem<T>::BITS];
+        Cell<T> rows[TB];
         unpack_rows<T, W>(in, [&](auto R, const Cell<T>& v) {
             prev = v.add(prev);
             rows[decltype(R)::value] = prev;
         });
         __shared__ __attribute__((aligned(16))) char lds[(WG / 64) * RunExchange<T>::WAVE_BYTES];
         store_lane_runs_lines<T>(lds + (tid >> 3) * RunExchange<T>::BLOCK_BYTES, c, rows, st);
+    } else {
+        // rows leave through the wave-contiguous LDS staging: every lane takes part in the stores of
+        // all 8 blocks of its wavefront, so only whole wavefronts past the end may leave early
+        using WS = WaveRowStore<T>;
+        __shared__ __attribute__((aligned(16))) char lds[(WG / 64) * WS::WAVE_LDS];
+        const unsigned wave = tid >> 6, lane = tid & 63u;
+        const uint64_t first_blk = tile * BLOCKS_PER_WG + wave * 8;
+        if (first_blk >= a.n_blocks) return;
+        const uint64_t blk = first_blk + (lane >> 3);
+        const bool valid = blk < a.n_blocks;
+        Cell<T> in[W ? W : 1];
+        static_for<(W ? W : 1)>([&](auto Wd) { in[decltype(Wd)::value] = Cell<T>::zero(); });
+        if (valid) {
+            const u32x4* pk = a.in + blk * (uint64_t)(8 * W) + c;
+            static_for<W>([&](auto Wd) { in[decltype(Wd)::value] = load_cell<T, NTL>(pk + 8 * decltype(Wd)::value); });
+        }
+        const WS ws(a.out, first_blk, a.n_blocks, lds + wave * WS::WAVE_LDS, lane);
+        if constexpr (BODY == BODY_STORE || BODY == BODY_ADD_REF) {
+            Cell<T> ref = Cell<T>::zero();
+            if constexpr (BODY == BODY_ADD_REF) {
+                if (valid) ref = Cell<T>::splat(static_cast<const T*>(a.aux)[blk * a.aux_stride]);
+            }
+            // stateless bodies: rows are produced directly in ascending address order (the reference
+            // visits them in row order only "in case the kernel has side effects", macros.rs:119)
+            static_for<WS::GROUPS>([&](auto G) {
+                constexpr int grp = decltype(G)::value;
+                static_for<8>([&](auto I) {
+                    constexpr int row = WS::row_at(8 * grp + decltype(I)::value);
+                    const Cell<T> v = unpack_row<T, W, row>(in);
+                    if constexpr (BODY == BODY_ADD_REF) ws.template put<decltype(I)::value>(v.add(ref));   // ffor.rs:46-48
+                    else ws.template put<decltype(I)::value>(v);                                          // bitpacking.rs:103-105
+                });
+                ws.template flush<grp>();
+            });
+        } else {
+            // undelta_pack: the per-lane running sum needs row order (delta.rs:56-61); all T rows are
+            // kept in registers and leave in address order afterwards
+            Cell<T> prev = Cell<T>::zero();
+            if (valid) prev = load_cell<T, false>(static_cast<const u32x4*>(a.aux) + blk * 8 + c);   // delta.rs:56
+            Cell<T> rows[TB];
+            unpack_rows<T, W>(in, [&](auto R, const Cell<T>& v) {
+                prev = v.add(prev);                                                                  // delta.rs:58-60
+                rows[decltype(R)::value] = prev;
+            });
+            static_for<WS::GROUPS>([&](auto G) {
+                constexpr int grp = decltype(G)::value;
+                static_for<8>([&](auto I) { ws.template put<decltype(I)::value>(rows[WS::row_at(8 * grp + decltype(I)::value)]); });
+                ws.template flush<grp>();
+            });
+        }
     }
 }
 

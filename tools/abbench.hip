@@ -183,6 +183,57 @@ __global__ __launch_bounds__(256) void k_unpack_p(Args a, unsigned wgs_per_xcd)
     }
 }
 
+// cell-column compute + LDS-staged WAVE-CONTIGUOUS stores: every group of 8 address-rows
+// (1 KiB per block) goes through LDS so that each store instruction writes 1 KiB contiguous
+// bytes of ONE block (as the wave-per-block sketch does) instead of 8 x 128 B at 4 KiB stride.
+template <typename T, int W, int AUX, int MAXW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, MAXW))) void k_unpack_cc_wavestore(Args a, unsigned K)
+{
+    constexpr int BPW = 32;
+    constexpr int TB = Elem<T>::BITS;
+    constexpr int GROUPS = TB / 8;                         // 1 KiB per block per group
+    __shared__ __attribute__((aligned(16))) char lds[4][8 * 1024];
+    const uint64_t n_wg = (a.n_blocks + BPW - 1) / BPW;
+    const uint64_t b = blockIdx.x;
+    uint64_t wg = b;
+    if (K > 1) { const uint64_t span = 8ull * K; wg = (b / span) * span + (b % 8) * K + (b / 8) % K; }
+    if (wg >= n_wg) return;
+    const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const unsigned g = lane >> 3, c = lane & 7u;
+    const uint64_t blk = wg * BPW + wave * 8 + g;
+    Cell<T> in[W];
+    if (blk < a.n_blocks) {
+        const u32x4* pk = a.in + blk * (uint64_t)(8 * W) + c;
+        static_for<W>([&](auto Wd) { in[decltype(Wd)::value] = load_cell<T, false>(pk + 8 * decltype(Wd)::value); });
+    }
+    // the wave's 8 blocks are one contiguous 8*BLOCK_BYTES region
+    constexpr unsigned BLOCK_BYTES = Elem<T>::CELLS_PER_BLOCK * 16;
+    const uint64_t first_blk = wg * BPW + wave * 8;
+    const uint64_t rem = a.n_blocks > first_blk ? a.n_blocks - first_blk : 0;
+    auto rs = __builtin_amdgcn_make_buffer_rsrc((char*)a.out + first_blk * BLOCK_BYTES, 0,
+                                                (unsigned)(rem < 8 ? rem : 8) * BLOCK_BYTES, 0x00020000);
+    char* my = &lds[wave][0];
+    constexpr int PER_S = TB / 8;
+    static_for<GROUPS>([&](auto KK) {
+        constexpr int k = decltype(KK)::value;
+        static_for<8>([&](auto I) {
+            constexpr int j = 8 * k + decltype(I)::value;                     // address-row
+            constexpr int row = fl_order((j % PER_S) * (8 / PER_S)) * 8 + j / PER_S;
+            const Cell<T> v = unpack_row<T, W, row>(in);
+            *reinterpret_cast<u32x4*>(my + g * 1024 + decltype(I)::value * 128 + c * 16) = __builtin_bit_cast(u32x4, v);
+        });
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        static_for<8>([&](auto B) {
+            constexpr int bb = decltype(B)::value;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(my + bb * 1024 + lane * 16);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, bb * BLOCK_BYTES + k * 1024 + lane * 16, 0, AUX);
+        });
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    });
+}
+
 // The north_star sketch, for the record: a wavefront owns whole blocks (here 2: lanes 0-31 /
 // 32-63 = the 32 FL lanes of block A / B), each lane unpacks its FL lane's 32 values with
 // compile-time shifts from 4-byte loads, the values are scattered to their index(row,lane)
@@ -256,6 +307,26 @@ __global__ __launch_bounds__(256) void k_stream(const u32x4* in, u32x4* out, uin
 
 __global__ void k_fill(uint64_t* p, uint64_t n);
 
+// tuned plain streams: XCD-contiguous tiles, sc1|nt buffer stores, waves/SIMD cap -- the ceiling of
+// the memory system for a given read:write mix under the same policy as the product kernels
+template <int RD, int WR, int MAXW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, MAXW)))
+void k_stream_tuned(const u32x4* in, u32x4* out, uint64_t n_tiles, uint64_t tiles_per_xcd, u32x4* sink)
+{
+    const uint64_t tile = (uint64_t)(blockIdx.x & 7u) * tiles_per_xcd + (blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
+    const unsigned tid = threadIdx.x;
+    u32x4 acc = {0, 0, 0, 0};
+    const u32x4* src = in + tile * (uint64_t)(256 * RD);
+#pragma unroll
+    for (int i = 0; i < RD; ++i) acc += src[i * 256 + tid];
+    if constexpr (WR > 0) {
+        auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(out + tile * (uint64_t)(256 * WR)), 0, 256 * WR * 16, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < WR; ++i) __builtin_amdgcn_raw_buffer_store_b128(acc + (unsigned)i, rs, (i * 256 + tid) * 16, 0, 18);
+    } else if (acc.x == 0x12345678u) *sink = acc;
+}
+
 struct Variant { std::string name; double bytes; std::function<void()> launch; std::vector<float> ms; };
 
 int main(int argc, char** argv)
@@ -296,11 +367,34 @@ int main(int argc, char** argv)
         addW("wave-per-block+LDS G st18 maxw4", k_unpack_waveblock<7, 18, 4>, G8);
         addW("wave-per-block+LDS G st18 maxw8", k_unpack_waveblock<7, 18, 8>, G8);
     }
+    addX("cell-column + LDS wave-contig stores maxw2", k_unpack_cc_wavestore<uint32_t, 7, 18, 2>, G, a, bytes, 0);
+    addX("cell-column + LDS wave-contig stores maxw3", k_unpack_cc_wavestore<uint32_t, 7, 18, 3>, G, a, bytes, 0);
     addX("cell-column G st18 maxw2 addr-order (again)", k_unpack_x<uint32_t, 7, 18, -1, 2, 1>, G, a, bytes, 0);
     const uint64_t n_thr = n * 8;
     auto addS = [&](const char* name, auto kern, double by) {
         vs.push_back({name, by, [=]() { hipLaunchKernelGGL(kern, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, 0, (const u32x4*)in, out, n_thr, sink); }, {}});
     };
+    {
+        const uint64_t n_tiles = n / 32;   // a tile = 256 threads x (RD+WR) cells = 32 blocks' worth
+        const uint64_t tpx = (n_tiles + 7) / 8;
+        auto addT = [&](const char* name, auto kern, double by) {
+            vs.push_back({name, by, [=]() { hipLaunchKernelGGL(kern, dim3((unsigned)(tpx * 8)), dim3(256), 0, 0, (const u32x4*)in, out, n_tiles, tpx, sink); }, {}});
+        };
+        addT("tuned stream 7rd:32wr maxw2", k_stream_tuned<7, 32, 2>, (double)n_tiles * 32 * 4992);
+        addT("tuned stream 7rd:32wr maxw4", k_stream_tuned<7, 32, 4>, (double)n_tiles * 32 * 4992);
+        addT("tuned stream write-only 32 maxw2", k_stream_tuned<0, 32, 2>, (double)n_tiles * 32 * 4096);
+        addT("tuned stream write-only 32 maxw8", k_stream_tuned<0, 32, 8>, (double)n_tiles * 32 * 4096);
+        addT("tuned stream read-only 7 maxw2", k_stream_tuned<7, 0, 2>, (double)n_tiles * 32 * 896);
+        addT("tuned stream read-only 7 maxw8", k_stream_tuned<7, 0, 8>, (double)n_tiles * 32 * 896);
+        // read-heavy mixes read the big buffer (`out`, 4096 B/block) and write the small one (`in`)
+        auto addR = [&](const char* name, auto kern, double by) {
+            vs.push_back({name, by, [=]() { hipLaunchKernelGGL(kern, dim3((unsigned)(tpx * 8)), dim3(256), 0, 0, (const u32x4*)out, in, n_tiles, tpx, sink); }, {}});
+        };
+        addR("tuned stream read-only 32 maxw1", k_stream_tuned<32, 0, 1>, (double)n_tiles * 32 * 4096);
+        addR("tuned stream read-only 32 maxw2", k_stream_tuned<32, 0, 2>, (double)n_tiles * 32 * 4096);
+        addR("tuned stream 32rd:7wr maxw1", k_stream_tuned<32, 7, 1>, (double)n_tiles * 32 * 4992);
+        addR("tuned stream 32rd:7wr maxw2", k_stream_tuned<32, 7, 2>, (double)n_tiles * 32 * 4992);
+    }
     addS("stream 7rd:32wr nt", k_stream<7, 32, true>, bytes);
     addS("stream write-only 32", k_stream<0, 32, false>, (double)n * 4096);
 
@@ -324,6 +418,11 @@ int main(int argc, char** argv)
         hipLaunchKernelGGL((k_unpack_waveblock<7, 18, 2>), dim3((unsigned)n_wg), dim3(256), 0, 0, a, G8);
         grab(alt);
         printf("wave-per-block+LDS output == cell-column output on sampled blocks: %s\n", ref == alt ? "yes" : "NO");
+        CK(hipMemset(out, 0xEF, n * 4096));
+        n_wg = (n_wg0 + 8ull * G_ - 1) / (8ull * G_) * (8ull * G_);
+        hipLaunchKernelGGL((k_unpack_cc_wavestore<uint32_t, 7, 18, 2>), dim3((unsigned)n_wg), dim3(256), 0, 0, a, (unsigned)G_);
+        grab(alt);
+        printf("cell-column + LDS wave-contig stores output == cell-column output: %s\n", ref == alt ? "yes" : "NO");
     }
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
