@@ -265,28 +265,42 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, PackPolic
 void k_delta(StreamArgs a)
 {
     constexpr int TB = Elem<T>::BITS;
+    using WS = WaveRowStore<T>;
+    __shared__ __attribute__((aligned(16))) char lds[(WG / 64) * WS::WAVE_LDS];
     uint64_t tile;
     if (!tile_of_workgroup(a, tile)) return;
     const unsigned tid = threadIdx.x;
-    const uint64_t blk = tile * BLOCKS_PER_WG + (tid >> 3);
-    const unsigned c = tid & 7u;
-    if (blk >= a.n_blocks) return;
-    const u32x4* src = a.in + blk * (uint64_t)Elem<T>::CELLS_PER_BLOCK + c;
-    Cell<T> prev = load_cell<T, false>(static_cast<const u32x4*>(a.aux) + blk * 8 + c);
+    const unsigned wave = tid >> 6, lane = tid & 63u, c = tid & 7u;
+    const uint64_t first_blk = tile * BLOCKS_PER_WG + wave * 8;
+    if (first_blk >= a.n_blocks) return;                       // whole wavefront past the end
+    const uint64_t blk = first_blk + (lane >> 3);
+    const bool valid = blk < a.n_blocks;
     Cell<T> rows[TB];
-    static_for<TB>([&](auto R) {
-        rows[decltype(R)::value] = load_cell<T, true>(src + Elem<T>::row_cell(decltype(R)::value));
-    });
-    const TileStore<Elem<T>::CELLS_PER_BLOCK * 16> st(a.out, tile, a.n_blocks, tid);
+    Cell<T> prev = Cell<T>::zero();
+    static_for<TB>([&](auto R) { rows[decltype(R)::value] = Cell<T>::zero(); });
+    if (valid) {
+        const u32x4* src = a.in + blk * (uint64_t)Elem<T>::CELLS_PER_BLOCK + c;
+        prev = load_cell<T, false>(static_cast<const u32x4*>(a.aux) + blk * 8 + c);
+        static_for<TB>([&](auto R) {
+            rows[decltype(R)::value] = load_cell<T, true>(src + Elem<T>::row_cell(decltype(R)::value));
+        });
+    }
     static_for<TB>([&](auto R) {
         constexpr int row = decltype(R)::value;
         if constexpr (INVERSE) {
             prev = rows[row].add(prev);                                         // delta.rs:40-42
-            st.store(Elem<T>::row_cell(row), prev);
+            rows[row] = prev;
         } else {
-            st.store(Elem<T>::row_cell(row), rows[row].sub(prev));              // delta.rs:28-30
-            prev = rows[row];
+            const Cell<T> next = rows[row];
+            rows[row] = next.sub(prev);                                         // delta.rs:28-30
+            prev = next;
         }
+    });
+    const WS ws(a.out, first_blk, a.n_blocks, lds + wave * WS::WAVE_LDS, lane);
+    static_for<WS::GROUPS>([&](auto G) {
+        constexpr int grp = decltype(G)::value;
+        static_for<8>([&](auto I) { ws.template put<decltype(I)::value>(rows[WS::row_at(8 * grp + decltype(I)::value)]); });
+        ws.template flush<grp>();
     });
 }
 

@@ -26,22 +26,31 @@ void k_transpose(StreamArgs a)
     uint64_t tile;
     if (!tile_of_workgroup(a, tile)) return;
     const unsigned tid = threadIdx.x;
-    const uint64_t blk = tile * BLOCKS_PER_WG + (tid >> 3);
-    const unsigned c = tid & 7u;
-    if (blk >= a.n_blocks) return;
-    const char* in_blk = reinterpret_cast<const char*>(a.in) + blk * (uint64_t)(1024 * sizeof(T));
-    char* out_blk = reinterpret_cast<char*>(a.out) + blk * (uint64_t)(1024 * sizeof(T));
+    const unsigned wave = tid >> 6, lane = tid & 63u, c = tid & 7u;
+    const uint64_t first_blk = tile * BLOCKS_PER_WG + wave * 8;
+    if (first_blk >= a.n_blocks) return;                       // whole wavefront past the end
+    const uint64_t blk = first_blk + (lane >> 3);
+    const bool valid = blk < a.n_blocks;
     Cell<T> rows[TB];
     if constexpr (!INVERSE) {
         // original order -> transposed: out[index(r,l)] = in[lane_base(l) + r]   (transpose.rs:12-14)
         __shared__ __attribute__((aligned(16))) char lds_in[(WG / 64) * RunExchange<T>::WAVE_BYTES];
-        load_lane_runs_lines<T>(lds_in + (tid >> 3) * RunExchange<T>::BLOCK_BYTES, c,
-                                reinterpret_cast<const u32x4*>(in_blk), rows);
-        const TileStore<Elem<T>::CELLS_PER_BLOCK * 16> st(a.out, tile, a.n_blocks, tid);
-        static_for<TB>([&](auto R) { st.store(Elem<T>::row_cell(decltype(R)::value), rows[decltype(R)::value]); });
+        using WS = WaveRowStore<T>;
+        __shared__ __attribute__((aligned(16))) char lds_out[(WG / 64) * WS::WAVE_LDS];
+        static_for<TB>([&](auto R) { rows[decltype(R)::value] = Cell<T>::zero(); });
+        if (valid)
+            load_lane_runs_lines<T>(lds_in + (tid >> 3) * RunExchange<T>::BLOCK_BYTES, c,
+                                    a.in + blk * (uint64_t)Elem<T>::CELLS_PER_BLOCK, rows);
+        const WS ws(a.out, first_blk, a.n_blocks, lds_out + wave * WS::WAVE_LDS, lane);
+        static_for<WS::GROUPS>([&](auto G) {
+            constexpr int grp = decltype(G)::value;
+            static_for<8>([&](auto I) { ws.template put<decltype(I)::value>(rows[WS::row_at(8 * grp + decltype(I)::value)]); });
+            ws.template flush<grp>();
+        });
     } else {
         // transposed -> original order: out[lane_base(l) + r] = in[index(r,l)]   (transpose.rs:19-21)
-        const u32x4* src = reinterpret_cast<const u32x4*>(in_blk) + c;
+        if (!valid) return;                                    // per-block exchange only
+        const u32x4* src = a.in + blk * (uint64_t)Elem<T>::CELLS_PER_BLOCK + c;
         static_for<TB>([&](auto R) {
             rows[decltype(R)::value] = load_cell<T, true>(src + Elem<T>::row_cell(decltype(R)::value));
         });
