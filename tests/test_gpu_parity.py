@@ -521,3 +521,83 @@ def test_mixed_plan_sparse_bucket_uses_fallback_stores(fl, oracle):
         pk = to_np(col[off[b]:off[b] + 16 * w], "u64")
         assert np.array_equal(to_np(out[b * 1024:(b + 1) * 1024], "u64"), oracle.unpack("u64", w, pk)), b
     plan.close()
+
+
+@pytest.mark.parametrize("ty", TYS)
+def test_no_write_past_the_end_of_the_column(fl, ty):
+    """Partial wavefronts rely on the buffer descriptor's bounds check to drop the stores of
+    blocks past the end: a guard region right behind every output must stay untouched."""
+    import torch
+    T = tbits(ty)
+    tdt = {"u8": torch.uint8, "u16": torch.uint16, "u32": torch.uint32, "u64": torch.uint64}[ty]
+    esz = T // 8
+    GUARD = 64 * 1024  # bytes
+
+    def guarded(n_elems):
+        big = torch.full((n_elems * esz + GUARD,), 0xA5, dtype=torch.uint8, device="cuda:0")
+        return big, big[:n_elems * esz].view(tdt)
+
+    for n in (1, 5, 9, 37, 263):
+        w = max(1, T // 3)
+        pk = to_dev(values(ty, n * packed_len(ty, w), 600 + n))
+        v = to_dev(values(ty, n * 1024, 601 + n))
+        bases = to_dev(values(ty, n * lanes(ty), 602 + n))
+        refs = to_dev(values(ty, n, 603 + n))
+        plan = fl.MixedWidthPlan(ty, np.full(n, w, dtype=np.uint8))
+        calls = [
+            (n * 1024, lambda o: fl.BitPacking.unpack(w, pk, output=o)),
+            (n * 1024, lambda o: fl.FoR.unfor_pack(w, pk, refs, output=o)),
+            (n * 1024, lambda o: fl.Delta.undelta_pack(w, pk, bases, output=o)),
+            (n * 1024, lambda o: fl.Delta.undelta_pack_untranspose(w, pk, bases, output=o)),
+            (n * 1024, lambda o: fl.Delta.delta(v, bases, output=o)),
+            (n * 1024, lambda o: fl.Delta.undelta(v, bases, output=o)),
+            (n * 1024, lambda o: fl.Transpose.transpose(v, output=o)),
+            (n * 1024, lambda o: fl.Transpose.untranspose(v, output=o)),
+            (n * packed_len(ty, w), lambda o: fl.BitPacking.pack(w, v, output=o)),
+            (n * packed_len(ty, w), lambda o: fl.FoR.for_pack(w, v, refs, output=o)),
+            (n * packed_len(ty, w), lambda o: fl.Delta.transpose_delta_pack(w, v, bases, output=o)),
+            (n * 1024, lambda o: plan.unpack(pk, output=o)),
+            (n * packed_len(ty, w), lambda o: plan.pack(v, output=o)),
+        ]
+        for k, (n_elems, call) in enumerate(calls):
+            big, out = guarded(n_elems)
+            call(out)
+            torch.cuda.synchronize()
+            assert bool((big[n_elems * esz:] == 0xA5).all()), (ty, n, k)
+        plan.close()
+
+
+def test_random_shapes_fuzz(fl, oracle):
+    """Seeded fuzz over (type, width, op, block count): tail handling of tiles / wavefronts."""
+    rng = np.random.default_rng(2024)
+    ops = ["pack", "unpack", "for_pack", "unfor_pack", "undelta_pack", "delta", "undelta", "transpose", "untranspose"]
+    for _ in range(60):
+        ty = TYS[rng.integers(0, 4)]
+        T = tbits(ty)
+        w = int(rng.integers(0, T + 1))
+        n = int(rng.choice([1, 2, 7, 8, 9, 31, 32, 33, 63, 64, 65, 255, 256, 257, 300, 511, 777]))
+        op = ops[rng.integers(0, len(ops))]
+        seed = int(rng.integers(0, 1 << 30))
+        v = values(ty, n * 1024, seed)
+        pk = values(ty, n * packed_len(ty, w), seed + 1)
+        refs = values(ty, n, seed + 2)
+        bases = values(ty, n * lanes(ty), seed + 3)
+        if op == "pack":
+            got, want = fl.BitPacking.pack(w, to_dev(v)), oracle.batch("pack", ty, w, v)
+        elif op == "unpack":
+            got, want = fl.BitPacking.unpack(w, to_dev(pk), n_blocks=n), oracle.batch("unpack", ty, w, pk, n_blocks=n)
+        elif op == "for_pack":
+            got, want = fl.FoR.for_pack(w, to_dev(v), to_dev(refs)), oracle.batch("for_pack", ty, w, v, aux=refs)
+        elif op == "unfor_pack":
+            got = fl.FoR.unfor_pack(w, to_dev(pk), to_dev(refs), n_blocks=n)
+            want = oracle.batch("unfor_pack", ty, w, pk, aux=refs, n_blocks=n)
+        elif op == "undelta_pack":
+            got = fl.Delta.undelta_pack(w, to_dev(pk), to_dev(bases))
+            want = oracle.batch("undelta_pack", ty, w, pk, aux=bases, n_blocks=n)
+        elif op in ("delta", "undelta"):
+            got = getattr(fl.Delta, op)(to_dev(v), to_dev(bases))
+            want = oracle.batch(op, ty, None, v, aux=bases)
+        else:
+            got = getattr(fl.Transpose, op)(to_dev(v))
+            want = oracle.batch(op, ty, None, v)
+        assert np.array_equal(to_np(got, ty), want), (ty, w, op, n, seed)
