@@ -37,6 +37,7 @@ def _signatures(ty):
         "transpose_delta_pack": [_U, _P, _P, _P, _Z, _P],
         "unpack_block_sums": [_U, _P, _Z, _P, _P],
         "block_min_max": [_P, _Z, _P, _P, _P],
+        "unpack_compare": [_U, _P, ctypes.c_int, c, _Z, _P, _P],
         "unpack_mixed": [_P, _P, _P, _P],
         "pack_mixed": [_P, _P, _P, _P],
     }

@@ -229,6 +229,30 @@ class BitPacking:
                    f"fl_{ty}_unpack_block_sums")
         return out
 
+    CMP = {"==": 0, "!=": 1, "<": 2, "<=": 3, ">": 4, ">=": 5}
+
+    @staticmethod
+    def unpack_compare(width, packed, op, constant, n_blocks=None):
+        """Selection mask straight from packed data: bit i of block b's 1024-bit mask =
+        (BitPacking.unpack(width, block b)[i] <op> constant), op in '==','!=','<','<=','>','>='.
+        Device tier only; returns a CUDA int32 tensor of 32 words per block (bit i of word i//32,
+        LSB first)."""
+        import torch
+        src = _Arg(packed)
+        ty = src.ty
+        if width > _lib.BITS[ty]:
+            raise FastLanesError(1, f"fl_{ty}_unpack_compare")
+        n = _blocks(src.n, packed_len(ty, width), "unpack_compare input")
+        if n is None:
+            n = n_blocks or 0
+        out = torch.empty(n * 32, dtype=torch.int32, device=src.x.device)
+        k = _lib.CTYPE[ty](int(constant) & ((1 << _lib.BITS[ty]) - 1))
+        with torch.cuda.device(src.x.device):
+            _check(getattr(_lib.load(), f"fl_{ty}_unpack_compare")(width, src.ptr, BitPacking.CMP[op], k, n,
+                                                                   out.data_ptr(), _stream(src)),
+                   f"fl_{ty}_unpack_compare")
+        return out
+
     @staticmethod
     def block_min_max(values):
         """(mins, maxs) per 1024-value block of an unpacked column.  Device tier only."""

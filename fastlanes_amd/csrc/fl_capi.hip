@@ -99,6 +99,39 @@ int dev_unpack_block_sums(unsigned w, const T* in, size_t n, uint64_t* sums, voi
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
 template <typename T>
+int dev_unpack_compare(unsigned w, const T* in, int op, T constant, size_t n, uint32_t* mask, void* s)
+{
+    if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
+    if (op < FL_CMP_EQ || op > FL_CMP_GE) return FL_ERR_INDEX;
+    if (n == 0) return FL_OK;
+    if (!mask || (w != 0 && !in)) return FL_ERR_NULL;
+    if (misaligned(in) || misaligned(mask)) return FL_ERR_ALIGN;
+    // reduce the six predicates to  x == k  /  x <= k  plus a complement
+    const T MAXV = (T) ~(T)0;
+    CompareArgs a;
+    a.in = reinterpret_cast<const u32x4*>(in);
+    a.mask = reinterpret_cast<u32x4*>(mask);
+    a.n_blocks = n;
+    a.tiles_per_xcd = 0;
+    a.is_eq = 0;
+    a.invert = 0;
+    a.constant = constant;
+    switch (op) {
+    case FL_CMP_EQ: a.is_eq = 1; break;
+    case FL_CMP_NE: a.is_eq = 1; a.invert = 1; break;
+    case FL_CMP_LE: break;
+    case FL_CMP_GT: a.invert = 1; break;
+    case FL_CMP_LT:                       // x < k  ==  x <= k-1 ;  x < 0 is never true
+        if (constant == 0) { a.constant = MAXV; a.invert = 1; } else a.constant = (T)(constant - 1);
+        break;
+    default:                              // FL_CMP_GE: x >= k == !(x <= k-1) ; x >= 0 is always true
+        if (constant == 0) a.constant = MAXV; else { a.constant = (T)(constant - 1); a.invert = 1; }
+        break;
+    }
+    hipError_t e = (a.is_eq ? compare_table_impl<T, true>() : compare_table_impl<T, false>()).fn[w](a, static_cast<hipStream_t>(s));
+    return e == hipSuccess ? FL_OK : hip_fail(e);
+}
+template <typename T>
 int dev_block_min_max(const T* in, size_t n, T* mins, T* maxs, void* s)
 {
     if (n == 0) return FL_OK;
@@ -326,6 +359,8 @@ size_t fl_packed_len(unsigned type_bits, unsigned width)
     { return dev_transpose_delta_pack<T>(w, in, b, out, n, s); }                                          \
     int fl_##S##_unpack_block_sums(unsigned w, const T* in, size_t n, uint64_t* sums, void* s)           \
     { return dev_unpack_block_sums<T>(w, in, n, sums, s); }                                               \
+    int fl_##S##_unpack_compare(unsigned w, const T* in, int op, T k, size_t n, uint32_t* mask, void* s)  \
+    { return dev_unpack_compare<T>(w, in, op, k, n, mask, s); }                                           \
     int fl_##S##_block_min_max(const T* in, size_t n, T* mins, T* maxs, void* s)                          \
     { return dev_block_min_max<T>(in, n, mins, maxs, s); }                                                \
     int fl_##S##_transpose(const T* in, T* out, size_t n, void* s) { return dev_transpose<T>(false, in, out, n, s); } \

@@ -117,6 +117,114 @@ __global__ __launch_bounds__(WG) void k_block_min_max(ReduceArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------
+// unpack_compare<W>: mask bit i of block b = cmp(unpack::<W>(packed_b)[i], constant), i in the
+// unpacked (FastLanes index) order -- a selection vector straight from packed data: 128*W bytes
+// in, 128 bytes out per block.  Every predicate is reduced on the host to one of two primitives
+// (x == k, x <= k) plus a final complement.  Address-row j of a block is elements [j*LANES,
+// (j+1)*LANES): the 8 column threads OR their PER_CELL-bit pieces together with three DPP steps
+// (lane^1, lane^2, 7-lane) per 32-bit mask word, and thread c keeps words 4c..4c+3, so the mask
+// leaves as one coalesced 16-byte store per thread.
+// ---------------------------------------------------------------------------
+struct CompareArgs {
+    const u32x4* in;
+    u32x4* mask;           // [n_blocks][8] cells = 128 bytes per block
+    uint64_t constant;     // k of the primitive, already adjusted
+    uint32_t is_eq;        // 1: x == k, 0: x <= k (selects the kernel instance on the host)
+    uint32_t invert;       // complement the result
+    uint64_t n_blocks;
+    uint64_t tiles_per_xcd;
+};
+
+__device__ __forceinline__ uint32_t or_allreduce8(uint32_t x)
+{
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]: lane ^ 1
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]: lane ^ 2
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true);   // row_half_mirror: lane -> 7 - lane
+    return x;
+}
+
+template <typename T, int W, bool IS_EQ>
+__device__ __forceinline__ void compare_block(const Cell<T>* in, T k, unsigned c, uint32_t (&keep)[4])
+{
+    constexpr int TB = Elem<T>::BITS;
+    constexpr int N = Elem<T>::PER_CELL;              // bits this thread contributes per row
+    constexpr int LANES = Elem<T>::LANES;             // bits per address-row
+    constexpr int PER_S = TB / 8;
+    // per address-row bit pieces of this thread
+    uint32_t piece[TB];
+    static_for<TB>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        constexpr int row = fl_order((j % PER_S) * (8 / PER_S)) * 8 + j / PER_S;
+        const Cell<T> v = unpack_row<T, W, row>(in);
+        uint32_t bits = 0;
+        static_for<N>([&](auto E) {
+            const T x = (T)cell_get<T>(v, decltype(E)::value);
+            const uint32_t p = IS_EQ ? (x == k) : (x <= k);
+            bits |= p << decltype(E)::value;
+        });
+        piece[j] = bits;
+    });
+    // 32 mask words per block; word d covers bits [32d, 32d+32) = rows (32d)/LANES ...
+    static_for<32>([&](auto D) {
+        constexpr int d = decltype(D)::value;
+        uint32_t w = 0;
+        if constexpr (LANES <= 32) {
+            constexpr int RPW = 32 / LANES;           // address-rows per mask word (u32: 1, u64: 2)
+            static_for<RPW>([&](auto Q) {
+                constexpr int q = decltype(Q)::value;
+                w |= piece[d * RPW + q] << (q * LANES + c * N);
+            });
+        } else {
+            constexpr int WPR = LANES / 32;           // mask words per address-row (u16: 2, u8: 4)
+            constexpr int j = d / WPR, h = d % WPR;
+            const unsigned pos = c * N;               // bit position of this thread's piece in its row
+            w = (pos / 32 == (unsigned)h) ? piece[j] << (pos % 32) : 0u;
+        }
+        w = or_allreduce8(w);
+        if (d / 4 == (int)c) keep[d % 4] = w;
+    });
+}
+
+template <typename T, int W, bool IS_EQ>
+__global__ __launch_bounds__(WG) void k_unpack_compare(CompareArgs a)
+{
+    const uint64_t n_tiles = (a.n_blocks + BLOCKS_PER_WG - 1) / BLOCKS_PER_WG;
+    const uint64_t tile = (uint64_t)(blockIdx.x & 7u) * a.tiles_per_xcd + (blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
+    const unsigned tid = threadIdx.x;
+    const uint64_t blk = tile * BLOCKS_PER_WG + (tid >> 3);
+    const unsigned c = tid & 7u;
+    if (blk >= a.n_blocks) return;     // whole 8-thread groups leave together (DPP stays inside a group)
+    Cell<T> in[W ? W : 1];
+    const u32x4* pk = a.in + blk * (uint64_t)(8 * W) + c;
+    static_for<W>([&](auto Wd) { in[decltype(Wd)::value] = load_cell<T, true>(pk + 8 * decltype(Wd)::value); });
+    uint32_t keep[4] = {0, 0, 0, 0};
+    compare_block<T, W, IS_EQ>(in, (T)a.constant, c, keep);
+    const uint32_t flip = a.invert ? ~0u : 0u;
+    u32x4 out = {keep[0] ^ flip, keep[1] ^ flip, keep[2] ^ flip, keep[3] ^ flip};
+    a.mask[blk * 8 + c] = out;
+}
+
+typedef hipError_t (*compare_launch_t)(const CompareArgs&, hipStream_t);
+template <typename T, int W, bool IS_EQ> hipError_t launch_unpack_compare(const CompareArgs& a0, hipStream_t s)
+{
+    if (a0.n_blocks == 0) return hipSuccess;
+    CompareArgs a = a0;
+    const uint64_t n_tiles = (a.n_blocks + BLOCKS_PER_WG - 1) / BLOCKS_PER_WG;
+    a.tiles_per_xcd = (n_tiles + 7) / 8;
+    hipLaunchKernelGGL((k_unpack_compare<T, W, IS_EQ>), dim3((unsigned)(a.tiles_per_xcd * 8)), dim3(WG), 0, s, a);
+    return hipGetLastError();
+}
+template <typename T> struct CompareTable { compare_launch_t fn[Elem<T>::BITS + 1]; };
+template <typename T, bool IS_EQ, int... Ws>
+constexpr CompareTable<T> make_compare_table(std::integer_sequence<int, Ws...>)
+{
+    return CompareTable<T>{{&launch_unpack_compare<T, Ws, IS_EQ>...}};
+}
+// the two primitives live in separate translation units (families 11 / 12) to build in parallel
+template <typename T, bool IS_EQ> const CompareTable<T>& compare_table_impl();
+
 typedef hipError_t (*reduce_launch_t)(const ReduceArgs&, hipStream_t);
 
 inline unsigned plan_grid(ReduceArgs& a)

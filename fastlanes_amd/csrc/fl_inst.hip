@@ -4,7 +4,7 @@
 //   0 unpack (store)   1 unfor_pack   2 undelta_pack   3 pack   4 for_pack
 //   5 delta / undelta / transpose / untranspose / unpack_single
 //   6 unpack / 7 pack over a mixed-width plan (one launch, per-tile width dispatch)
-//   10 fused consumers: unpack_block_sums, block_min_max
+//   10 fused consumers: unpack_block_sums, block_min_max   11 / 12 unpack_compare (selection masks: x <= k / x == k)
 //   8 undelta_pack+untranspose (fused decode to original order)   9 transpose+delta+pack (fused encode)
 #include "fl_kernels.hpp"
 #include "fl_misc.hpp"
@@ -63,7 +63,13 @@ template <> const WidthTable<T>& pack_table_impl<T, PACK_TRANSPOSE_DELTA>() { re
 static constexpr ReduceTable<T> t_sums = make_sum_table<T>(Ws{});
 template <> const ReduceTable<T>& sum_table_impl<T>() { return t_sums; }
 template <> reduce_launch_t min_max_launcher<T>() { return &launch_block_min_max<T>; }
+#elif FL_FAMILY == 11
+static constexpr CompareTable<T> t_compare_le = make_compare_table<T, false>(Ws{});
+template <> const CompareTable<T>& compare_table_impl<T, false>() { return t_compare_le; }
+#elif FL_FAMILY == 12
+static constexpr CompareTable<T> t_compare_eq = make_compare_table<T, true>(Ws{});
+template <> const CompareTable<T>& compare_table_impl<T, true>() { return t_compare_eq; }
 #else
-#error "FL_FAMILY must be 0..10"
+#error "FL_FAMILY must be 0..12"
 #endif
 }  // namespace fl

@@ -65,6 +65,9 @@ typedef enum fl_status {
     FL_ERR_HIP = 5      /* HIP runtime error; see fl_last_hip_error()              */
 } fl_status;
 
+/* predicates of fl_<ty>_unpack_compare (unsigned comparison with a constant) */
+typedef enum fl_cmp { FL_CMP_EQ = 0, FL_CMP_NE = 1, FL_CMP_LT = 2, FL_CMP_LE = 3, FL_CMP_GT = 4, FL_CMP_GE = 5 } fl_cmp;
+
 /* Library / build identification and diagnostics. */
 const char *fl_version(void);
 const char *fl_status_string(int status);
@@ -141,6 +144,11 @@ const uint64_t *fl_mixed_plan_offsets(const fl_mixed_plan *plan);
     int fl_##S##_unpack_block_sums(unsigned width, const T *in, size_t n_blocks, uint64_t *sums,  \
                                    void *stream);                                               \
     int fl_##S##_block_min_max(const T *in, size_t n_blocks, T *mins, T *maxs, void *stream);    \
+    /*   unpack_compare:    bit i of mask[b*32 .. b*32+32) = (unpack::<W>(block b)[i] <op> constant),  \
+     *                      i in the unpacked (index) order: a selection vector straight from packed   \
+     *                      data, 128*W bytes in, 128 bytes out per block.  op is an fl_cmp. */       \
+    int fl_##S##_unpack_compare(unsigned width, const T *in, int op, T constant, size_t n_blocks, \
+                                uint32_t *mask, void *stream);                                  \
     /* Transpose::transpose (transpose.rs:5,11-15) */                                           \
     int fl_##S##_transpose(const T *in, T *out, size_t n_blocks, void *stream);                 \
     /* Transpose::untranspose (transpose.rs:6,17-22) */                                         \

@@ -601,3 +601,24 @@ def test_random_shapes_fuzz(fl, oracle):
             got = getattr(fl.Transpose, op)(to_dev(v))
             want = oracle.batch(op, ty, None, v)
         assert np.array_equal(to_np(got, ty), want), (ty, w, op, n, seed)
+
+
+@pytest.mark.parametrize("ty", TYS)
+def test_unpack_compare_vs_oracle(fl, oracle, ty):
+    """unpack_compare (extension): mask = numpy compare of the oracle's unpack
+    output, packed LSB-first in index order; all six predicates incl. the k = 0 / k = MAX edges."""
+    import operator
+    T = tbits(ty)
+    n = 41
+    ops = {"==": operator.eq, "!=": operator.ne, "<": operator.lt, "<=": operator.le, ">": operator.gt, ">=": operator.ge}
+    for w in sorted({0, 1, 3, T // 2, T - 1, T}):
+        pk = values(ty, n * packed_len(ty, w), 15000 + 64 * T + w)
+        un = oracle.batch("unpack", ty, w, pk, n_blocks=n)
+        dpk = to_dev(pk)
+        maxv = (1 << w) - 1 if w else 0
+        consts = sorted({0, 1, maxv // 2, maxv, int(un[5]), (1 << T) - 1})
+        for k in consts:
+            for name, f in ops.items():
+                got = fl.BitPacking.unpack_compare(w, dpk, name, k, n_blocks=n).cpu().numpy().view(np.uint8)
+                want = np.packbits(f(un, TYPES[ty][0](k)), bitorder="little")
+                assert np.array_equal(got, want), (ty, w, name, k)

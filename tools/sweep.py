@@ -32,6 +32,8 @@ def bytes_per_block(op, ty, w):
         return 128 * w + 128 + 128 * T
     if op == "unpack_block_sums":
         return 128 * w + 8
+    if op == "unpack_compare":
+        return 128 * w + 128
     if op == "block_min_max":
         return 128 * T + 2 * ESZ[ty]
     if op in ("delta", "undelta"):
@@ -65,6 +67,9 @@ def run(op, ty, w, gb, reps):
     elif op == "unpack_block_sums":
         src = pk(1)
         f = lambda: fl.BitPacking.unpack_block_sums(w, src)
+    elif op == "unpack_compare":
+        src = pk(1)
+        f = lambda: fl.BitPacking.unpack_compare(w, src, "<", (1 << w) // 2)
     elif op == "block_min_max":
         src = un(1)
         f = lambda: fl.BitPacking.block_min_max(src)
@@ -131,7 +136,9 @@ def main():
                   ("transpose_delta_pack", "u32", 12), ("transpose_delta_pack", "u64", 20),
                   ("transpose_delta_pack", "u16", 9), ("transpose_delta_pack", "u8", 4)]
     elif args.cases == "consume":
-        cases = [("unpack_block_sums", "u32", 7), ("unpack_block_sums", "u32", 20), ("unpack_block_sums", "u64", 17),
+        cases = [("unpack_compare", "u32", 7), ("unpack_compare", "u32", 20), ("unpack_compare", "u64", 17),
+                 ("unpack_compare", "u16", 3), ("unpack_compare", "u8", 3),
+                 ("unpack_block_sums", "u32", 7), ("unpack_block_sums", "u32", 20), ("unpack_block_sums", "u64", 17),
                  ("unpack_block_sums", "u16", 3), ("unpack_block_sums", "u8", 3),
                  ("block_min_max", "u32", 0), ("block_min_max", "u64", 0), ("block_min_max", "u16", 0), ("block_min_max", "u8", 0)]
     elif args.cases == "fused":
