@@ -57,6 +57,7 @@ template <typename T> struct Abi;
         static constexpr auto transpose_delta_pack = fl_##S##_transpose_delta_pack;                  \
         static constexpr auto unpack_block_sums = fl_##S##_unpack_block_sums;                        \
         static constexpr auto block_min_max = fl_##S##_block_min_max;                                \
+        static constexpr auto unpack_compare = fl_##S##_unpack_compare;                              \
         static constexpr auto unpack_mixed = fl_##S##_unpack_mixed;                                  \
         static constexpr auto pack_mixed = fl_##S##_pack_mixed;                                      \
         static constexpr auto pack_host = fl_##S##_pack_host;                                        \
@@ -137,6 +138,10 @@ template <typename T> struct BitPacking : FastLanes<T> {
     static void unpack_block_sums_device(std::size_t width, const T* d_packed, std::size_t n_blocks, std::uint64_t* d_sums,
                                          void* stream = nullptr)
     { detail::check(A::unpack_block_sums((unsigned)width, d_packed, n_blocks, d_sums, stream), "unpack_block_sums_device"); }
+    // mask bit i of block b = (unpack(block b)[i] <op> constant); 32 words per block
+    static void unpack_compare_device(std::size_t width, const T* d_packed, fl_cmp op, T constant, std::size_t n_blocks,
+                                      std::uint32_t* d_mask, void* stream = nullptr)
+    { detail::check(A::unpack_compare((unsigned)width, d_packed, (int)op, constant, n_blocks, d_mask, stream), "unpack_compare_device"); }
     static void block_min_max_device(const T* d_values, std::size_t n_blocks, T* d_mins, T* d_maxs, void* stream = nullptr)
     { detail::check(A::block_min_max(d_values, n_blocks, d_mins, d_maxs, stream), "block_min_max_device"); }
     static void unpack_single_device(std::size_t width, const T* d_packed, std::size_t n_blocks, const std::uint64_t* d_indices,

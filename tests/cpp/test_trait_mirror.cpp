@@ -151,6 +151,11 @@ static void test_device_tier()
     BitPacking<uint32_t>::unpack_block_sums_device(7, dp.p, N, ds.p);
     auto sums = ds.down();
     for (size_t b = 0; b < N; ++b) { uint64_t s = 0; for (int i = 0; i < 1024; ++i) s += v[b * 1024 + i]; EXPECT(sums[b] == s); }
+    // selection mask straight from packed data: v < 64
+    DevVec<uint32_t> dmask(N * 32);
+    BitPacking<uint32_t>::unpack_compare_device(7, dp.p, FL_CMP_LT, 64u, N, dmask.p);
+    auto mask = dmask.down();
+    for (size_t i = 0; i < v.size(); i += 97) EXPECT(((mask[i / 32] >> (i % 32)) & 1u) == (v[i] < 64u ? 1u : 0u));
     // fused encode/decode in the ORIGINAL order round-trips (W = 32: lossless for any data)
     std::vector<uint32_t> bases(N * 32, 12345u);
     DevVec<uint32_t> db(N * 32), de(N * 1024), dd(N * 1024);
