@@ -419,7 +419,11 @@ class MixedWidthPlan:
             _lib.load().fl_mixed_plan_destroy(self._plan)
             self._plan = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: the library may already be gone
+            pass
 
     def _torch_dtype(self):
         import torch

@@ -235,7 +235,7 @@ int run_mixed(bool pack, const fl_mixed_plan* p, const void* packed, void* unpac
 
 extern "C" {
 
-int fl_mixed_plan_create(unsigned type_bits, const uint8_t* widths, size_t n_blocks, fl_mixed_plan** plan)
+static int mixed_plan_create_impl(unsigned type_bits, const uint8_t* widths, size_t n_blocks, fl_mixed_plan** plan)
 {
     if (!plan || (n_blocks && !widths)) return FL_ERR_NULL;
     *plan = nullptr;
@@ -248,6 +248,10 @@ int fl_mixed_plan_create(unsigned type_bits, const uint8_t* widths, size_t n_blo
     }
     fl_mixed_plan* p = new (std::nothrow) fl_mixed_plan;
     if (!p) return FL_ERR_HIP;
+    struct Guard {   // frees the half-built plan on every early exit, including exceptions
+        fl_mixed_plan* p;
+        ~Guard() { if (p) fl_mixed_plan_destroy(p); }
+    } guard{p};
     p->type_bits = type_bits;
     p->n_blocks = n_blocks;
     size_t bucket_start[67] = {0};
@@ -297,10 +301,22 @@ int fl_mixed_plan_create(unsigned type_bits, const uint8_t* widths, size_t n_blo
         if (e == hipSuccess) e = hipMemcpy(p->d_entries, entries.data(), n_blocks * sizeof(MixedEntry), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(p->d_offsets, off.data(), n_blocks * sizeof(uint64_t), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(p->d_tiles, tiles.data(), tiles.size() * sizeof(MixedTile), hipMemcpyHostToDevice);
-        if (e != hipSuccess) { fl_mixed_plan_destroy(p); return hip_fail(e); }
+        if (e != hipSuccess) return hip_fail(e);
     }
+    guard.p = nullptr;
     *plan = p;
     return FL_OK;
+}
+
+int fl_mixed_plan_create(unsigned type_bits, const uint8_t* widths, size_t n_blocks, fl_mixed_plan** plan)
+{
+    // nothing may throw across the C ABI (the host-side tables are std::vectors)
+    try {
+        return mixed_plan_create_impl(type_bits, widths, n_blocks, plan);
+    } catch (...) {
+        g_last_hip_error = (int)hipErrorOutOfMemory;
+        return FL_ERR_HIP;
+    }
 }
 
 void fl_mixed_plan_destroy(fl_mixed_plan* p)

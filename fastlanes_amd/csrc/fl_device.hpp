@@ -32,7 +32,6 @@
 namespace fl {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 // lib.rs:22 FL_ORDER = [0,4,2,6,1,5,3,7], nibble-packed so it folds.
@@ -57,7 +56,6 @@ template <typename T> struct Elem {
     static constexpr int BITS = sizeof(T) * 8;
     static constexpr int LANES = 1024 / BITS;
     static constexpr int PER_CELL = 16 / sizeof(T);   // FL lanes per 16-byte cell
-    static constexpr int ROWS = BITS;                 // unpacked cell-rows per block
     static constexpr int CELLS_PER_BLOCK = 8 * BITS;  // 1024*sizeof(T)/16
     // cell-row of logical row r inside an unpacked block (macros.rs:20-24 in cells)
     __host__ __device__ static constexpr int row_cell(int r)
