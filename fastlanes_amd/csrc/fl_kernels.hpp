@@ -250,8 +250,8 @@ void k_pack(StreamArgs a)
             prev = next;
         });
     } else {
-        static_for<TB>([&](auto R) {
-            rows[decltype(R)::value] = load_cell<T, NTL>(un + Elem<T>::row_cell(decltype(R)::value));
+        static_for<TB>([&](auto J) {   // issued in ascending address order
+            rows[WaveRowStore<T>::row_at(decltype(J)::value)] = load_cell<T, NTL>(un + 8 * decltype(J)::value);
         });
     }
     const TileStore<(W ? W : 1) * 128> st(a.out, tile, a.n_blocks, tid);
@@ -285,8 +285,8 @@ void k_delta(StreamArgs a)
     if (valid) {
         const u32x4* src = a.in + blk * (uint64_t)Elem<T>::CELLS_PER_BLOCK + c;
         prev = load_cell<T, false>(static_cast<const u32x4*>(a.aux) + blk * 8 + c);
-        static_for<TB>([&](auto R) {
-            rows[decltype(R)::value] = load_cell<T, true>(src + Elem<T>::row_cell(decltype(R)::value));
+        static_for<TB>([&](auto J) {   // issued in ascending address order
+            rows[WaveRowStore<T>::row_at(decltype(J)::value)] = load_cell<T, true>(src + 8 * decltype(J)::value);
         });
     }
     static_for<TB>([&](auto R) {

@@ -51,8 +51,8 @@ void k_transpose(StreamArgs a)
         // transposed -> original order: out[lane_base(l) + r] = in[index(r,l)]   (transpose.rs:19-21)
         if (!valid) return;                                    // per-block exchange only
         const u32x4* src = a.in + blk * (uint64_t)Elem<T>::CELLS_PER_BLOCK + c;
-        static_for<TB>([&](auto R) {
-            rows[decltype(R)::value] = load_cell<T, true>(src + Elem<T>::row_cell(decltype(R)::value));
+        static_for<TB>([&](auto J) {   // issued in ascending address order
+            rows[WaveRowStore<T>::row_at(decltype(J)::value)] = load_cell<T, true>(src + 8 * decltype(J)::value);
         });
         const TileStore<Elem<T>::CELLS_PER_BLOCK * 16> st(a.out, tile, a.n_blocks, tid);
         __shared__ __attribute__((aligned(16))) char lds[(WG / 64) * RunExchange<T>::WAVE_BYTES];

@@ -77,8 +77,8 @@ __device__ __forceinline__ void pack_mixed_tile(const MixedArgs& a, const MixedT
     if constexpr (W == 0) return;
     const u32x4* un = reinterpret_cast<const u32x4*>(a.unpacked + e.blk * BLOCK_BYTES) + c;
     Cell<T> rows[TB];
-    static_for<TB>([&](auto R) {
-        rows[decltype(R)::value] = load_cell<T, true>(un + Elem<T>::row_cell(decltype(R)::value));
+    static_for<TB>([&](auto J) {   // issued in ascending address order
+        rows[WaveRowStore<T>::row_at(decltype(J)::value)] = load_cell<T, true>(un + 8 * decltype(J)::value);
     });
     char* pk = const_cast<char*>(a.packed);
     const SpanStore<WINDOW> st(pk + t.first_off, pk + e.packed_off + c * 16);
