@@ -1,0 +1,69 @@
+//! Raw declarations of the C ABI in `include/fastlanes_amd.h` (host tier + the batched device
+//! tier).  Uncompiled: see ../README.md.
+#![allow(dead_code)]
+use core::ffi::{c_char, c_void};
+
+macro_rules! declare_type {
+    ($T:ty, $pack_host:ident, $unpack_host:ident, $single_host:ident, $for_pack_host:ident, $unfor_pack_host:ident,
+     $delta_host:ident, $undelta_host:ident, $undelta_pack_host:ident, $transpose_host:ident, $untranspose_host:ident,
+     $pack:ident, $unpack:ident, $for_pack:ident, $unfor_pack:ident, $delta:ident, $undelta:ident,
+     $undelta_pack:ident, $transpose:ident, $untranspose:ident) => {
+        extern "C" {
+            // host tier: the trait methods' own slices; n_blocks = 1 per trait call
+            pub fn $pack_host(width: u32, input: *const $T, output: *mut $T, n_blocks: usize) -> i32;
+            pub fn $unpack_host(width: u32, input: *const $T, output: *mut $T, n_blocks: usize) -> i32;
+            pub fn $single_host(width: u32, packed: *const $T, n_blocks: usize, index: u64, value: *mut $T) -> i32;
+            pub fn $for_pack_host(width: u32, input: *const $T, reference: $T, output: *mut $T, n_blocks: usize) -> i32;
+            pub fn $unfor_pack_host(width: u32, input: *const $T, reference: $T, output: *mut $T, n_blocks: usize) -> i32;
+            pub fn $delta_host(input: *const $T, bases: *const $T, output: *mut $T, n_blocks: usize) -> i32;
+            pub fn $undelta_host(input: *const $T, bases: *const $T, output: *mut $T, n_blocks: usize) -> i32;
+            pub fn $undelta_pack_host(width: u32, input: *const $T, bases: *const $T, output: *mut $T, n_blocks: usize) -> i32;
+            pub fn $transpose_host(input: *const $T, output: *mut $T, n_blocks: usize) -> i32;
+            pub fn $untranspose_host(input: *const $T, output: *mut $T, n_blocks: usize) -> i32;
+            // device tier: device pointers, n_blocks contiguous blocks, asynchronous on a hipStream_t
+            pub fn $pack(width: u32, d_in: *const $T, d_out: *mut $T, n_blocks: usize, stream: *mut c_void) -> i32;
+            pub fn $unpack(width: u32, d_in: *const $T, d_out: *mut $T, n_blocks: usize, stream: *mut c_void) -> i32;
+            pub fn $for_pack(width: u32, d_in: *const $T, d_refs: *const $T, ref_stride: usize, d_out: *mut $T,
+                             n_blocks: usize, stream: *mut c_void) -> i32;
+            pub fn $unfor_pack(width: u32, d_in: *const $T, d_refs: *const $T, ref_stride: usize, d_out: *mut $T,
+                               n_blocks: usize, stream: *mut c_void) -> i32;
+            pub fn $delta(d_in: *const $T, d_bases: *const $T, d_out: *mut $T, n_blocks: usize, stream: *mut c_void) -> i32;
+            pub fn $undelta(d_in: *const $T, d_bases: *const $T, d_out: *mut $T, n_blocks: usize, stream: *mut c_void) -> i32;
+            pub fn $undelta_pack(width: u32, d_in: *const $T, d_bases: *const $T, d_out: *mut $T, n_blocks: usize,
+                                 stream: *mut c_void) -> i32;
+            pub fn $transpose(d_in: *const $T, d_out: *mut $T, n_blocks: usize, stream: *mut c_void) -> i32;
+            pub fn $untranspose(d_in: *const $T, d_out: *mut $T, n_blocks: usize, stream: *mut c_void) -> i32;
+        }
+    };
+}
+
+declare_type!(u8, fl_u8_pack_host, fl_u8_unpack_host, fl_u8_unpack_single_host, fl_u8_for_pack_host, fl_u8_unfor_pack_host,
+              fl_u8_delta_host, fl_u8_undelta_host, fl_u8_undelta_pack_host, fl_u8_transpose_host, fl_u8_untranspose_host,
+              fl_u8_pack, fl_u8_unpack, fl_u8_for_pack, fl_u8_unfor_pack, fl_u8_delta, fl_u8_undelta,
+              fl_u8_undelta_pack, fl_u8_transpose, fl_u8_untranspose);
+declare_type!(u16, fl_u16_pack_host, fl_u16_unpack_host, fl_u16_unpack_single_host, fl_u16_for_pack_host, fl_u16_unfor_pack_host,
+              fl_u16_delta_host, fl_u16_undelta_host, fl_u16_undelta_pack_host, fl_u16_transpose_host, fl_u16_untranspose_host,
+              fl_u16_pack, fl_u16_unpack, fl_u16_for_pack, fl_u16_unfor_pack, fl_u16_delta, fl_u16_undelta,
+              fl_u16_undelta_pack, fl_u16_transpose, fl_u16_untranspose);
+declare_type!(u32, fl_u32_pack_host, fl_u32_unpack_host, fl_u32_unpack_single_host, fl_u32_for_pack_host, fl_u32_unfor_pack_host,
+              fl_u32_delta_host, fl_u32_undelta_host, fl_u32_undelta_pack_host, fl_u32_transpose_host, fl_u32_untranspose_host,
+              fl_u32_pack, fl_u32_unpack, fl_u32_for_pack, fl_u32_unfor_pack, fl_u32_delta, fl_u32_undelta,
+              fl_u32_undelta_pack, fl_u32_transpose, fl_u32_untranspose);
+declare_type!(u64, fl_u64_pack_host, fl_u64_unpack_host, fl_u64_unpack_single_host, fl_u64_for_pack_host, fl_u64_unfor_pack_host,
+              fl_u64_delta_host, fl_u64_undelta_host, fl_u64_undelta_pack_host, fl_u64_transpose_host, fl_u64_untranspose_host,
+              fl_u64_pack, fl_u64_unpack, fl_u64_for_pack, fl_u64_unfor_pack, fl_u64_delta, fl_u64_undelta,
+              fl_u64_undelta_pack, fl_u64_transpose, fl_u64_untranspose);
+
+extern "C" {
+    pub fn fl_status_string(status: i32) -> *const c_char;
+    pub fn fl_last_hip_error() -> i32;
+}
+
+/// The reference has no `Result`: `width > T` is `unreachable!()` (bitpacking.rs:93,126,197) and an
+/// out-of-range index is `assert!` (bitpacking.rs:152).  A nonzero status therefore panics, as there.
+#[inline]
+pub(crate) fn check(status: i32, what: &str) {
+    if status != 0 {
+        panic!("{what}: fastlanes_amd status {status} (hipError_t {})", unsafe { fl_last_hip_error() });
+    }
+}
