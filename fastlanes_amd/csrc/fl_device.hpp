@@ -217,8 +217,8 @@ template <typename T> struct LaneRun {
 
 // store_lane_runs_lines: original-order block <- rows[r] (column c of a TRANSPOSED block),
 // the inverse of load_lane_runs, with every global store a FULL 128-byte line.  The 8 threads of a block first exchange 16-byte pieces through a private
-// 1152-byte LDS region (8 line slots, 144-byte stride => conflict-free ds_write_b128 /
-// ds_read_b128), one "phase" of 8 output lines at a time (sizeof(T) phases per block), then
+// 1152-byte LDS region (8 line slots, 144-byte stride, for u16 slots 4..7 a further 16 bytes
+// on => conflict-free ds_write_b128 / ds_read_b128 for u16/u32/u64), one "phase" of 8 output lines at a time (sizeof(T) phases per block), then
 // thread c' stores piece c' of each line through `st` (a TileStore over the original-order
 // block).  Only lanes of the same wavefront touch a region: LDS operations of one wave execute
 // in order, so a compiler-level fence is all the synchronisation needed (no s_barrier).
@@ -272,7 +272,8 @@ __device__ __forceinline__ void store_lane_runs_lines(char* lds_blk, unsigned c,
                         constexpr int d = decltype(D)::value;
                         piece[d] = (uint32_t)cell_get<T>(rows[8 * j + 2 * d], e) | ((uint32_t)cell_get<T>(rows[8 * j + 2 * d + 1], e) << 16);
                     });
-                    *reinterpret_cast<u32x4*>(lds_blk + (4 * (c & 1u) + ep) * X::LS + fl_order(c >> 1) * 16 + 16 * j) = piece;
+                    // slots 4..7 (written by the odd columns) sit 16 bytes further: conflict-free ds_write_b128
+                    *reinterpret_cast<u32x4*>(lds_blk + (4 * (c & 1u) + ep) * X::LS + (c & 1u) * 16 + fl_order(c >> 1) * 16 + 16 * j) = piece;
                 });
             });
         } else {
@@ -293,7 +294,7 @@ __device__ __forceinline__ void store_lane_runs_lines(char* lds_blk, unsigned c,
         wave_lds_fence();
         static_for<8>([&](auto S) {
             constexpr int s = decltype(S)::value;
-            const u32x4 piece = *reinterpret_cast<const u32x4*>(lds_blk + s * X::LS + 16 * c);
+            const u32x4 piece = *reinterpret_cast<const u32x4*>(lds_blk + s * X::LS + (E == 2 ? 16 * (s / 4) : 0) + 16 * c);
             // byte address of this slot's line inside the original-order block
             constexpr unsigned line =
                 E == 8 ? (unsigned)((2 * s + p / 4) * 512 + 128 * (p % 4)) :
@@ -333,7 +334,8 @@ __device__ __forceinline__ void load_lane_runs_lines(char* lds_blk, unsigned c, 
     static_for<X::PHASES>([&](auto P) {
         constexpr int p = decltype(P)::value;
         static_for<8>([&](auto S) {
-            *reinterpret_cast<u32x4*>(lds_blk + decltype(S)::value * X::LS + 16 * c) = lines[p][decltype(S)::value];
+            *reinterpret_cast<u32x4*>(lds_blk + decltype(S)::value * X::LS + (E == 2 ? 16 * (decltype(S)::value / 4) : 0) + 16 * c) =
+                lines[p][decltype(S)::value];
         });
         wave_lds_fence();
         if constexpr (E >= 4) {
@@ -358,7 +360,7 @@ __device__ __forceinline__ void load_lane_runs_lines(char* lds_blk, unsigned c, 
                 static_for<2>([&](auto J) {
                     constexpr int j = decltype(J)::value;
                     const u32x4 piece = *reinterpret_cast<const u32x4*>(
-                        lds_blk + (4 * (c & 1u) + ep) * X::LS + fl_order(c >> 1) * 16 + 16 * j);
+                        lds_blk + (4 * (c & 1u) + ep) * X::LS + (c & 1u) * 16 + fl_order(c >> 1) * 16 + 16 * j);
                     static_for<4>([&](auto D) {
                         constexpr int d = decltype(D)::value;
                         cell_or<T>(rows[8 * j + 2 * d], e, piece[d] & 0xffffu);
