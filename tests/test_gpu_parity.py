@@ -622,3 +622,35 @@ def test_unpack_compare_vs_oracle(fl, oracle, ty):
                 got = fl.BitPacking.unpack_compare(w, dpk, name, k, n_blocks=n).cpu().numpy().view(np.uint8)
                 want = np.packbits(f(un, TYPES[ty][0](k)), bitorder="little")
                 assert np.array_equal(got, want), (ty, w, name, k)
+
+
+@pytest.mark.parametrize("ty", TYS)
+def test_host_tier_all_methods(fl, oracle, ty):
+    """Every fl_<ty>_*_host entry point (numpy in / numpy out, the trait methods' own slices),
+    several blocks per call and the single-block shape of one trait call."""
+    T = tbits(ty)
+    for n in (1, 3):
+        for w in sorted({0, 1, T // 2 + 1, T}):
+            v = values(ty, n * 1024, 800 + T + w)
+            pk = values(ty, n * packed_len(ty, w), 801 + T + w)
+            bases = values(ty, n * lanes(ty), 802 + T + w)
+            ref = int(values(ty, 1, 803 + T + w)[0])
+            assert np.array_equal(fl.BitPacking.pack(w, v), oracle.batch("pack", ty, w, v))
+            assert np.array_equal(fl.BitPacking.unpack(w, pk, n_blocks=n), oracle.batch("unpack", ty, w, pk, n_blocks=n))
+            refs = np.full(n, ref, dtype=TYPES[ty][0])
+            assert np.array_equal(fl.FoR.for_pack(w, v, ref), oracle.batch("for_pack", ty, w, v, aux=refs))
+            assert np.array_equal(fl.FoR.unfor_pack(w, pk, ref, n_blocks=n),
+                                  oracle.batch("unfor_pack", ty, w, pk, aux=refs, n_blocks=n))
+            assert np.array_equal(fl.Delta.undelta_pack(w, pk, bases),
+                                  oracle.batch("undelta_pack", ty, w, pk, aux=bases, n_blocks=n))
+            if w:
+                i = (n - 1) * 1024 + 777
+                pl = packed_len(ty, w)
+                assert fl.BitPacking.unpack_single(w, pk, i, n_blocks=n) == \
+                    oracle.unpack_single(ty, w, pk[(n - 1) * pl:n * pl], 777)
+        v = values(ty, n * 1024, 900 + T)
+        bases = values(ty, n * lanes(ty), 901 + T)
+        assert np.array_equal(fl.Delta.delta(v, bases), oracle.batch("delta", ty, None, v, aux=bases))
+        assert np.array_equal(fl.Delta.undelta(v, bases), oracle.batch("undelta", ty, None, v, aux=bases))
+        assert np.array_equal(fl.Transpose.transpose(v), oracle.batch("transpose", ty, None, v))
+        assert np.array_equal(fl.Transpose.untranspose(v), oracle.batch("untranspose", ty, None, v))
