@@ -266,7 +266,8 @@ def main():
             "data": "synthetic (uniform random packed bits, generated on device; inputs resident in HBM)",
             "config": {"workload": f"{op} {ty} W={width}, {n} blocks x 1024 values per GPU "
                                    f"(BASELINE.json configs[1])" if args.workload == "u32_w7_unpack"
-                                   else f"{op} {ty} W={width}, {n} blocks per GPU",
+                                   else (f"{op} {ty} width[b] = 1 + b mod 32 (BASELINE.json configs[4]), {n} blocks per GPU"
+                                         if op == "unpack_mixed" else f"{op} {ty} W={width}, {n} blocks per GPU"),
                        "blocks_per_gpu": n, "sharding": "contiguous block range per GPU, no collective"},
             "roofline": {
                 "bound": "hbm",
