@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--workload", default="u32_w7_unpack", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="CPU baseline time budget per leg")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 PMC passes (roofline.traffic "
+                    "then comes from profiles/pmc_traffic.json, or is null)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier / max-time "
                     "reduction (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--single-device", action="store_true",
@@ -124,8 +127,92 @@ def cpu_baseline(args, ty, width, op):
     }
 
 
+def pmc_child(args):
+    """Body of the rocprofv3 --pmc passes: a calibration copy of known size, then 3 launches of the
+    workload's kernel.  No timing, no oracle."""
+    import torch
+    import fastlanes_amd as fl
+    dev = torch.device("cuda", 0)
+    ty, width, op, _ = WORKLOADS[args.workload]
+    tdt = {"u8": torch.uint8, "u16": torch.uint16, "u32": torch.uint32, "u64": torch.uint64}[ty]
+    esz = {"u8": 1, "u16": 2, "u32": 4, "u64": 8}[ty]
+    a = rand_u8(PMC_CAL_BYTES, 5, dev)
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)                                   # known traffic: PMC_CAL_BYTES read + written
+    torch.cuda.synchronize()
+    del a, b
+    n = args.blocks
+    if op == "unpack_mixed":
+        return
+    in_b, out_b = (1024 * esz, 128 * width) if op == "pack" else (128 * width, 1024 * esz)
+    src = rand_u8(n * in_b, 6, dev).view(tdt)
+    dst = torch.empty(n * out_b // esz, dtype=tdt, device=dev)
+    bases = rand_u8(n * 128, 7, dev).view(tdt) if op == "undelta_pack" else None
+    for _ in range(3):
+        if op == "unpack":
+            fl.BitPacking.unpack(width, src, output=dst)
+        elif op == "pack":
+            fl.BitPacking.pack(width, src, output=dst)
+        else:
+            fl.Delta.undelta_pack(width, src, bases, output=dst)
+    torch.cuda.synchronize()
+
+
+PMC_CAL_BYTES = 2 << 30
+
+
+def live_pmc_traffic(args):
+    """HBM bytes per launch of the workload's kernel from rocprofv3 PMC counters, collected as
+    MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC slots), with
+    --kernel-trace only, in KiB units, and FETCH_SIZE corrected by the factor a copy of known size
+    shows in the same pass (gfx950 reports half of wide coalesced reads).  None on any failure."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    out = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="fl_pmc_", dir="/tmp")
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload,
+                   "--blocks", str(args.blocks)]
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=300,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            cal, ker = [], []
+            for r in csv.DictReader(open(files[0])):
+                if r["Counter_Name"] != counter:
+                    continue
+                v = float(r["Counter_Value"]) * 1024.0
+                name = r["Kernel_Name"]
+                if "fl::k_" in name:
+                    ker.append(v)
+                elif v > 0.25 * PMC_CAL_BYTES and ("copy" in name.lower() or "elementwise" in name.lower()) \
+                        and "distribution" not in name:
+                    cal.append(v)
+            shutil.rmtree(d, ignore_errors=True)
+            if not ker or not cal:
+                return None
+            out[counter] = (sum(ker) / len(ker), PMC_CAL_BYTES / (sum(cal) / len(cal)))
+        fetch, f_factor = out["FETCH_SIZE"]
+        write, w_factor = out["WRITE_SIZE"]
+        if not (1.8 < f_factor < 2.2 and 0.9 < w_factor < 1.1):
+            return None   # calibration does not look like the documented gfx950 behaviour: do not guess
+        return {"bytes": fetch * f_factor + write * w_factor, "fetch_factor": round(f_factor, 4),
+                "write_factor": round(w_factor, 4)}
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
+    if args.pmc_child:
+        return pmc_child(args)
     import torch
     import torch.distributed as dist
 
@@ -242,8 +329,17 @@ def main():
         avg_kernel_s = sum(kern_ms) / len(kern_ms) / 1e3
         achieved = n * bytes_per_block / avg_kernel_s / 1e9
         traffic = None
+        traffic_source = None
+        if world == 1 and not args.no_pmc and op != "unpack_mixed":
+            live = live_pmc_traffic(args)
+            if live is not None:
+                traffic = int(live["bytes"])
+                traffic_source = ("live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of this "
+                                  f"workload; FETCH x{live['fetch_factor']}, WRITE x{live['write_factor']} from a "
+                                  f"{PMC_CAL_BYTES >> 30} GiB copy in the same passes")
         prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(prof):
+        if traffic is None and os.path.exists(prof):
+            traffic_source = "profiles/pmc_traffic.json (committed rocprofv3 PMC run)"
             try:
                 traffic = json.load(open(prof)).get(args.workload, {}).get("hbm_bytes_per_launch_at_10M_blocks")
                 if traffic is not None and n != 10_000_000:
@@ -276,6 +372,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": traffic,
+                "traffic_source": traffic_source if traffic is not None else None,
                 "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBPS, 4),
                 "algorithmic_bytes_per_launch": n * bytes_per_block,
                 "kernel_ms_avg": round(avg_kernel_s * 1e3, 4),
