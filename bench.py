@@ -181,7 +181,7 @@ def live_pmc_traffic(args):
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
                    sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload,
                    "--blocks", str(args.blocks)]
-            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=300,
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=120,
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             cal, ker = [], []
