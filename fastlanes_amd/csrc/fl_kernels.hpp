@@ -170,7 +170,9 @@ void k_unpack(StreamArgs a)
         // all 8 blocks of its wavefront, so only whole wavefronts past the end may leave early
         using WS = WaveRowStore<T>;
         __shared__ __attribute__((aligned(16))) char lds[(WG / 64) * WS::WAVE_LDS];
-        const unsigned wave = tid >> 6, lane = tid & 63u;
+        // readfirstlane: the wave index must be provably wave-uniform, or hipcc wraps every buffer store
+        // of the wave's descriptor in a waterfall loop (cdna_hip_programming.md T20)
+        const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
         const uint64_t first_blk = tile * BLOCKS_PER_WG + wave * 8;
         if (first_blk >= a.n_blocks) return;
         const uint64_t blk = first_blk + (lane >> 3);
@@ -274,7 +276,8 @@ void k_delta(StreamArgs a)
     uint64_t tile;
     if (!tile_of_workgroup(a, tile)) return;
     const unsigned tid = threadIdx.x;
-    const unsigned wave = tid >> 6, lane = tid & 63u, c = tid & 7u;
+    // readfirstlane: keeps the wave's store descriptor in SGPRs (no waterfall loop around each store)
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u, c = tid & 7u;
     const uint64_t first_blk = tile * BLOCKS_PER_WG + wave * 8;
     if (first_blk >= a.n_blocks) return;                       // whole wavefront past the end
     const uint64_t blk = first_blk + (lane >> 3);

@@ -26,7 +26,8 @@ void k_transpose(StreamArgs a)
     uint64_t tile;
     if (!tile_of_workgroup(a, tile)) return;
     const unsigned tid = threadIdx.x;
-    const unsigned wave = tid >> 6, lane = tid & 63u, c = tid & 7u;
+    // readfirstlane: keeps the wave's store descriptor in SGPRs (no waterfall loop around each store)
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u, c = tid & 7u;
     const uint64_t first_blk = tile * BLOCKS_PER_WG + wave * 8;
     if (first_blk >= a.n_blocks) return;                       // whole wavefront past the end
     const uint64_t blk = first_blk + (lane >> 3);
