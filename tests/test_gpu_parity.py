@@ -654,3 +654,37 @@ def test_host_tier_all_methods(fl, oracle, ty):
         assert np.array_equal(fl.Delta.undelta(v, bases), oracle.batch("undelta", ty, None, v, aux=bases))
         assert np.array_equal(fl.Transpose.transpose(v), oracle.batch("transpose", ty, None, v))
         assert np.array_equal(fl.Transpose.untranspose(v), oracle.batch("untranspose", ty, None, v))
+
+
+def test_concurrent_host_threads(fl, oracle):
+    """The C ABI is re-entrant: host threads on their own streams (ctypes drops the GIL during
+    the call) produce exact results concurrently, for different (type, width) instances."""
+    import threading
+    import torch
+    jobs = [("u32", 7), ("u64", 17), ("u16", 3), ("u8", 5), ("u32", 12), ("u64", 33)]
+    n = 400
+    data = {j: values(j[0], n * packed_len(*j), 70 + i) for i, j in enumerate(jobs)}
+    want = {j: oracle.batch("unpack", j[0], j[1], data[j]) for j in jobs}
+    dev_in = {j: to_dev(data[j]) for j in jobs}
+    errors = []
+
+    def worker(j):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(25):
+                    out = fl.BitPacking.unpack(j[1], dev_in[j])
+                    back = fl.BitPacking.pack(j[1], out)
+                s.synchronize()
+            if not np.array_equal(to_np(out, j[0]), want[j]) or not np.array_equal(to_np(back, j[0]), data[j]):
+                errors.append(j)
+        except Exception as e:  # pragma: no cover
+            errors.append((j, repr(e)))
+
+    torch.cuda.synchronize()
+    threads = [threading.Thread(target=worker, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
