@@ -688,3 +688,37 @@ def test_concurrent_host_threads(fl, oracle):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("ty", TYS)
+def test_sixteen_byte_aligned_columns(fl, oracle, ty):
+    """The documented precondition is 16-byte alignment (128 is only recommended): columns that
+    start 16 / 48 bytes into an allocation decode and encode exactly."""
+    import torch
+    T = tbits(ty)
+    esz = T // 8
+    tdt = {"u8": torch.uint8, "u16": torch.uint16, "u32": torch.uint32, "u64": torch.uint64}[ty]
+    n = 45
+    w = max(1, T // 3)
+    pk = values(ty, n * packed_len(ty, w), 1234 + T)
+    bases = values(ty, n * lanes(ty), 1235 + T)
+    want_un = oracle.batch("unpack", ty, w, pk)
+    want_ud = oracle.batch("undelta_pack", ty, w, pk, aux=bases)
+    for off_in, off_out in ((16, 48), (48, 16)):
+        raw_in = torch.zeros(pk.nbytes + 256, dtype=torch.uint8, device="cuda:0")
+        raw_in[off_in:off_in + pk.nbytes] = torch.from_numpy(pk.view(np.uint8)).cuda()
+        d_in = raw_in[off_in:off_in + pk.nbytes].view(tdt)
+        raw_out = torch.zeros(n * 1024 * esz + 256, dtype=torch.uint8, device="cuda:0")
+        d_out = raw_out[off_out:off_out + n * 1024 * esz].view(tdt)
+        assert d_in.data_ptr() % 128 != 0 and d_out.data_ptr() % 128 != 0
+        fl.BitPacking.unpack(w, d_in, output=d_out)
+        assert np.array_equal(to_np(d_out, ty), want_un)
+        fl.Delta.undelta_pack(w, d_in, to_dev(bases), output=d_out)
+        assert np.array_equal(to_np(d_out, ty), want_ud)
+        assert not raw_out[:off_out].any() and not raw_out[off_out + n * 1024 * esz:].any()
+        # and back: pack from the offset unpacked column into an offset packed column
+        fl.BitPacking.unpack(w, d_in, output=d_out)
+        raw_pk2 = torch.zeros(pk.nbytes + 256, dtype=torch.uint8, device="cuda:0")
+        d_pk2 = raw_pk2[off_out:off_out + pk.nbytes].view(tdt)
+        fl.BitPacking.pack(w, d_out, output=d_pk2)
+        assert np.array_equal(to_np(d_pk2, ty), oracle.batch("pack", ty, w, want_un))
