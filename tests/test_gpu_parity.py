@@ -569,9 +569,9 @@ def test_no_write_past_the_end_of_the_column(fl, ty):
 
 def test_random_shapes_fuzz(fl, oracle):
     """Seeded fuzz over (type, width, op, block count): tail handling of tiles / wavefronts."""
-    rng = np.random.default_rng(2024)
+    rng = np.random.default_rng(int(os.environ.get("FL_FUZZ_SEED", "2024")))
     ops = ["pack", "unpack", "for_pack", "unfor_pack", "undelta_pack", "delta", "undelta", "transpose", "untranspose"]
-    for _ in range(60):
+    for _ in range(int(os.environ.get("FL_FUZZ_ITERS", "60"))):
         ty = TYS[rng.integers(0, 4)]
         T = tbits(ty)
         w = int(rng.integers(0, T + 1))
