@@ -74,7 +74,11 @@ int fl_oracle_parallel_fill(void *base, size_t bytes_per_block, size_t n_blocks,
     int fl_oracle_fast_unfor_pack_##S(unsigned width, const T *in, const T *refs,         \
                                       T *out, size_t n_blocks, unsigned nthreads);        \
     int fl_oracle_fast_undelta_pack_##S(unsigned width, const T *in, const T *bases,      \
-                                        T *out, size_t n_blocks, unsigned nthreads);
+                                        T *out, size_t n_blocks, unsigned nthreads);      \
+    /* per-block content hashes of an unpacked column (full-size GPU-vs-oracle check):     \
+     * sum[b] = sum_i v[i], wsum[b] = sum_i (i+1)*v[i], both wrapping uint64 */            \
+    int fl_oracle_block_hashes_##S(const T *v, size_t n_blocks, uint64_t *sum,            \
+                                   uint64_t *wsum, unsigned nthreads);
 
 FL_ORACLE_DECL(uint8_t, u8)
 FL_ORACLE_DECL(uint16_t, u16)

@@ -196,6 +196,18 @@ class Oracle:
             raise ValueError(f"oracle fill rc={rc}")
         return arr
 
+    def block_hashes(self, ty, v, nthreads=1):
+        """(sum, weighted sum) per 1024-value block, wrapping uint64 (full-size content check)."""
+        v = np.ascontiguousarray(v, dtype=TYPES[ty][0])
+        n = v.size // 1024
+        s = np.empty(n, dtype=np.uint64)
+        w = np.empty(n, dtype=np.uint64)
+        rc = getattr(self.lib, f"fl_oracle_block_hashes_{ty}")(self._p(v), ctypes.c_size_t(n), self._p(s), self._p(w),
+                                                               ctypes.c_uint(nthreads))
+        if rc:
+            raise ValueError(f"oracle hash rc={rc}")
+        return s, w
+
     # ---- fast family (CPU baseline only) -------------------------------------
     def fast(self, op, ty, w, data, aux=None, n_blocks=None, nthreads=1, out=None):
         dt = TYPES[ty][0]

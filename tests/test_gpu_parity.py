@@ -722,3 +722,42 @@ def test_sixteen_byte_aligned_columns(fl, oracle, ty):
         d_pk2 = raw_pk2[off_out:off_out + pk.nbytes].view(tdt)
         fl.BitPacking.pack(w, d_out, output=d_pk2)
         assert np.array_equal(to_np(d_pk2, ty), oracle.batch("pack", ty, w, want_un))
+
+
+def _splitmix_on_device(n_words, seed):
+    """The stream fl_oracle_parallel_fill writes (splitmix64 of seed + (i+1)*GOLDEN), regenerated on
+    the GPU with wrapping int64 arithmetic -- host and device see identical bits without a PCIe copy."""
+    import torch
+    def c(x):  # two's-complement view of a uint64 constant
+        return x - (1 << 64) if x >= (1 << 63) else x
+    G, C1, C2 = c(0x9E3779B97F4A7C15), c(0xBF58476D1CE4E5B9), c(0x94D049BB133111EB)
+    z = torch.arange(1, n_words + 1, dtype=torch.int64, device="cuda:0") * G + c(seed & (2**64 - 1))
+    z = (z ^ ((z >> 30) & ((1 << 34) - 1))) * C1       # logical >> via mask
+    z = (z ^ ((z >> 27) & ((1 << 37) - 1))) * C2
+    return z ^ ((z >> 31) & ((1 << 33) - 1))
+
+
+def test_config2_full_column_content_hash_vs_cpu_oracle(fl, oracle):
+    """SURVEY.md 8(d) 'correctness at scale' (2): the whole 10 M-block u32 W=7 column, chunk by
+    chunk -- the GPU decodes a device-generated stream, the multithreaded CPU oracle decodes the
+    same stream regenerated on the host, and two 64-bit content hashes per block (sum and
+    position-weighted sum) of ALL 10.24 G values must agree."""
+    import torch
+    n_total, chunk = 10_000_000, 1_000_000
+    threads = min(64, os.cpu_count() or 1)
+    w_idx = torch.arange(1, 1025, dtype=torch.int64, device="cuda:0")
+    for k in range(n_total // chunk):
+        seed = 0xC0FFEE + k
+        host_pk = np.empty(chunk * 224, dtype=np.uint32)
+        oracle.parallel_fill(host_pk, 896, chunk, seed, threads)
+        host_out = oracle.fast("unpack", "u32", 7, host_pk, n_blocks=chunk, nthreads=threads)
+        s_cpu, w_cpu = oracle.block_hashes("u32", host_out, threads)
+        dev_pk = _splitmix_on_device(chunk * 112, seed).view(torch.uint32)
+        if k == 0:   # the two generators really are the same stream
+            assert np.array_equal(to_np(dev_pk[:4096], "u32"), host_pk[:4096])
+        vals = fl.BitPacking.unpack(7, dev_pk).view(torch.int32).view(chunk, 1024).to(torch.int64)
+        s_gpu = vals.sum(dim=1)
+        w_gpu = (vals * w_idx).sum(dim=1)
+        assert np.array_equal(s_gpu.cpu().numpy().view(np.uint64), s_cpu), k
+        assert np.array_equal(w_gpu.cpu().numpy().view(np.uint64), w_cpu), k
+        del vals, dev_pk
