@@ -737,27 +737,42 @@ def _splitmix_on_device(n_words, seed):
     return z ^ ((z >> 31) & ((1 << 33) - 1))
 
 
-def test_config2_full_column_content_hash_vs_cpu_oracle(fl, oracle):
-    """SURVEY.md 8(d) 'correctness at scale' (2): the whole 10 M-block u32 W=7 column, chunk by
-    chunk -- the GPU decodes a device-generated stream, the multithreaded CPU oracle decodes the
-    same stream regenerated on the host, and two 64-bit content hashes per block (sum and
-    position-weighted sum) of ALL 10.24 G values must agree."""
+@pytest.mark.parametrize("ty,w,op", [("u32", 7, "unpack"), ("u64", 17, "unpack"), ("u32", 12, "undelta_pack")])
+def test_full_column_content_hash_vs_cpu_oracle(fl, oracle, ty, w, op):
+    """SURVEY.md 8(d) 'correctness at scale' (2) for BASELINE configs 2, 3 and 4: the whole 10 M-block
+    column, chunk by chunk -- the GPU decodes a device-generated stream, the multithreaded CPU oracle
+    decodes the same stream regenerated on the host, and two 64-bit content hashes per block (sum and
+    position-weighted sum, wrapping) of ALL 10.24 G values must agree."""
     import torch
     n_total, chunk = 10_000_000, 1_000_000
+    T = tbits(ty)
+    tdt = {"u32": torch.uint32, "u64": torch.uint64}[ty]
+    wpb = 128 * w // 8                      # 64-bit words per packed block
     threads = min(64, os.cpu_count() or 1)
     w_idx = torch.arange(1, 1025, dtype=torch.int64, device="cuda:0")
     for k in range(n_total // chunk):
-        seed = 0xC0FFEE + k
-        host_pk = np.empty(chunk * 224, dtype=np.uint32)
-        oracle.parallel_fill(host_pk, 896, chunk, seed, threads)
-        host_out = oracle.fast("unpack", "u32", 7, host_pk, n_blocks=chunk, nthreads=threads)
-        s_cpu, w_cpu = oracle.block_hashes("u32", host_out, threads)
-        dev_pk = _splitmix_on_device(chunk * 112, seed).view(torch.uint32)
+        seed = 0xC0FFEE + 17 * T + k
+        host_pk = np.empty(chunk * packed_len(ty, w), dtype=TYPES[ty][0])
+        oracle.parallel_fill(host_pk, 128 * w, chunk, seed, threads)
+        dev_pk = _splitmix_on_device(chunk * wpb, seed).view(tdt)
         if k == 0:   # the two generators really are the same stream
-            assert np.array_equal(to_np(dev_pk[:4096], "u32"), host_pk[:4096])
-        vals = fl.BitPacking.unpack(7, dev_pk).view(torch.int32).view(chunk, 1024).to(torch.int64)
+            assert np.array_equal(to_np(dev_pk[:4096], ty), host_pk[:4096])
+        if op == "undelta_pack":
+            host_bases = np.empty(chunk * lanes(ty), dtype=TYPES[ty][0])
+            oracle.parallel_fill(host_bases, 128, chunk, seed + 1000, threads)
+            dev_bases = _splitmix_on_device(chunk * 16, seed + 1000).view(tdt)
+            host_out = oracle.fast(op, ty, w, host_pk, aux=host_bases, n_blocks=chunk, nthreads=threads)
+            out = fl.Delta.undelta_pack(w, dev_pk, dev_bases)
+        else:
+            host_out = oracle.fast(op, ty, w, host_pk, n_blocks=chunk, nthreads=threads)
+            out = fl.BitPacking.unpack(w, dev_pk)
+        s_cpu, w_cpu = oracle.block_hashes(ty, host_out, threads)
+        if ty == "u32":
+            vals = out.view(torch.int32).view(chunk, 1024).to(torch.int64) & 0xFFFFFFFF
+        else:
+            vals = out.view(torch.int64).view(chunk, 1024)
         s_gpu = vals.sum(dim=1)
         w_gpu = (vals * w_idx).sum(dim=1)
         assert np.array_equal(s_gpu.cpu().numpy().view(np.uint64), s_cpu), k
         assert np.array_equal(w_gpu.cpu().numpy().view(np.uint64), w_cpu), k
-        del vals, dev_pk
+        del vals, out, dev_pk
