@@ -58,13 +58,13 @@ template <typename T>
 int dev_for_pack(unsigned w, const T* in, const T* refs, size_t stride, T* out, size_t n, void* s)
 {
     if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
-    return run_stream<T>(pack_table_impl<T, PACK_FOR>().fn[w], in, out, refs, stride ? 1 : 0, n, true, w != 0, true, s);
+    return run_stream<T>(pack_table_impl<T, PACK_FOR>().fn[w], in, out, refs, stride, n, true, w != 0, true, s);
 }
 template <typename T>
 int dev_unfor_pack(unsigned w, const T* in, const T* refs, size_t stride, T* out, size_t n, void* s)
 {
     if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
-    return run_stream<T>(unpack_table_impl<T, BODY_ADD_REF>().fn[w], in, out, refs, stride ? 1 : 0, n, w != 0, true, true, s);
+    return run_stream<T>(unpack_table_impl<T, BODY_ADD_REF>().fn[w], in, out, refs, stride, n, w != 0, true, true, s);
 }
 template <typename T>
 int dev_undelta_pack(unsigned w, const T* in, const T* bases, T* out, size_t n, void* s)

@@ -776,3 +776,25 @@ def test_full_column_content_hash_vs_cpu_oracle(fl, oracle, ty, w, op):
         assert np.array_equal(s_gpu.cpu().numpy().view(np.uint64), s_cpu), k
         assert np.array_equal(w_gpu.cpu().numpy().view(np.uint64), w_cpu), k
         del vals, out, dev_pk
+
+
+def test_for_reference_stride_through_the_c_abi(fl, oracle):
+    """fl_<ty>_for_pack / unfor_pack read references[b * reference_stride]: 0 broadcasts one scalar,
+    1 is one per block, larger strides pick every k-th element (e.g. a struct-of-stats array)."""
+    import ctypes
+    import torch
+    lib = fl.load()
+    n, w = 70, 9
+    v = values("u32", n * 1024, 31)
+    refs3 = values("u32", n * 3, 32)
+    dv, dr = to_dev(v), to_dev(refs3)
+    out = torch.empty(n * packed_len("u32", w), dtype=torch.uint32, device="cuda:0")
+    for stride, eff in ((0, np.full(n, refs3[0])), (1, refs3[:n]), (3, refs3[::3])):
+        rc = lib.fl_u32_for_pack(w, dv.data_ptr(), dr.data_ptr(), stride, out.data_ptr(), n, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(to_np(out, "u32"), oracle.batch("for_pack", "u32", w, v, aux=eff)), stride
+        back = torch.empty(n * 1024, dtype=torch.uint32, device="cuda:0")
+        assert lib.fl_u32_unfor_pack(w, out.data_ptr(), dr.data_ptr(), stride, back.data_ptr(), n, None) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(to_np(back, "u32"), oracle.batch("unfor_pack", "u32", w, to_np(out, "u32"), aux=eff)), stride
