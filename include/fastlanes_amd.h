@@ -146,7 +146,8 @@ const uint64_t *fl_mixed_plan_offsets(const fl_mixed_plan *plan);
     int fl_##S##_block_min_max(const T *in, size_t n_blocks, T *mins, T *maxs, void *stream);    \
     /*   unpack_compare:    bit i of mask[b*32 .. b*32+32) = (unpack::<W>(block b)[i] <op> constant),  \
      *                      i in the unpacked (index) order: a selection vector straight from packed   \
-     *                      data, 128*W bytes in, 128 bytes out per block.  op is an fl_cmp. */       \
+     *                      data, 128*W bytes in, 128 bytes out per block.  op is an fl_cmp (any other    \
+     *                      value: FL_ERR_INDEX). */       \
     int fl_##S##_unpack_compare(unsigned width, const T *in, int op, T constant, size_t n_blocks, \
                                 uint32_t *mask, void *stream);                                  \
     /* Transpose::transpose (transpose.rs:5,11-15) */                                           \
