@@ -134,3 +134,14 @@ def test_python_mirror_rejects_mismatched_buffers():
         fl.BitPacking.pack(3, np.zeros(2048, dtype=np.uint16)[::2])
     with pytest.raises(TypeError):
         fl.Delta.delta(v, np.zeros(64, dtype=np.uint8))
+
+
+def test_headers_are_plain_c_and_cxx17():
+    """include/fastlanes_amd.h must be consumable by a C compiler (cgo / bindgen / ctypes users);
+    the C++ mirror by a plain C++17 compiler without HIP."""
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-fsyntax-only", "-x", "c",
+                           os.path.join(inc, "fastlanes_amd.h")])
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-fsyntax-only", "-x", "c++", "-I", inc,
+                           os.path.join(inc, "fastlanes_amd.hpp")])
