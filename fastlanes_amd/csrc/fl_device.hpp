@@ -182,10 +182,10 @@ __device__ __forceinline__ void store_cell(u32x4* p, const Cell<T>& c)
 // (checked against transpose.rs:29-36 for every T, r, l in tests/test_oracle_properties.py).
 // The thread that owns lanes n*c .. n*c+n-1 for all T rows therefore holds, per lane, one
 // contiguous RUN of T elements (T*sizeof(T) bytes: 8 B for u8 .. 512 B for u64) of the
-// original order, and the permutation is a pure in-register regroup: no LDS, no cross-lane
-// traffic.  So that the run-side global accesses are full 128-byte lines too, the 8 threads
-// of a block exchange 16-byte pieces through a wave-private LDS region
-// (store_lane_runs_lines / load_lane_runs_lines below).
+// original order: the 1024-element permutation needs no shuffle network, only a regroup of
+// registers.  The one thing exchanged between the 8 threads of a block (through a wave-private
+// LDS region, store_lane_runs_lines / load_lane_runs_lines below) is 16-byte pieces of those
+// runs, purely so that the run-side global accesses are full 128-byte lines as well.
 // ---------------------------------------------------------------------------
 __host__ __device__ constexpr unsigned lane_base(unsigned l) { return (l % 16) * 64 + fl_order(l / 16) * 8; }
 
@@ -204,30 +204,34 @@ template <typename T> __device__ __forceinline__ void cell_or(Cell<T>& c, int e,
     else c.x[e / 4] |= (uint32_t)v << (8 * (e % 4));
 }
 
-template <typename T> struct LaneRun {
-    static constexpr int TB = Elem<T>::BITS;
-    static constexpr int N = Elem<T>::PER_CELL;          // FL lanes per thread
-    static constexpr int E = sizeof(T);
-    static constexpr int RUN_BYTES = TB * E;
-    static constexpr int PIECE = RUN_BYTES < 16 ? RUN_BYTES : 16;
-    static constexpr int PIECES = RUN_BYTES / PIECE;
-    static constexpr int PER_PIECE = PIECE / E;          // elements per piece
-    typedef uint32_t piece_t __attribute__((ext_vector_type(PIECE / 4)));
-};
-
-// store_lane_runs_lines: original-order block <- rows[r] (column c of a TRANSPOSED block),
-// the inverse of load_lane_runs, with every global store a FULL 128-byte line.  The 8 threads of a block first exchange 16-byte pieces through a private
-// 1152-byte LDS region (8 line slots, 144-byte stride, for u16 slots 4..7 a further 16 bytes
-// on => conflict-free ds_write_b128 / ds_read_b128 for u16/u32/u64), one "phase" of 8 output lines at a time (sizeof(T) phases per block), then
-// thread c' stores piece c' of each line through `st` (a TileStore over the original-order
-// block).  Only lanes of the same wavefront touch a region: LDS operations of one wave execute
-// in order, so a compiler-level fence is all the synchronisation needed (no s_barrier).
+// store_lane_runs_lines: original-order block <- rows[r] (column c of a TRANSPOSED block), the
+// inverse of load_lane_runs_lines, with every global store a FULL 128-byte line.  The 8 threads
+// of a block exchange 16-byte pieces through a private 1152-byte LDS region: 8 line slots with a
+// 144-byte stride (for u16, slots 4..7 sit a further 16 bytes on), which makes ds_write_b128 /
+// ds_read_b128 conflict-free for u16/u32/u64.  One "phase" moves 8 output lines; a block has
+// 8*sizeof(T) lines, hence sizeof(T) phases.  After the exchange thread c' stores piece c' of
+// each line through `st` (a TileStore over the original-order block).  Only lanes of the same
+// wavefront touch a region and the LDS operations of one wave execute in order, so a
+// compiler-level fence is all the synchronisation needed (no s_barrier).
 template <typename T> struct RunExchange {
     static constexpr int E = sizeof(T);
     static constexpr int PHASES = E;          // 8E lines per block, 8 per phase
     static constexpr int LS = 144;            // padded line stride in LDS
     static constexpr int BLOCK_BYTES = 8 * LS;
     static constexpr int WAVE_BYTES = 8 * BLOCK_BYTES;
+    // LDS offset of line slot s inside a block's region
+    __host__ __device__ static constexpr unsigned slot_base(int s) { return s * LS + (E == 2 ? 16 * (s / 4) : 0); }
+    // byte offset, inside the ORIGINAL-order block, of the 128-byte line that slot s holds in phase p
+    //   u64: phase = (lane e = p/4, quarter q = p%4) of the slot's thread s -> lane_base(2s+e)*8 + 128q
+    //   u32: phase = lane e = p of thread s                                 -> lane_base(4s+p)*4
+    //   u16: lines 8*(s/4) + 4p + s%4 (four 32-byte runs each);   u8: line s (sixteen 8-byte runs)
+    __host__ __device__ static constexpr unsigned line_of(int p, int s)
+    {
+        return E == 8 ? (unsigned)((2 * s + p / 4) * 512 + 128 * (p % 4))
+             : E == 4 ? (unsigned)(((4 * s + p) % 16) * 256 + ((4 * s + p) / 16) * 128)
+             : E == 2 ? (unsigned)((8 * (s / 4) + 4 * p + s % 4) * 128)
+                      : (unsigned)(s * 128);
+    }
 };
 
 __device__ __forceinline__ void wave_lds_fence()
@@ -294,14 +298,8 @@ __device__ __forceinline__ void store_lane_runs_lines(char* lds_blk, unsigned c,
         wave_lds_fence();
         static_for<8>([&](auto S) {
             constexpr int s = decltype(S)::value;
-            const u32x4 piece = *reinterpret_cast<const u32x4*>(lds_blk + s * X::LS + (E == 2 ? 16 * (s / 4) : 0) + 16 * c);
-            // byte address of this slot's line inside the original-order block
-            constexpr unsigned line =
-                E == 8 ? (unsigned)((2 * s + p / 4) * 512 + 128 * (p % 4)) :
-                E == 4 ? (unsigned)(((4 * s + p) % 16) * 256 + ((4 * s + p) / 16) * 128) :
-                E == 2 ? (unsigned)((8 * (s / 4) + 4 * p + s % 4) * 128) :
-                         (unsigned)(s * 128);
-            st.store(line / 16, __builtin_bit_cast(Cell<T>, piece));   // st already adds this thread's 16*c
+            const u32x4 piece = *reinterpret_cast<const u32x4*>(lds_blk + X::slot_base(s) + 16 * c);
+            st.store(X::line_of(p, s) / 16, __builtin_bit_cast(Cell<T>, piece));   // st adds this thread's 16*c
         });
         wave_lds_fence();
     });
@@ -322,20 +320,14 @@ __device__ __forceinline__ void load_lane_runs_lines(char* lds_blk, unsigned c, 
         constexpr int p = decltype(P)::value;
         static_for<8>([&](auto S) {
             constexpr int s = decltype(S)::value;
-            constexpr unsigned line =
-                E == 8 ? (unsigned)((2 * s + p / 4) * 512 + 128 * (p % 4)) :
-                E == 4 ? (unsigned)(((4 * s + p) % 16) * 256 + ((4 * s + p) / 16) * 128) :
-                E == 2 ? (unsigned)((8 * (s / 4) + 4 * p + s % 4) * 128) :
-                         (unsigned)(s * 128);
-            lines[p][s] = __builtin_nontemporal_load(blk_cells + line / 16 + c);
+            lines[p][s] = __builtin_nontemporal_load(blk_cells + X::line_of(p, s) / 16 + c);
         });
     });
     static_for<TB>([&](auto R) { rows[decltype(R)::value] = Cell<T>::zero(); });
     static_for<X::PHASES>([&](auto P) {
         constexpr int p = decltype(P)::value;
         static_for<8>([&](auto S) {
-            *reinterpret_cast<u32x4*>(lds_blk + decltype(S)::value * X::LS + (E == 2 ? 16 * (decltype(S)::value / 4) : 0) + 16 * c) =
-                lines[p][decltype(S)::value];
+            *reinterpret_cast<u32x4*>(lds_blk + X::slot_base(decltype(S)::value) + 16 * c) = lines[p][decltype(S)::value];
         });
         wave_lds_fence();
         if constexpr (E >= 4) {
