@@ -369,6 +369,10 @@ int main(int argc, char** argv)
     }
     addX("cell-column + LDS wave-contig stores maxw2", k_unpack_cc_wavestore<uint32_t, 7, 18, 2>, G, a, bytes, 0);
     addX("cell-column + LDS wave-contig stores maxw3", k_unpack_cc_wavestore<uint32_t, 7, 18, 3>, G, a, bytes, 0);
+    addX("cell-column + LDS wave-contig stores maxw4", k_unpack_cc_wavestore<uint32_t, 7, 18, 4>, G, a, bytes, 0);
+    addX("cell-column + LDS wave-contig stores maxw5", k_unpack_cc_wavestore<uint32_t, 7, 18, 5>, G, a, bytes, 0);
+    addX("cell-column + LDS wave-contig stores maxw8", k_unpack_cc_wavestore<uint32_t, 7, 18, 8>, G, a, bytes, 0);
+    addX("cell-column + LDS wave-contig stores maxw3 (again)", k_unpack_cc_wavestore<uint32_t, 7, 18, 3>, G, a, bytes, 0);
     addX("cell-column G st18 maxw2 addr-order (again)", k_unpack_x<uint32_t, 7, 18, -1, 2, 1>, G, a, bytes, 0);
     const uint64_t n_thr = n * 8;
     auto addS = [&](const char* name, auto kern, double by) {
