@@ -154,6 +154,24 @@ def main():
     if args.cases == "host":
         host_tier()
         return
+    if args.cases == "small":
+        # launch-bound regime: one call per small array (e.g. a 64 Ki-value chunk = 64 blocks)
+        for nb in (1, 8, 64, 512, 4096, 32768, 262144):
+            pk = rnd(nb * 896, 1).view(torch.uint32)
+            out = torch.empty(nb * 1024, dtype=torch.uint32, device=dev)
+            for _ in range(20):
+                fl.BitPacking.unpack(7, pk, output=out)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 200
+            a.record()
+            for _ in range(reps):
+                fl.BitPacking.unpack(7, pk, output=out)
+            b.record(); b.synchronize()
+            us = a.elapsed_time(b) * 1e3 / reps
+            print(f"unpack u32 W=7 n_blocks={nb:>7d}: {us:9.2f} us per call (back-to-back on one stream)  "
+                  f"{nb * 1024 / us / 1e3:9.2f} Gint/s  {nb * 4992 / us / 1e3:8.1f} GB/s", flush=True)
+        return
     if args.cases == "single":
         # batched unpack_single (random access): 64 M random indices into a 1 M-block u32 W=7 column
         n, k = 1_000_000, 64_000_000
