@@ -123,9 +123,13 @@ def _run(method, ty, width, src, out, n_blocks, aux=None, aux_stride=None, scala
     args += [out.ptr, n_blocks]
     if dev:
         import torch
-        with torch.cuda.device(src.x.device):
+        if src.x.device.index == torch.cuda.current_device():   # common case: skip the device context switch
             args.append(_stream(src))
             rc = fn(*args)
+        else:
+            with torch.cuda.device(src.x.device):
+                args.append(_stream(src))
+                rc = fn(*args)
     else:
         rc = fn(*args)
     _check(rc, f"fl_{ty}_{method}")
