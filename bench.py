@@ -7,14 +7,25 @@ resident in HBM, output materialised to HBM.  With --gpus N every rank decodes
 its own 10 M-block column on its own GPU (block-range sharding, no collective
 on the data path): weak scaling, value = N * 10.24 G integers / max-over-ranks time.
 
-Prints ONE JSON line on rank 0 (see the task contract): metric/value/unit,
-`roofline` (live HIP-event timing of the kernel vs the 8 TB/s HBM peak) and
-`cpu_baseline` (the oracle's auto-vectorised C restatement of the reference's
-scalar loop, timed on this box's host cores on a bounded sample).
+`python bench.py --gpus N` with no torchrun environment SPAWNS the N ranks itself
+(one process per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, RCCL barrier and
+max-over-ranks time); under `python -m torch.distributed.run ... bench.py --gpus N`
+it is one of the N ranks.  Either way rank 0 prints ONE JSON line.
+
+After the headline leg the same processes time BASELINE.json configs[4] --
+u32, width[b] = 1 + b mod 32, the 10 B-integer column (9 765 625 blocks) sharded
+by contiguous block range over the N GPUs, widths / offsets device-resident --
+and report it STRONG-scaled under "config5_strong" (per-rank GB/s included).
+
+The line also carries `roofline` (live HIP-event timing of the kernel vs the
+8 TB/s HBM peak, PMC traffic) and, at N=1, `cpu_baseline` (the oracle's
+auto-vectorised C restatement of the reference's scalar loop, timed on this
+box's host cores on a bounded sample).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,6 +34,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_CEILING_GBPS = 6290.0  # same table: measured float4-copy ceiling
+CONFIG5_BLOCKS = 9_765_625      # 10 B integers / 1024 (BASELINE.json configs[4])
 
 WORKLOADS = {
     # name: (type, width, op, bytes per block = SURVEY.md 8(d): 128*W + 128*T [+128 bases])
@@ -35,6 +47,8 @@ WORKLOADS = {
     # BASELINE.json configs[4]: width[b] = 1 + b % 32; bytes per block averaged over the 32 widths
     "u32_mixed_unpack": ("u32", None, "unpack_mixed", 128 * 16.5 + 128 * 32),
 }
+TORCH_DT = {"u8": "uint8", "u16": "uint16", "u32": "uint32", "u64": "uint64"}
+ESZ = {"u8": 1, "u16": 2, "u32": 4, "u64": 8}
 
 
 def parse():
@@ -48,12 +62,46 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="CPU baseline time budget per leg")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 PMC passes (roofline.traffic "
                     "then comes from profiles/pmc_traffic.json, or is null)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the strong-scaled mixed-width leg")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier / max-time "
                     "reduction (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--single-device", action="store_true",
                     help="plumbing test: put every rank on cuda:0 (use with --backend gloo)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher plumbing only, no GPU: spawn / rendezvous / barrier / max-reduce / sharding run for "
+                         "real, the codec step is skipped and the line says so (value null) -- never a measurement")
     return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------
+# launcher: `bench.py --gpus N` without a torchrun environment spawns its own N ranks
+# ---------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            if r != 0 and rc == 0:
+                rc = r
+                for q in live:            # a dead rank leaves the others in a barrier: stop exactly our children
+                    q.terminate()
+    return rc
 
 
 def rand_u8(nbytes, seed, dev):
@@ -65,6 +113,17 @@ def rand_u8(nbytes, seed, dev):
     return torch.randint(-2**63, 2**63 - 1, (n8,), dtype=torch.int64, device=dev, generator=g).view(torch.uint8)[:nbytes]
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(args, ty, width, op):
     """Oracle 'fast' family (C restatement, gcc -O3, lane loop auto-vectorised) on host cores."""
     import numpy as np
@@ -73,24 +132,41 @@ def cpu_baseline(args, ty, width, op):
     from oracle_lib import lanes, load_native_oracle, packed_len
     o, cflags = load_native_oracle()
     n = 524288  # blocks: 537 M integers; u32 W=7: 470 MB in + 2.1 GB out (DRAM-resident)
-    pl = packed_len(ty, width)
     cores = os.cpu_count() or 1
-    npdt = values(ty, 1, 0).dtype
-    esz = npdt.itemsize
-    in_elems, out_elems = (1024, pl) if op == "pack" else (pl, 1024)
-    # random input / output pages first-touched by the thread that will stream them (NUMA placement)
-    src = o.parallel_fill(np.empty(n * in_elems, dtype=npdt), in_elems * esz, n, 7, cores)
-    out = o.parallel_fill(np.empty(n * out_elems, dtype=npdt), out_elems * esz, n, 9, cores)
-    aux = o.parallel_fill(np.empty(n * lanes(ty), dtype=npdt), 128, n, 8, cores) if op == "undelta_pack" else None
     res = {}
+    if op == "unpack_mixed":
+        # the reference's caller loop over per-block widths (bitpacking.rs:109-129), width[b] = 1 + b mod 32
+        widths = (1 + np.arange(n, dtype=np.int64) % 32).astype(np.uint8)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(widths.astype(np.uint64) * np.uint64(128), out=off[1:])
+        # one fill per 32-block period keeps every thread's pages first-touched by (roughly) its own range
+        src = o.parallel_fill(np.empty(int(off[-1]) // 4, dtype=np.uint32), int(off[32]), n // 32, 7, cores)
+        out = o.parallel_fill(np.empty(n * 1024, dtype=np.uint32), 4096, n, 9, cores)
+
+        def run(nt):
+            o.fast_unpack_mixed_u32(widths, off[:-1], src, n_blocks=n, nthreads=nt, out=out)
+        what = f"unpack u32 width[b] = 1 + b mod 32 (caller loop over per-block widths), {n} blocks"
+    else:
+        pl = packed_len(ty, width)
+        npdt = values(ty, 1, 0).dtype
+        esz = npdt.itemsize
+        in_elems, out_elems = (1024, pl) if op == "pack" else (pl, 1024)
+        # random input / output pages first-touched by the thread that will stream them (NUMA placement)
+        src = o.parallel_fill(np.empty(n * in_elems, dtype=npdt), in_elems * esz, n, 7, cores)
+        out = o.parallel_fill(np.empty(n * out_elems, dtype=npdt), out_elems * esz, n, 9, cores)
+        aux = o.parallel_fill(np.empty(n * lanes(ty), dtype=npdt), 128, n, 8, cores) if op == "undelta_pack" else None
+
+        def run(nt):
+            o.fast(op, ty, width, src, aux=aux, n_blocks=n, nthreads=nt, out=out)
+        what = f"{op} {ty} W={width}, {n} blocks"
     for label, nt in (("single_thread", 1), ("all_cores", cores)):
-        o.fast(op, ty, width, src, aux=aux, n_blocks=n, nthreads=nt, out=out)  # warm (page faults)
+        run(nt)  # warm (page faults)
         best = None
         t_end = time.time() + args.cpu_seconds
         reps = 0
         while time.time() < t_end or reps < 2:
             t0 = time.perf_counter()
-            o.fast(op, ty, width, src, aux=aux, n_blocks=n, nthreads=nt, out=out)
+            run(nt)
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
             reps += 1
@@ -119,47 +195,154 @@ def cpu_baseline(args, ty, width, op):
         "value": round(res["all_cores"], 3),
         "unit": "Gint/s",
         "cores": cores,
+        "cpu_model": cpu_model(),
         "kind": "port",
         "single_thread_value": round(res["single_thread"], 3),
-        "sample": f"{op} {ty} W={width}, {n} blocks ({n * 1024 / 1e6:.0f} M ints, DRAM-resident), "
+        "sample": f"{what} ({n * 1024 / 1e6:.0f} M ints, DRAM-resident), "
                   f"best of repeated passes over ~{args.cpu_seconds:.0f} s per leg; oracle/ C restatement of the "
                   "reference scalar loop (gcc -O3 " + cflags + ", lane loop auto-vectorised), not the Rust crate",
     }
+
+
+# ---------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------
+class Workload:
+    """One rank's share of a workload: device buffers + step()."""
+
+    def __init__(self, name, n, first_block, rank, dev):
+        import torch
+        import fastlanes_amd as fl
+        self.name = name
+        self.ty, self.width, self.op, _ = WORKLOADS[name]
+        self.n = n
+        ty, width, op = self.ty, self.width, self.op
+        tdt = getattr(torch, TORCH_DT[ty])
+        esz = ESZ[ty]
+        un_bytes = 1024 * esz
+        self.bases = None
+        if op == "unpack_mixed":
+            # widths and offsets are DEVICE arrays, built on the device: nothing about the column touches the host
+            self.widths = (1 + (torch.arange(n, dtype=torch.int64, device=dev) + first_block) % 32).to(torch.uint8)
+            self.offsets, total = fl.widths_to_offsets(ty, self.widths)
+            packed_bytes = int(total.item())
+            self.src = rand_u8(packed_bytes, 1234 + rank, dev).view(tdt)
+            self.dst = torch.empty(n * 1024, dtype=tdt, device=dev)
+            self.in_bytes, self.out_bytes = packed_bytes, n * un_bytes          # per launch
+            self.step = lambda: fl.unpack_widths(self.widths, self.offsets, self.src, output=self.dst, check=False)
+        else:
+            pl_bytes = 128 * width
+            ib, ob = (un_bytes, pl_bytes) if op == "pack" else (pl_bytes, un_bytes)
+            self.src = rand_u8(n * ib, 1234 + rank, dev).view(tdt)
+            self.dst = torch.empty(n * ob // esz, dtype=tdt, device=dev)
+            self.in_bytes, self.out_bytes = n * ib, n * ob
+            if op == "undelta_pack":
+                self.bases = rand_u8(n * 128, 99 + rank, dev).view(tdt)
+                self.in_bytes += n * 128
+                self.step = lambda: fl.Delta.undelta_pack(width, self.src, self.bases, output=self.dst)
+            elif op == "unpack":
+                self.step = lambda: fl.BitPacking.unpack(width, self.src, output=self.dst)
+            else:
+                self.step = lambda: fl.BitPacking.pack(width, self.src, output=self.dst)
+        self.bytes = self.in_bytes + self.out_bytes      # algorithmic bytes per launch (SURVEY.md 8(d))
+
+    def check_against_oracle(self):
+        """Sampled blocks of what was just timed vs the oracle (rank 0, N=1, outside the timed region)."""
+        import numpy as np
+        import torch
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle_lib import load_oracle
+        o = load_oracle()
+        ty, width, op, n = self.ty, self.width, self.op, self.n
+        esz = ESZ[ty]
+        npdt = {"u8": np.uint8, "u16": np.uint16, "u32": np.uint32, "u64": np.uint64}[ty]
+
+        def host(t):
+            return t.view(torch.uint8).cpu().numpy().view(npdt)
+        ok = True
+        for b in sorted({0, 1, 31, 32, n // 2, n - 2, n - 1}):
+            if op == "unpack_mixed":
+                w = int(self.widths[b].item())
+                lo = int(self.offsets[b].item()) // esz
+                want = o.unpack(ty, w, host(self.src[lo:lo + 1024 * w // (8 * esz)]))
+                got = host(self.dst[b * 1024:(b + 1) * 1024])
+            else:
+                ipb, opb = self.src.numel() // n, self.dst.numel() // n
+                s = host(self.src[b * ipb:(b + 1) * ipb])
+                got = host(self.dst[b * opb:(b + 1) * opb])
+                if op == "unpack":
+                    want = o.unpack(ty, width, s)
+                elif op == "pack":
+                    want = o.pack(ty, width, s)
+                else:
+                    want = o.undelta_pack(ty, width, s, host(self.bases[b * (128 // esz):(b + 1) * (128 // esz)]))
+            ok = ok and bool(np.array_equal(got, want))
+        return "bit-exact vs oracle on 7 sampled blocks" if ok else "MISMATCH vs oracle"
+
+
+def timed_region(step, args, dist_ctx):
+    """W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides;
+    returns (max-over-ranks wall seconds, this rank's per-launch HIP-event milliseconds)."""
+    import torch
+    world, reduce_dev, dist = dist_ctx
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record()   # HIP events on torch's current stream == the stream the kernel is launched on
+        step()
+        b.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = [a.elapsed_time(b) for a, b in evs]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, kern_ms
+
+
+def gather_per_rank(vals, dist_ctx):
+    """[[vals of rank 0], [vals of rank 1], ...] on every rank."""
+    import torch
+    world, reduce_dev, dist = dist_ctx
+    t = torch.tensor(vals, dtype=torch.float64, device=reduce_dev)
+    if world == 1:
+        return [t.tolist()]
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [o.tolist() for o in out]
+
+
+# ---------------------------------------------------------------------------------------------
+# PMC traffic (N=1): the workload's kernel re-run under rocprofv3, separate passes per counter
+# ---------------------------------------------------------------------------------------------
+PMC_CAL_BYTES = 2 << 30
 
 
 def pmc_child(args):
     """Body of the rocprofv3 --pmc passes: a calibration copy of known size, then 3 launches of the
     workload's kernel.  No timing, no oracle."""
     import torch
-    import fastlanes_amd as fl
     dev = torch.device("cuda", 0)
-    ty, width, op, _ = WORKLOADS[args.workload]
-    tdt = {"u8": torch.uint8, "u16": torch.uint16, "u32": torch.uint32, "u64": torch.uint64}[ty]
-    esz = {"u8": 1, "u16": 2, "u32": 4, "u64": 8}[ty]
     a = rand_u8(PMC_CAL_BYTES, 5, dev)
     b = torch.empty_like(a)
     for _ in range(3):
         b.copy_(a)                                   # known traffic: PMC_CAL_BYTES read + written
     torch.cuda.synchronize()
     del a, b
-    n = args.blocks
-    if op == "unpack_mixed":
-        return
-    in_b, out_b = (1024 * esz, 128 * width) if op == "pack" else (128 * width, 1024 * esz)
-    src = rand_u8(n * in_b, 6, dev).view(tdt)
-    dst = torch.empty(n * out_b // esz, dtype=tdt, device=dev)
-    bases = rand_u8(n * 128, 7, dev).view(tdt) if op == "undelta_pack" else None
+    n = CONFIG5_BLOCKS if (WORKLOADS[args.workload][2] == "unpack_mixed" and args.blocks == 10_000_000) else args.blocks
+    w = Workload(args.workload, n, 0, 0, dev)
     for _ in range(3):
-        if op == "unpack":
-            fl.BitPacking.unpack(width, src, output=dst)
-        elif op == "pack":
-            fl.BitPacking.pack(width, src, output=dst)
-        else:
-            fl.Delta.undelta_pack(width, src, bases, output=dst)
+        w.step()
     torch.cuda.synchronize()
-
-
-PMC_CAL_BYTES = 2 << 30
 
 
 def live_pmc_traffic(args):
@@ -170,7 +353,6 @@ def live_pmc_traffic(args):
     import csv
     import glob
     import shutil
-    import subprocess
     import tempfile
     if shutil.which("rocprofv3") is None:
         return None
@@ -181,7 +363,8 @@ def live_pmc_traffic(args):
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
                    sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload,
                    "--blocks", str(args.blocks)]
-            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=120,
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+            subprocess.run(cmd, cwd="/tmp", env=dict(env, TMPDIR="/tmp"), timeout=180,
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             cal, ker = [], []
@@ -190,7 +373,7 @@ def live_pmc_traffic(args):
                     continue
                 v = float(r["Counter_Value"]) * 1024.0
                 name = r["Kernel_Name"]
-                if "fl::k_" in name:
+                if "fl::k_" in name and "k_scan" not in name:
                     ker.append(v)
                 elif v > 0.25 * PMC_CAL_BYTES and ("copy" in name.lower() or "elementwise" in name.lower()) \
                         and "distribution" not in name:
@@ -209,128 +392,147 @@ def live_pmc_traffic(args):
         return None
 
 
+def roofline(w, kern_ms, traffic=None, traffic_source=None):
+    avg_s = sum(kern_ms) / len(kern_ms) / 1e3
+    achieved = w.bytes / avg_s / 1e9
+    return {
+        "bound": "hbm",
+        "achieved": round(achieved, 1),
+        "peak": HBM_PEAK_GBPS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBPS, 4),
+        "traffic": traffic,
+        "traffic_source": traffic_source if traffic is not None else None,
+        "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBPS, 4),
+        "algorithmic_bytes_per_launch": int(w.bytes),
+        "kernel_ms_avg": round(avg_s * 1e3, 4),
+        "kernel_ms_min": round(min(kern_ms), 4),
+        "read_GBps": round(w.in_bytes / avg_s / 1e9, 1),
+        "write_GBps": round(w.out_bytes / avg_s / 1e9, 1),
+        "timing": "HIP events on the launch stream around each of the K launches (rank 0)",
+    }
+
+
+def config5_leg(args, world, rank, dev, dist_ctx):
+    """BASELINE.json configs[4], STRONG scaling: the 10 B-integer u32 column (9 765 625 blocks, width[b] = 1 + b mod 32)
+    sharded by contiguous block range over the ranks (no collective on the data path)."""
+    from fastlanes_amd.sharding import block_range
+    first, n = block_range(CONFIG5_BLOCKS, world, rank)
+    if args.dry_run:
+        per_rank = gather_per_rank([float(n), 0.0, 0.0], dist_ctx)
+        return {"dry_run": True, "per_rank": [{"rank": r, "first_block": block_range(CONFIG5_BLOCKS, world, r)[0],
+                                               "blocks": int(v[0])} for r, v in enumerate(per_rank)]}
+    w = Workload("u32_mixed_unpack", n, first, rank, dev)
+    elapsed, kern_ms = timed_region(w.step, args, dist_ctx)
+    avg_ms = sum(kern_ms) / len(kern_ms)
+    per_rank = gather_per_rank([float(n), avg_ms, float(w.bytes)], dist_ctx)
+    check = w.check_against_oracle() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    if rank != 0:
+        return None
+    ranks = [{"rank": r, "first_block": block_range(CONFIG5_BLOCKS, world, r)[0], "blocks": int(v[0]),
+              "kernel_ms_avg": round(v[1], 4), "GBps": round(v[2] / (v[1] / 1e3) / 1e9, 1),
+              "frac": round(v[2] / (v[1] / 1e3) / 1e9 / HBM_PEAK_GBPS, 4)} for r, v in enumerate(per_rank)]
+    return {
+        "metric": "billion integers/sec decoded (u32 mixed widths 1-32, 10 B-integer column sharded over the GPUs)",
+        "workload": "unpack u32 width[b] = 1 + b mod 32, 9 765 625 blocks in total (BASELINE.json configs[4]); widths[] / "
+                    "offsets[] device-resident, one launch per rank per step, contiguous block range per GPU, no collective",
+        "value": round(CONFIG5_BLOCKS * 1024 * args.steps / elapsed / 1e9, 2),
+        "unit": "Gint/s",
+        "scaling": "strong",
+        "n_gpus": world,
+        "steps": args.steps,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "aggregate_GBps": round(sum(v[2] for v in per_rank) * args.steps / elapsed / 1e9, 1),
+        "per_rank": ranks,
+        "roofline_rank0": roofline(w, kern_ms),
+        "correctness": check,
+    }
+
+
 def main():
     args = parse()
     if args.pmc_child:
         return pmc_child(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; running {world} ranks", file=sys.stderr)
     if args.single_device:
         local_rank = 0
+    if args.dry_run:
+        dev = torch.device("cpu")
+        if args.backend == "nccl":
+            args.backend = "gloo"
+    else:
+        if not torch.cuda.is_available():
+            sys.exit("bench.py needs a GPU (there is no CPU path); --dry-run only exercises the launcher")
+        if local_rank >= torch.cuda.device_count():
+            sys.exit(f"rank {rank}: cuda:{local_rank} does not exist ({torch.cuda.device_count()} devices visible)")
+        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
-    torch.cuda.set_device(dev)
+    reduce_dev = dev if (args.backend == "nccl" and not args.dry_run) else torch.device("cpu")
+    dist_ctx = (world, reduce_dev, dist)
+
+    ty, width, op, _ = WORKLOADS[args.workload]
+    strong_main = op == "unpack_mixed" and args.blocks == 10_000_000
+    n, first = args.blocks, rank * args.blocks
+    if strong_main:   # BASELINE.json configs[4]: 10 B integers in total, sharded by block range
+        from fastlanes_amd.sharding import block_range
+        first, n = block_range(CONFIG5_BLOCKS, world, rank)
+
+    if args.dry_run:
+        # plumbing only: the same barrier / max-reduce / gather calls, no codec work, no number
+        t0 = time.perf_counter()
+        if world > 1:
+            dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        per_rank = gather_per_rank([float(rank), float(n)], dist_ctx)
+        c5 = None if (args.no_config5 or strong_main) else config5_leg(args, world, rank, dev, dist_ctx)
+        if rank == 0:
+            print(json.dumps({"metric": "DRY RUN (no GPU work): launcher / rendezvous / sharding plumbing only",
+                              "value": None, "unit": "Gint/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "dry_run": True, "ranks": [int(v[0]) for v in per_rank],
+                              "blocks_per_rank": [int(v[1]) for v in per_rank], "config5_strong": c5}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     import fastlanes_amd as fl
     fl.load()  # fails loudly if the HIP extension is missing
 
-    ty, width, op, bytes_per_block = WORKLOADS[args.workload]
-    n = args.blocks
-    tdt = {"u8": torch.uint8, "u16": torch.uint16, "u32": torch.uint32, "u64": torch.uint64}[ty]
-    esz = {"u8": 1, "u16": 2, "u32": 4, "u64": 8}[ty]
-    un_bytes = 1024 * esz
-    plan = None
-    if op == "unpack_mixed":
-        import numpy as np
-        first = rank * n
-        if args.blocks == 10_000_000:
-            # BASELINE.json configs[4]: 10 B integers = 9 765 625 blocks in total, sharded by block range
-            from fastlanes_amd.sharding import block_range
-            first, n = block_range(9_765_625, world, rank)
-        widths = (1 + (np.arange(n, dtype=np.int64) + first) % 32).astype(np.uint8)
-        plan = fl.MixedWidthPlan(ty, widths)
-        src = rand_u8(plan.packed_bytes, 1234 + rank, dev).view(tdt)
-        dst = torch.empty(n * 1024, dtype=tdt, device=dev)
-        in_bytes, out_bytes = plan.packed_bytes / n, un_bytes
-        bytes_per_block = in_bytes + out_bytes
-    else:
-        pl_bytes = 128 * width
-        in_bytes, out_bytes = (un_bytes, pl_bytes) if op == "pack" else (pl_bytes, un_bytes)
-        src = rand_u8(n * in_bytes, 1234 + rank, dev).view(tdt)
-        dst = torch.empty(n * out_bytes // esz, dtype=tdt, device=dev)
-    bases = rand_u8(n * 128, 99 + rank, dev).view(tdt) if op == "undelta_pack" else None
-
-    def step():
-        if op == "unpack_mixed":
-            plan.unpack(src, output=dst)
-        elif op == "unpack":
-            fl.BitPacking.unpack(width, src, output=dst)
-        elif op == "pack":
-            fl.BitPacking.pack(width, src, output=dst)
-        else:
-            fl.Delta.undelta_pack(width, src, bases, output=dst)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-
-    # ---- timed region: barrier + sync on both sides, exactly K steps -----------------
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for a, b in evs:
-        a.record()   # HIP events on torch's current stream == the stream the kernel is launched on
-        step()
-        b.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    kern_ms = [a.elapsed_time(b) for a, b in evs]
-
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    w = Workload(args.workload, n, first, rank, dev)
+    elapsed, kern_ms = timed_region(w.step, args, dist_ctx)
+    avg_ms = sum(kern_ms) / len(kern_ms)
+    per_rank = gather_per_rank([float(n), avg_ms, float(w.bytes)], dist_ctx)
 
     # ---- rank 0, N=1: the cpu_baseline leg (the only place bench.py touches oracle/) also
     # ---- checks sampled blocks of what was just timed against the oracle, outside the timed region
-    check = None
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and op != "unpack_mixed":
-        import numpy as np
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from oracle_lib import load_oracle
-        o = load_oracle()
-        npdt = {"u8": np.uint8, "u16": np.uint16, "u32": np.uint32, "u64": np.uint64}[ty]
-        ok = True
-        ipb, opb = in_bytes // esz, out_bytes // esz
-        for b in sorted({0, 1, 31, 32, n // 2, n - 2, n - 1}):
-            s = src[b * ipb:(b + 1) * ipb].view(torch.uint8).cpu().numpy().view(npdt)
-            d = dst[b * opb:(b + 1) * opb].view(torch.uint8).cpu().numpy().view(npdt)
-            if op == "unpack":
-                want = o.unpack(ty, width, s)
-            elif op == "pack":
-                want = o.pack(ty, width, s)
-            else:
-                bb = bases[b * (128 // esz):(b + 1) * (128 // esz)].view(torch.uint8).cpu().numpy().view(npdt)
-                want = o.undelta_pack(ty, width, s, bb)
-            ok = ok and bool(np.array_equal(d, want))
-        check = "bit-exact vs oracle on 7 sampled blocks" if ok else "MISMATCH vs oracle"
+    check = cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        check = w.check_against_oracle()
         cpu = cpu_baseline(args, ty, width, op)
 
+    out = None
     if rank == 0:
-        ints = n * 1024 * world
-        if op == "unpack_mixed" and args.blocks == 10_000_000:
-            ints = 9_765_625 * 1024    # strong scaling: the whole column, however it is sharded
+        ints = CONFIG5_BLOCKS * 1024 if strong_main else n * 1024 * world
         value = ints * args.steps / elapsed / 1e9
-        avg_kernel_s = sum(kern_ms) / len(kern_ms) / 1e3
-        achieved = n * bytes_per_block / avg_kernel_s / 1e9
-        traffic = None
-        traffic_source = None
-        if world == 1 and not args.no_pmc and op != "unpack_mixed":
+        traffic = traffic_source = None
+        if world == 1 and not args.no_pmc:
             live = live_pmc_traffic(args)
             if live is not None:
                 traffic = int(live["bytes"])
@@ -346,6 +548,13 @@ def main():
                     traffic = traffic * n / 10_000_000
             except Exception:
                 traffic = None
+        if args.workload == "u32_w7_unpack":
+            workload = f"{op} {ty} W={width}, {n} blocks x 1024 values per GPU (BASELINE.json configs[1])"
+        elif op == "unpack_mixed":
+            workload = (f"{op} {ty} width[b] = 1 + b mod 32 (BASELINE.json configs[4]), widths[]/offsets[] device-resident, "
+                        f"{n} blocks on rank 0" + (f" of {CONFIG5_BLOCKS} in total" if strong_main else " per GPU"))
+        else:
+            workload = f"{op} {ty} W={width}, {n} blocks per GPU"
         out = {
             # BASELINE.json "metric", verbatim, for the headline workload
             "metric": "billion integers/sec decoded (u32 width-7) + achieved HBM GB/s vs peak, 1-8 GPU"
@@ -358,41 +567,36 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "strong" if op == "unpack_mixed" and args.blocks == 10_000_000 else "weak",
+            "scaling": "strong" if strong_main else "weak",
             "vs_baseline": None,
             "dtype": ty,
             "data": "synthetic (uniform random packed bits, generated on device; inputs resident in HBM)",
-            "config": {"workload": f"{op} {ty} W={width}, {n} blocks x 1024 values per GPU "
-                                   f"(BASELINE.json configs[1])" if args.workload == "u32_w7_unpack"
-                                   else (f"{op} {ty} width[b] = 1 + b mod 32 (BASELINE.json configs[4]), {n} blocks per GPU"
-                                         if op == "unpack_mixed" else f"{op} {ty} W={width}, {n} blocks per GPU"),
-                       "blocks_per_gpu": n, "sharding": "contiguous block range per GPU, no collective"},
-            "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": traffic,
-                "traffic_source": traffic_source if traffic is not None else None,
-                "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBPS, 4),
-                "algorithmic_bytes_per_launch": n * bytes_per_block,
-                "kernel_ms_avg": round(avg_kernel_s * 1e3, 4),
-                "kernel_ms_min": round(min(kern_ms), 4),
-                "read_GBps": round(n * in_bytes / avg_kernel_s / 1e9, 1),
-                "write_GBps": round(n * out_bytes / avg_kernel_s / 1e9, 1),
-                "timing": "HIP events on the launch stream around each of the K launches (rank 0)",
-            },
+            "config": {"workload": workload, "blocks_per_gpu": n, "sharding": "contiguous block range per GPU, no collective"},
+            "roofline": roofline(w, kern_ms, traffic, traffic_source),
+            "per_rank": [{"rank": r, "blocks": int(v[0]), "kernel_ms_avg": round(v[1], 4),
+                          "GBps": round(v[2] / (v[1] / 1e3) / 1e9, 1)} for r, v in enumerate(per_rank)],
             "correctness": check,
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out), flush=True)
-        if check and "MISMATCH" in check:
-            sys.exit(1)
 
+    # ---- second leg: BASELINE.json configs[4] strong-scaled over the same ranks ------------------
+    if not args.no_config5 and not strong_main:
+        import torch
+        del w
+        torch.cuda.empty_cache()
+        c5 = config5_leg(args, world, rank, dev, dist_ctx)
+        if rank == 0:
+            out["config5_strong"] = c5
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if rank == 0:
+        bad = [c for c in (out.get("correctness"), (out.get("config5_strong") or {}).get("correctness")) if c and "MISMATCH" in c]
+        if bad:
+            sys.exit(1)
 
 
 if __name__ == "__main__":

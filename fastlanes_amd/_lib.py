@@ -40,6 +40,8 @@ def _signatures(ty):
         "unpack_compare": [_U, _P, ctypes.c_int, c, _Z, _P, _P],
         "unpack_mixed": [_P, _P, _P, _P],
         "pack_mixed": [_P, _P, _P, _P],
+        "unpack_widths": [_P, _P, _P, _P, _Z, _P, _P],
+        "pack_widths": [_P, _P, _P, _P, _Z, _P, _P],
     }
     host = {
         "pack_host": [_U, _P, _P, _Z],
@@ -61,7 +63,8 @@ def exported_symbols():
     """Every symbol include/fastlanes_amd.h declares."""
     names = ["fl_version", "fl_status_string", "fl_last_hip_error", "fl_packed_len",
              "fl_mixed_plan_create", "fl_mixed_plan_destroy", "fl_mixed_plan_n_blocks",
-             "fl_mixed_plan_packed_bytes", "fl_mixed_plan_offsets"]
+             "fl_mixed_plan_packed_bytes", "fl_mixed_plan_offsets", "fl_mixed_plan_widths",
+             "fl_widths_to_offsets", "fl_host_release"]
     for ty in TYPES:
         names += [f"fl_{ty}_{m}" for m in _signatures(ty)]
     return names
@@ -96,6 +99,12 @@ def load():
     lib.fl_mixed_plan_packed_bytes.argtypes = [_P]
     lib.fl_mixed_plan_offsets.restype = _P
     lib.fl_mixed_plan_offsets.argtypes = [_P]
+    lib.fl_mixed_plan_widths.restype = _P
+    lib.fl_mixed_plan_widths.argtypes = [_P]
+    lib.fl_host_release.restype = None
+    lib.fl_host_release.argtypes = []
+    lib.fl_widths_to_offsets.restype = ctypes.c_int
+    lib.fl_widths_to_offsets.argtypes = [_U, _P, _Z, _P, _P, _P, _P]
     for ty in TYPES:
         for m, argtypes in _signatures(ty).items():
             fn = getattr(lib, f"fl_{ty}_{m}")

@@ -104,10 +104,36 @@ def _stream(arg):
     return ctypes.c_void_p(torch.cuda.current_stream(arg.x.device).cuda_stream)
 
 
+def _same_tier(src, *others):
+    """Every buffer of one call lives on the same tier (all numpy, or all CUDA tensors of ONE device):
+    a host pointer handed to a device kernel -- or a tensor of another GPU -- would fault the process."""
+    for o in others:
+        if o is None:
+            continue
+        if o.torch != src.torch:
+            raise TypeError("input, output and base/reference must all be numpy arrays (host tier) or all be "
+                            "CUDA tensors (device tier)")
+        if src.torch and o.x.device != src.x.device:
+            raise ValueError(f"tensors live on different devices ({src.x.device} vs {o.x.device})")
+
+
+def _out(src, output, ty, n_elems, what):
+    """The caller's output buffer (checked: a short buffer would be overrun by the kernel, which sizes
+    its stores from n_blocks) or a fresh one.  Mirrors the reference's length asserts
+    (bitpacking.rs:78-80,111-113)."""
+    if output is None:
+        return _Arg(_empty_like(src, n_elems, ty), ty)
+    out = _Arg(output, ty)
+    if out.n != n_elems:
+        raise ValueError(f"{what}: output holds {out.n} elements, expected {n_elems}")
+    return out
+
+
 def _run(method, ty, width, src, out, n_blocks, aux=None, aux_stride=None, scalar=None):
     """Dispatch to fl_<ty>_<method>[_host]."""
     lib = _lib.load()
     dev = src.torch
+    _same_tier(src, out, aux)
     fn = getattr(lib, f"fl_{ty}_{method}" + ("" if dev else "_host"))
     args = []
     if width is not None:
@@ -155,9 +181,7 @@ class BitPacking:
         if width > _lib.BITS[ty]:
             raise FastLanesError(1, f"fl_{ty}_pack")
         n = _blocks(src.n, 1024, "pack input")
-        out = _Arg(output, ty) if output is not None else _Arg(_empty_like(src, n * packed_len(ty, width), ty), ty)
-        if out.n != n * packed_len(ty, width):
-            raise ValueError("Output buffer must be of size 1024 * W / T per block")  # bitpacking.rs:78
+        out = _out(src, output, ty, n * packed_len(ty, width), "pack")     # bitpacking.rs:78
         return _run("pack", ty, width, src, out, n)
 
     unchecked_pack = pack
@@ -173,9 +197,7 @@ class BitPacking:
         n = _blocks(src.n, packed_len(ty, width), "unpack input")
         if n is None:
             n = n_blocks if n_blocks is not None else (_Arg(output, ty).n // 1024 if output is not None else 0)
-        out = _Arg(output, ty) if output is not None else _Arg(_empty_like(src, n * 1024, ty), ty)
-        if out.n != n * 1024:
-            raise ValueError("Output buffer must be of size 1024 per block")  # bitpacking.rs:112
+        out = _out(src, output, ty, n * 1024, "unpack")                    # bitpacking.rs:112
         return _run("unpack", ty, width, src, out, n)
 
     unchecked_unpack = unpack
@@ -282,6 +304,7 @@ class FoR:
         import torch
         if _is_torch(reference):
             r = _Arg(reference.contiguous(), ty)
+            _same_tier(src, r)
             if r.n not in (1, n):
                 raise ValueError("references must hold 1 or n_blocks elements")
             return r, (0 if r.n == 1 else 1), None
@@ -297,7 +320,7 @@ class FoR:
         if width > _lib.BITS[ty]:
             raise FastLanesError(1, f"fl_{ty}_for_pack")
         n = _blocks(src.n, 1024, "for_pack input")
-        out = _Arg(output, ty) if output is not None else _Arg(_empty_like(src, n * packed_len(ty, width), ty), ty)
+        out = _out(src, output, ty, n * packed_len(ty, width), "for_pack")
         aux, stride, scalar = FoR._ref(src, ty, reference, n)
         return _run("for_pack", ty, width, src, out, n, aux=aux, aux_stride=stride, scalar=scalar)
 
@@ -309,9 +332,9 @@ class FoR:
         if width > _lib.BITS[ty]:
             raise FastLanesError(1, f"fl_{ty}_unfor_pack")
         n = _blocks(src.n, packed_len(ty, width), "unfor_pack input")
-        if n is None:
-            n = n_blocks if n_blocks is not None else 0
-        out = _Arg(output, ty) if output is not None else _Arg(_empty_like(src, n * 1024, ty), ty)
+        if n is None:   # width 0: the packed input is empty -- take the block count from n_blocks or the output
+            n = n_blocks if n_blocks is not None else (_Arg(output, ty).n // 1024 if output is not None else 0)
+        out = _out(src, output, ty, n * 1024, "unfor_pack")
         aux, stride, scalar = FoR._ref(src, ty, reference, n)
         return _run("unfor_pack", ty, width, src, out, n, aux=aux, aux_stride=stride, scalar=scalar)
 
@@ -331,7 +354,7 @@ class Delta:
             n = n_blocks if n_blocks is not None else b.n // (1024 // _lib.BITS[ty])
         if b.n != n * (1024 // _lib.BITS[ty]):
             raise ValueError("base must hold LANES elements per block")
-        out = _Arg(output, ty) if output is not None else _Arg(_empty_like(src, n * 1024, ty), ty)
+        out = _out(src, output, ty, n * 1024, method)
         return _run(method, ty, width, src, out, n, aux=b)
 
     @staticmethod
@@ -373,7 +396,7 @@ class Delta:
         b = _Arg(base, ty)
         if b.n != n * (1024 // _lib.BITS[ty]):
             raise ValueError("base must hold LANES elements per block")
-        out = _Arg(output, ty) if output is not None else _Arg(_empty_like(src, n * packed_len(ty, width), ty), ty)
+        out = _out(src, output, ty, n * packed_len(ty, width), "transpose_delta_pack")
         return _run("transpose_delta_pack", ty, width, src, out, n, aux=b)
 
 
@@ -385,7 +408,7 @@ class Transpose:
         src = _Arg(input)
         ty = src.ty
         n = _blocks(src.n, 1024, f"{method} input")
-        out = _Arg(output, ty) if output is not None else _Arg(_empty_like(src, n * 1024, ty), ty)
+        out = _out(src, output, ty, n * 1024, method)
         return _run(method, ty, None, src, out, n)
 
     @staticmethod
@@ -399,17 +422,97 @@ class Transpose:
         return Transpose._go("untranspose", input, output)
 
 
+def _check_widths_host(ty, widths):
+    """Host widths -> contiguous uint8, refusing anything above T BEFORE the cast (300 must not wrap to 44)."""
+    w = np.asarray(widths)
+    if w.dtype.kind not in "ui":
+        raise TypeError("widths must be an integer array")
+    if w.size and (int(w.min()) < 0 or int(w.max()) > _lib.BITS[ty]):
+        raise FastLanesError(1, "widths")                       # bitpacking.rs:93 unreachable!()
+    return np.ascontiguousarray(w, dtype=np.uint8).reshape(-1)
+
+
+def widths_to_offsets(ty, widths):
+    """Device tier: (offsets, total) for a CUDA uint8 tensor of per-block widths -- offsets[b] = byte
+    offset of block b in a back-to-back packed column (exclusive prefix sum of 128*W, bitpacking.rs:77),
+    total = a 1-element CUDA int64 tensor holding the column's packed size.  No host round trip."""
+    import torch
+    w = _Arg(widths, "u8")
+    if not w.torch:
+        raise TypeError("widths_to_offsets is device tier (pass a CUDA uint8 tensor; sharding.packed_offsets is the host form)")
+    dev = w.x.device
+    offsets = torch.empty(w.n, dtype=torch.int64, device=dev)
+    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _check(_lib.load().fl_widths_to_offsets(_lib.BITS[ty], w.ptr, w.n, offsets.data_ptr(), total.data_ptr(),
+                                                err.data_ptr(), _stream(w)), "fl_widths_to_offsets")
+    if int(err.item()) != 0:
+        raise FastLanesError(1, "fl_widths_to_offsets")         # bitpacking.rs:93 unreachable!()
+    return offsets, total
+
+
+def _widths_call(method, ty, widths, offsets, packed, unpacked, check):
+    import torch
+    w = _Arg(widths, "u8")
+    o = _Arg(offsets, "u64")
+    _same_tier(packed, unpacked, w, o)
+    if not packed.torch:
+        raise TypeError(f"{method} is device tier: widths, offsets and data must be CUDA tensors")
+    n = w.n
+    if o.n != n:
+        raise ValueError("offsets must hold one entry per block")
+    if unpacked.n != n * 1024:
+        raise ValueError(f"{method}: the unpacked column must hold 1024 elements per block")
+    dev = packed.x.device
+    err = torch.zeros(1, dtype=torch.int32, device=dev) if check else None
+    # C ABI argument order is (widths, offsets, in, out, ..): packed -> unpacked for unpack, the reverse for pack
+    first, second = (packed, unpacked) if method == "unpack_widths" else (unpacked, packed)
+    with torch.cuda.device(dev):
+        _check(getattr(_lib.load(), f"fl_{ty}_{method}")(w.ptr, o.ptr, first.ptr, second.ptr, n,
+                                                         err.data_ptr() if check else None, _stream(packed)),
+               f"fl_{ty}_{method}")
+    if check and int(err.item()) != 0:
+        raise FastLanesError(1, f"fl_{ty}_{method}")            # bitpacking.rs:93,126 unreachable!()
+
+
+def unpack_widths(widths, offsets, packed, output=None, check=True):
+    """The reference's caller loop `for b: T::unchecked_unpack(widths[b], &packed[offsets[b]..], ..)`
+    (bitpacking.rs:109-129) as ONE launch with everything device-resident: `widths` (CUDA uint8, one per
+    block), `offsets` (CUDA int64/uint64 byte offsets into `packed`), `packed` (CUDA tensor of the element
+    type).  `check=True` reads the device error flag back (one sync) and raises on a width > T;
+    `check=False` stays asynchronous."""
+    src = _Arg(packed)
+    ty = src.ty
+    n = _Arg(widths, "u8").n
+    out = _out(src, output, ty, n * 1024, "unpack_widths")
+    _widths_call("unpack_widths", ty, widths, offsets, src, out, check)
+    return out.x
+
+
+def pack_widths(widths, offsets, input, output, check=True):
+    """`for b: T::unchecked_pack(widths[b], &input[b*1024..], &mut output[offsets[b]..])`
+    (bitpacking.rs:76-96), device-resident.  `output` is the packed column (the caller sizes it from
+    widths_to_offsets' total); bytes no block covers are left untouched."""
+    src = _Arg(input)
+    ty = src.ty
+    out = _Arg(output, ty)
+    _widths_call("pack_widths", ty, widths, offsets, out, src, check)
+    return out.x
+
+
 class MixedWidthPlan:
     """A column whose blocks each have their own width (BASELINE.json config 5): the
     reference's caller loop `for b: T::unchecked_unpack(widths[b], ..)` (bitpacking.rs:109-129)
-    as one call.  Built once from the host `widths` array; packed blocks lie back to back at
-    byte offsets = exclusive prefix sum of 128*widths[b]."""
+    as one call.  Built from the host `widths` array: uploads them and prefix-sums the packed byte
+    offsets (128*widths[b], back to back) ON THE DEVICE; `widths` / `offsets` are then device arrays
+    (see unpack_widths / pack_widths for callers whose widths already live in HBM)."""
 
     def __init__(self, ty, widths, device=None):
         import torch
         self.ty = ty
+        w = _check_widths_host(ty, widths)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        w = np.ascontiguousarray(widths, dtype=np.uint8)
         self._plan = ctypes.c_void_p()
         lib = _lib.load()
         with torch.cuda.device(self.device):
@@ -433,6 +536,11 @@ class MixedWidthPlan:
         import torch
         return {"u8": torch.uint8, "u16": torch.uint16, "u32": torch.uint32, "u64": torch.uint64}[self.ty]
 
+    def _on_device(self, *args):
+        for a in args:
+            if not a.torch or a.x.device != self.device:
+                raise ValueError(f"this plan lives on {self.device}: pass CUDA tensors of that device")
+
     def unpack(self, packed, output=None):
         import torch
         src = _Arg(packed, self.ty)
@@ -443,6 +551,7 @@ class MixedWidthPlan:
             torch.empty(self.n_blocks * 1024, dtype=self._torch_dtype(), device=self.device), self.ty)
         if out.n != self.n_blocks * 1024:
             raise ValueError("Output buffer must be of size 1024 per block")
+        self._on_device(src, out)
         with torch.cuda.device(self.device):
             _check(getattr(_lib.load(), f"fl_{self.ty}_unpack_mixed")(self._plan, src.ptr, out.ptr, _stream(out)),
                    f"fl_{self.ty}_unpack_mixed")
@@ -458,6 +567,7 @@ class MixedWidthPlan:
             torch.empty(self.packed_bytes // esz, dtype=self._torch_dtype(), device=self.device), self.ty)
         if out.n * esz != self.packed_bytes:
             raise ValueError("packed column has the wrong size for this plan")
+        self._on_device(src, out)
         with torch.cuda.device(self.device):
             _check(getattr(_lib.load(), f"fl_{self.ty}_pack_mixed")(self._plan, src.ptr, out.ptr, _stream(src)),
                    f"fl_{self.ty}_pack_mixed")

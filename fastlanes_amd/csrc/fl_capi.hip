@@ -5,12 +5,12 @@
 #include "../../include/fastlanes_amd.h"
 #include "fl_kernels.hpp"
 #include "fl_misc.hpp"
-#include "fl_mixed.hpp"
+#include "fl_widths.hpp"
+#include "fl_scan.hpp"
 #include "fl_consume.hpp"
 
-#include <algorithm>
+#include <cstring>
 #include <new>
-#include <vector>
 
 namespace {
 
@@ -163,30 +163,133 @@ int dev_unpack_single(unsigned w, const T* packed, size_t n_blocks, const uint64
 }
 
 // ---------------------------------------------------------------------------
-// Host tier: stage host slices through device memory and run the same kernels.
+// Host tier: the trait methods' host slices, run through the same kernels.
+//
+// The reference is allocation-free (`#![no_std]`, lib.rs:3); so is this tier after its first call
+// on a thread: every host thread keeps ONE cached context (HostCtx, thread_local) holding
+//   * a private non-blocking stream (concurrent host threads do not serialise on the null stream),
+//   * a pinned, device-mapped staging buffer and a device scratch buffer, both grown geometrically
+//     and freed at thread exit or by fl_host_release().
+// Small calls (one trait-method call = one block) are ZERO-COPY: the slices are copied into the
+// pinned buffer and the kernel reads / writes that host memory directly over PCIe -- one launch and
+// one stream sync, no DMA round trips.  Large calls stage through the device scratch buffer.
 // ---------------------------------------------------------------------------
-struct DevBuf {
-    void* p = nullptr;
-    hipError_t alloc(size_t bytes) { return bytes ? hipMalloc(&p, bytes) : hipSuccess; }
-    ~DevBuf() { if (p) (void)hipFree(p); }
+struct HostCtx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    char* dev = nullptr;
+    size_t dev_cap = 0;
+    char* pin = nullptr;
+    size_t pin_cap = 0;
+
+    void release()
+    {
+        if (device < 0) return;
+        int cur = -1;
+        const bool switched = hipGetDevice(&cur) == hipSuccess && cur != device && hipSetDevice(device) == hipSuccess;
+        if (stream) (void)hipStreamDestroy(stream);
+        if (dev) (void)hipFree(dev);
+        if (pin) (void)hipHostFree(pin);
+        if (switched) (void)hipSetDevice(cur);
+        stream = nullptr; dev = nullptr; pin = nullptr;
+        dev_cap = pin_cap = 0;
+        device = -1;
+    }
+    // bind to the calling thread's current device
+    hipError_t bind()
+    {
+        int cur = 0;
+        hipError_t e = hipGetDevice(&cur);
+        if (e != hipSuccess) return e;
+        if (cur == device) return hipSuccess;
+        release();
+        e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { stream = nullptr; return e; }
+        device = cur;
+        return hipSuccess;
+    }
+    static size_t grown(size_t need, size_t have) { return need > 2 * have ? need : 2 * have; }
+    hipError_t need_pinned(size_t bytes)
+    {
+        if (bytes <= pin_cap) return hipSuccess;
+        if (pin) { (void)hipStreamSynchronize(stream); (void)hipHostFree(pin); pin = nullptr; pin_cap = 0; }
+        const size_t cap = grown(bytes, pin_cap < 65536 ? 65536 : pin_cap);
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&pin), cap, hipHostMallocDefault);
+        if (e == hipSuccess) pin_cap = cap; else pin = nullptr;
+        return e;
+    }
+    hipError_t need_device(size_t bytes)
+    {
+        if (bytes <= dev_cap) return hipSuccess;
+        if (dev) { (void)hipStreamSynchronize(stream); (void)hipFree(dev); dev = nullptr; dev_cap = 0; }
+        const size_t cap = grown(bytes, dev_cap);
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&dev), cap);
+        if (e == hipSuccess) dev_cap = cap; else dev = nullptr;
+        return e;
+    }
+    ~HostCtx() { release(); }
 };
+thread_local HostCtx g_host;
+
+constexpr size_t HOST_ZERO_COPY_LIMIT = 256 * 1024;   // bytes (in + aux + out) served straight from pinned host memory
 
 #define FL_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return hip_fail(e_); } while (0)
 
+inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// dev(in, aux, out, stream) launches the device-tier op on pointers the GPU can reach.
 template <typename T, typename F>
 int host_run(const T* in, size_t in_elems, const T* aux, size_t aux_elems, T* out, size_t out_elems, F&& dev)
 {
     if ((in_elems && !in) || (out_elems && !out) || (aux_elems && !aux)) return FL_ERR_NULL;
-    DevBuf din, daux, dout;
-    FL_HIP(din.alloc(in_elems * sizeof(T)));
-    FL_HIP(daux.alloc(aux_elems * sizeof(T)));
-    FL_HIP(dout.alloc(out_elems * sizeof(T)));
-    if (in_elems) FL_HIP(hipMemcpy(din.p, in, in_elems * sizeof(T), hipMemcpyHostToDevice));
-    if (aux_elems) FL_HIP(hipMemcpy(daux.p, aux, aux_elems * sizeof(T), hipMemcpyHostToDevice));
-    int rc = dev(static_cast<const T*>(din.p), static_cast<const T*>(daux.p), static_cast<T*>(dout.p));
+    const size_t ib = in_elems * sizeof(T), ab = aux_elems * sizeof(T), ob = out_elems * sizeof(T);
+    const size_t o_aux = pad256(ib), o_out = o_aux + pad256(ab), total = o_out + pad256(ob);
+    HostCtx& c = g_host;
+    FL_HIP(c.bind());
+    if (total <= HOST_ZERO_COPY_LIMIT) {
+        FL_HIP(c.need_pinned(total));
+        if (ib) memcpy(c.pin, in, ib);
+        if (ab) memcpy(c.pin + o_aux, aux, ab);
+        int rc = dev(reinterpret_cast<const T*>(c.pin), reinterpret_cast<const T*>(c.pin + o_aux),
+                     reinterpret_cast<T*>(c.pin + o_out), c.stream);
+        if (rc != FL_OK) return rc;
+        FL_HIP(hipStreamSynchronize(c.stream));
+        if (ob) memcpy(out, c.pin + o_out, ob);
+        return FL_OK;
+    }
+    FL_HIP(c.need_device(total));
+    if (ib) FL_HIP(hipMemcpyAsync(c.dev, in, ib, hipMemcpyHostToDevice, c.stream));
+    if (ab) FL_HIP(hipMemcpyAsync(c.dev + o_aux, aux, ab, hipMemcpyHostToDevice, c.stream));
+    int rc = dev(reinterpret_cast<const T*>(c.dev), reinterpret_cast<const T*>(c.dev + o_aux),
+                 reinterpret_cast<T*>(c.dev + o_out), c.stream);
     if (rc != FL_OK) return rc;
-    FL_HIP(hipStreamSynchronize(nullptr));
-    if (out_elems) FL_HIP(hipMemcpy(out, dout.p, out_elems * sizeof(T), hipMemcpyDeviceToHost));
+    if (ob) FL_HIP(hipMemcpyAsync(out, c.dev + o_out, ob, hipMemcpyDeviceToHost, c.stream));
+    FL_HIP(hipStreamSynchronize(c.stream));
+    return FL_OK;
+}
+
+// unpack_single on host slices: only the indexed block travels (128*W bytes into the pinned buffer;
+// the kernel then touches the one or two words bitpacking.rs:164-178 reads).
+template <typename T>
+int host_unpack_single(unsigned w, const T* pk, size_t n_blocks, uint64_t index, T* value)
+{
+    if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
+    if (!value) return FL_ERR_NULL;
+    if (w == 0) { *value = 0; return FL_OK; }                 // bitpacking.rs:136-139 precedes the assert
+    if (index >= (uint64_t)n_blocks * 1024) return FL_ERR_INDEX;   // bitpacking.rs:152
+    if (!pk) return FL_ERR_NULL;
+    const size_t pl = (size_t)1024 * w / Elem<T>::BITS, pb = pl * sizeof(T);
+    const size_t o_idx = pad256(pb), o_val = o_idx + 256;
+    HostCtx& c = g_host;
+    FL_HIP(c.bind());
+    FL_HIP(c.need_pinned(o_val + 256));
+    memcpy(c.pin, pk + (index >> 10) * pl, pb);
+    *reinterpret_cast<uint64_t*>(c.pin + o_idx) = index & 1023u;
+    int rc = dev_unpack_single<T>(w, reinterpret_cast<const T*>(c.pin), 1, reinterpret_cast<const uint64_t*>(c.pin + o_idx), 1,
+                                  reinterpret_cast<T*>(c.pin + o_val), nullptr, c.stream);
+    if (rc != FL_OK) return rc;
+    FL_HIP(hipStreamSynchronize(c.stream));
+    *value = *reinterpret_cast<const T*>(c.pin + o_val);
     return FL_OK;
 }
 
@@ -195,21 +298,37 @@ template <typename T> size_t plen(unsigned w) { return (size_t)1024 * w / Elem<T
 }  // namespace
 
 // ---------------------------------------------------------------------------
-// mixed-width plan
+// mixed-width columns: device-resident widths[] / offsets[] (fl_widths.hpp)
 // ---------------------------------------------------------------------------
 struct fl_mixed_plan {
     unsigned type_bits = 0;
     size_t n_blocks = 0;
     uint64_t packed_bytes = 0;
-    uint64_t n_tiles = 0;
-    MixedEntry* d_entries = nullptr; // (block, packed offset) bucketed by width, ascending inside a bucket
-    uint64_t* d_offsets = nullptr;   // byte offset of every block in the packed column, natural order
-    MixedTile* d_tiles = nullptr;    // one descriptor per tile of <= 32 same-width blocks
-    bool window_unpack = false;      // every tile's span fits a 32-bit store window
-    bool window_pack = false;
+    uint8_t* d_widths = nullptr;     // widths[n_blocks] in HBM
+    uint64_t* d_offsets = nullptr;   // byte offset of every block in the packed column (exclusive prefix sum of 128*W)
 };
 
 namespace {
+
+template <typename T>
+int run_widths(bool pack, const uint8_t* widths, const uint64_t* offsets, const void* packed, void* unpacked,
+               size_t n_blocks, uint32_t* err_flag, void* stream)
+{
+    if (n_blocks == 0) return FL_OK;
+    if (!widths || !offsets || !packed || !unpacked) return FL_ERR_NULL;
+    if (misaligned(packed) || misaligned(unpacked)) return FL_ERR_ALIGN;
+    WidthsArgs a;
+    a.packed = static_cast<const char*>(packed);
+    a.unpacked = static_cast<char*>(unpacked);
+    a.widths = widths;
+    a.offsets = offsets;
+    a.err_flag = err_flag;
+    a.n_blocks = n_blocks;
+    a.tiles_per_xcd = 0;
+    a.uniform_width = 0;
+    hipError_t e = widths_launcher<T>(pack)(a, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? FL_OK : hip_fail(e);
+}
 
 template <typename T>
 int run_mixed(bool pack, const fl_mixed_plan* p, const void* packed, void* unpacked, void* stream)
@@ -218,120 +337,73 @@ int run_mixed(bool pack, const fl_mixed_plan* p, const void* packed, void* unpac
     if (p->type_bits != (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
     if (p->n_blocks == 0) return FL_OK;
     if (!unpacked || (p->packed_bytes && !packed)) return FL_ERR_NULL;
-    if (misaligned(packed) || misaligned(unpacked)) return FL_ERR_ALIGN;
-    MixedArgs a;
-    a.packed = static_cast<const char*>(packed);
-    a.unpacked = static_cast<char*>(unpacked);
-    a.entries = p->d_entries;
-    a.tiles = p->d_tiles;
-    a.n_tiles = p->n_tiles;
-    a.tiles_per_xcd = 0;
-    const bool window = pack ? p->window_pack : p->window_unpack;
-    hipError_t e = (pack ? mixed_pack_launcher<T>(window) : mixed_unpack_launcher<T>(window))(a, static_cast<hipStream_t>(stream));
-    return e == hipSuccess ? FL_OK : hip_fail(e);
+    // widths were validated at plan creation; an all-zero-width column has no packed bytes at all
+    static const char dummy[16] __attribute__((aligned(16))) = {0};
+    return run_widths<T>(pack, p->d_widths, p->d_offsets, p->packed_bytes ? packed : dummy, unpacked, p->n_blocks, nullptr, stream);
 }
 
 }  // namespace
 
 extern "C" {
 
-static int mixed_plan_create_impl(unsigned type_bits, const uint8_t* widths, size_t n_blocks, fl_mixed_plan** plan)
+int fl_widths_to_offsets(unsigned type_bits, const uint8_t* widths, size_t n_blocks, uint64_t* offsets,
+                         uint64_t* total_bytes, uint32_t* err_flag, void* stream)
 {
-    if (!plan || (n_blocks && !widths)) return FL_ERR_NULL;
-    *plan = nullptr;
     if (type_bits != 8 && type_bits != 16 && type_bits != 32 && type_bits != 64) return FL_ERR_WIDTH;
-    if (n_blocks > 0xFFFFFFFFull) return FL_ERR_INDEX;
-    size_t count[66] = {0};
-    for (size_t b = 0; b < n_blocks; ++b) {
-        if (widths[b] > type_bits) return FL_ERR_WIDTH;   // bitpacking.rs:93 unreachable!()
-        ++count[widths[b] + 1];
-    }
-    fl_mixed_plan* p = new (std::nothrow) fl_mixed_plan;
-    if (!p) return FL_ERR_HIP;
-    struct Guard {   // frees the half-built plan on every early exit, including exceptions
-        fl_mixed_plan* p;
-        ~Guard() { if (p) fl_mixed_plan_destroy(p); }
-    } guard{p};
-    p->type_bits = type_bits;
-    p->n_blocks = n_blocks;
-    size_t bucket_start[67] = {0};
-    for (unsigned w = 0; w <= 64; ++w) bucket_start[w + 1] = bucket_start[w] + count[w + 1];
-    std::vector<uint32_t> ids(n_blocks);
-    std::vector<uint64_t> off(n_blocks);
-    {
-        size_t cursor[66];
-        for (unsigned w = 0; w <= 64; ++w) cursor[w] = bucket_start[w];
-        uint64_t o = 0;
-        for (size_t b = 0; b < n_blocks; ++b) {
-            off[b] = o;
-            o += 128ull * widths[b];
-            ids[cursor[widths[b]]++] = (uint32_t)b;
-        }
-        p->packed_bytes = o;
-    }
-    // tiles: 32 same-width blocks each, buckets in width order; check the store windows
-    const uint64_t block_bytes = 128ull * type_bits;
-    std::vector<MixedEntry> entries(n_blocks);
-    for (size_t i = 0; i < n_blocks; ++i) entries[i] = MixedEntry{ids[i], off[ids[i]]};
-    std::vector<MixedTile> tiles;
-    tiles.reserve(n_blocks / 32 + 66);
-    bool wu = true, wp = true;
-    for (unsigned w = 0; w <= type_bits; ++w) {
-        const size_t s0 = bucket_start[w], m = bucket_start[w + 1] - s0;
-        for (size_t t = 0; t * 32 < m; ++t) {
-            const unsigned cnt = (unsigned)(m - t * 32 < 32 ? m - t * 32 : 32);
-            const uint64_t first = ids[s0 + t * 32], last = ids[s0 + t * 32 + cnt - 1];
-            tiles.push_back(MixedTile{(uint32_t)(s0 + t * 32), cnt | (w << 8), first, off[first], 0});
-            if ((last - first + 1) * block_bytes > 0xFFFFFFFFull) wu = false;
-            if (off[last] + 128ull * w - off[first] > 0xFFFFFFFFull) wp = false;
-        }
-    }
-    // Launch order = column order: tiles are sorted by their first block, so neighbouring
-    // workgroups (and each XCD's contiguous share of the tile list) cover the same region of
-    // the column whatever their widths -- the global traffic stays a dense sweep.  (Bucket
-    // order, i.e. one width after the other, measured 20-25 % slower on interleaved widths.)
-    std::sort(tiles.begin(), tiles.end(), [](const MixedTile& x, const MixedTile& y) { return x.first_blk < y.first_blk; });
-    p->n_tiles = tiles.size();
-    p->window_unpack = wu;
-    p->window_pack = wp;
-    if (n_blocks) {
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->d_entries), n_blocks * sizeof(MixedEntry));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_offsets), n_blocks * sizeof(uint64_t));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_tiles), tiles.size() * sizeof(MixedTile));
-        if (e == hipSuccess) e = hipMemcpy(p->d_entries, entries.data(), n_blocks * sizeof(MixedEntry), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(p->d_offsets, off.data(), n_blocks * sizeof(uint64_t), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(p->d_tiles, tiles.data(), tiles.size() * sizeof(MixedTile), hipMemcpyHostToDevice);
-        if (e != hipSuccess) return hip_fail(e);
-    }
-    guard.p = nullptr;
-    *plan = p;
-    return FL_OK;
+    if (n_blocks && (!widths || !offsets)) return FL_ERR_NULL;
+    ScanArgs a{widths, offsets, total_bytes, err_flag, n_blocks, type_bits};
+    hipError_t e = launch_widths_to_offsets(a, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? FL_OK : hip_fail(e);
 }
 
 int fl_mixed_plan_create(unsigned type_bits, const uint8_t* widths, size_t n_blocks, fl_mixed_plan** plan)
 {
-    // nothing may throw across the C ABI (the host-side tables are std::vectors)
-    try {
-        return mixed_plan_create_impl(type_bits, widths, n_blocks, plan);
-    } catch (...) {
-        g_last_hip_error = (int)hipErrorOutOfMemory;
-        return FL_ERR_HIP;
+    if (!plan || (n_blocks && !widths)) return FL_ERR_NULL;
+    *plan = nullptr;
+    if (type_bits != 8 && type_bits != 16 && type_bits != 32 && type_bits != 64) return FL_ERR_WIDTH;
+    for (size_t b = 0; b < n_blocks; ++b)
+        if (widths[b] > type_bits) return FL_ERR_WIDTH;   // bitpacking.rs:93 unreachable!()
+    fl_mixed_plan* p = new (std::nothrow) fl_mixed_plan;
+    if (!p) { g_last_hip_error = (int)hipErrorOutOfMemory; return FL_ERR_HIP; }
+    p->type_bits = type_bits;
+    p->n_blocks = n_blocks;
+    if (n_blocks) {
+        uint64_t* d_total = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->d_widths), n_blocks);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_offsets), (n_blocks + 1) * sizeof(uint64_t));
+        if (e == hipSuccess) {
+            d_total = p->d_offsets + n_blocks;             // the total rides behind the offsets: one allocation less
+            e = hipMemcpy(p->d_widths, widths, n_blocks, hipMemcpyHostToDevice);
+        }
+        if (e == hipSuccess) {
+            ScanArgs a{p->d_widths, p->d_offsets, d_total, nullptr, n_blocks, type_bits};
+            e = launch_widths_to_offsets(a, nullptr);
+        }
+        if (e == hipSuccess) e = hipMemcpy(&p->packed_bytes, d_total, sizeof(uint64_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            fl_mixed_plan_destroy(p);
+            return hip_fail(e);
+        }
     }
+    *plan = p;
+    return FL_OK;
 }
 
 void fl_mixed_plan_destroy(fl_mixed_plan* p)
 {
     if (!p) return;
-    if (p->d_entries) (void)hipFree(p->d_entries);
+    if (p->d_widths) (void)hipFree(p->d_widths);
     if (p->d_offsets) (void)hipFree(p->d_offsets);
-    if (p->d_tiles) (void)hipFree(p->d_tiles);
     delete p;
 }
 size_t fl_mixed_plan_n_blocks(const fl_mixed_plan* p) { return p ? p->n_blocks : 0; }
 uint64_t fl_mixed_plan_packed_bytes(const fl_mixed_plan* p) { return p ? p->packed_bytes : 0; }
 const uint64_t* fl_mixed_plan_offsets(const fl_mixed_plan* p) { return p ? p->d_offsets : nullptr; }
+const uint8_t* fl_mixed_plan_widths(const fl_mixed_plan* p) { return p ? p->d_widths : nullptr; }
 
-const char* fl_version(void) { return "fastlanes_amd 0.1.0 (gfx950; wire format of spiraldb/fastlanes 0.1.8)"; }
+void fl_host_release(void) { g_host.release(); }
+
+const char* fl_version(void) { return "fastlanes_amd 0.2.0 (gfx950; wire format of spiraldb/fastlanes 0.1.8)"; }
 
 const char* fl_status_string(int status)
 {
@@ -383,68 +455,61 @@ size_t fl_packed_len(unsigned type_bits, unsigned width)
     int fl_##S##_untranspose(const T* in, T* out, size_t n, void* s) { return dev_transpose<T>(true, in, out, n, s); } \
     int fl_##S##_unpack_mixed(const fl_mixed_plan* p, const T* pk, T* out, void* s) { return run_mixed<T>(false, p, pk, out, s); } \
     int fl_##S##_pack_mixed(const fl_mixed_plan* p, const T* in, T* pk, void* s) { return run_mixed<T>(true, p, pk, const_cast<T*>(in), s); } \
+    int fl_##S##_unpack_widths(const uint8_t* w, const uint64_t* o, const T* pk, T* out, size_t n, uint32_t* ef, void* s) \
+    { return run_widths<T>(false, w, o, pk, out, n, ef, s); }                                             \
+    int fl_##S##_pack_widths(const uint8_t* w, const uint64_t* o, const T* in, T* pk, size_t n, uint32_t* ef, void* s) \
+    { return run_widths<T>(true, w, o, pk, const_cast<T*>(in), n, ef, s); }                               \
     int fl_##S##_pack_host(unsigned w, const T* in, T* out, size_t n)                                     \
     {                                                                                                     \
         if (w > sizeof(T) * 8) return FL_ERR_WIDTH;                                                       \
         return host_run<T>(in, n * 1024, nullptr, 0, out, n * plen<T>(w),                                 \
-                           [&](const T* di, const T*, T* d_o) { return dev_pack<T>(w, di, d_o, n, nullptr); }); \
+                           [&](const T* di, const T*, T* d_o, void* st) { return dev_pack<T>(w, di, d_o, n, st); }); \
     }                                                                                                     \
     int fl_##S##_unpack_host(unsigned w, const T* in, T* out, size_t n)                                   \
     {                                                                                                     \
         if (w > sizeof(T) * 8) return FL_ERR_WIDTH;                                                       \
         return host_run<T>(in, n * plen<T>(w), nullptr, 0, out, n * 1024,                                 \
-                           [&](const T* di, const T*, T* d_o) { return dev_unpack<T>(w, di, d_o, n, nullptr); }); \
+                           [&](const T* di, const T*, T* d_o, void* st) { return dev_unpack<T>(w, di, d_o, n, st); }); \
     }                                                                                                     \
     int fl_##S##_unpack_single_host(unsigned w, const T* pk, size_t n, uint64_t index, T* value)          \
-    {                                                                                                     \
-        if (w > sizeof(T) * 8) return FL_ERR_WIDTH;                                                       \
-        if (!value) return FL_ERR_NULL;                                                                   \
-        if (w == 0) { *value = 0; return FL_OK; } /* bitpacking.rs:136-139 precedes the assert */         \
-        if (index >= (uint64_t)n * 1024) return FL_ERR_INDEX;                                             \
-        DevBuf didx;                                                                                      \
-        FL_HIP(didx.alloc(sizeof(uint64_t)));                                                             \
-        FL_HIP(hipMemcpy(didx.p, &index, sizeof(uint64_t), hipMemcpyHostToDevice));                       \
-        return host_run<T>(pk, n * plen<T>(w), nullptr, 0, value, 1, [&](const T* di, const T*, T* d_o) {  \
-            return dev_unpack_single<T>(w, di, n, static_cast<const uint64_t*>(didx.p), 1, d_o, nullptr, nullptr); \
-        });                                                                                               \
-    }                                                                                                     \
+    { return host_unpack_single<T>(w, pk, n, index, value); }                                             \
     int fl_##S##_for_pack_host(unsigned w, const T* in, T reference, T* out, size_t n)                    \
     {                                                                                                     \
         if (w > sizeof(T) * 8) return FL_ERR_WIDTH;                                                       \
         return host_run<T>(in, n * 1024, &reference, 1, out, n * plen<T>(w),                              \
-                           [&](const T* di, const T* da, T* d_o) { return dev_for_pack<T>(w, di, da, 0, d_o, n, nullptr); }); \
+                           [&](const T* di, const T* da, T* d_o, void* st) { return dev_for_pack<T>(w, di, da, 0, d_o, n, st); }); \
     }                                                                                                     \
     int fl_##S##_unfor_pack_host(unsigned w, const T* in, T reference, T* out, size_t n)                  \
     {                                                                                                     \
         if (w > sizeof(T) * 8) return FL_ERR_WIDTH;                                                       \
         return host_run<T>(in, n * plen<T>(w), &reference, 1, out, n * 1024,                              \
-                           [&](const T* di, const T* da, T* d_o) { return dev_unfor_pack<T>(w, di, da, 0, d_o, n, nullptr); }); \
+                           [&](const T* di, const T* da, T* d_o, void* st) { return dev_unfor_pack<T>(w, di, da, 0, d_o, n, st); }); \
     }                                                                                                     \
     int fl_##S##_delta_host(const T* in, const T* b, T* out, size_t n)                                    \
     {                                                                                                     \
         return host_run<T>(in, n * 1024, b, n * (1024 / (sizeof(T) * 8)), out, n * 1024,                  \
-                           [&](const T* di, const T* da, T* d_o) { return dev_delta<T>(false, di, da, d_o, n, nullptr); }); \
+                           [&](const T* di, const T* da, T* d_o, void* st) { return dev_delta<T>(false, di, da, d_o, n, st); }); \
     }                                                                                                     \
     int fl_##S##_undelta_host(const T* in, const T* b, T* out, size_t n)                                  \
     {                                                                                                     \
         return host_run<T>(in, n * 1024, b, n * (1024 / (sizeof(T) * 8)), out, n * 1024,                  \
-                           [&](const T* di, const T* da, T* d_o) { return dev_delta<T>(true, di, da, d_o, n, nullptr); }); \
+                           [&](const T* di, const T* da, T* d_o, void* st) { return dev_delta<T>(true, di, da, d_o, n, st); }); \
     }                                                                                                     \
     int fl_##S##_undelta_pack_host(unsigned w, const T* in, const T* b, T* out, size_t n)                 \
     {                                                                                                     \
         if (w > sizeof(T) * 8) return FL_ERR_WIDTH;                                                       \
         return host_run<T>(in, n * plen<T>(w), b, n * (1024 / (sizeof(T) * 8)), out, n * 1024,            \
-                           [&](const T* di, const T* da, T* d_o) { return dev_undelta_pack<T>(w, di, da, d_o, n, nullptr); }); \
+                           [&](const T* di, const T* da, T* d_o, void* st) { return dev_undelta_pack<T>(w, di, da, d_o, n, st); }); \
     }                                                                                                     \
     int fl_##S##_transpose_host(const T* in, T* out, size_t n)                                            \
     {                                                                                                     \
         return host_run<T>(in, n * 1024, nullptr, 0, out, n * 1024,                                       \
-                           [&](const T* di, const T*, T* d_o) { return dev_transpose<T>(false, di, d_o, n, nullptr); }); \
+                           [&](const T* di, const T*, T* d_o, void* st) { return dev_transpose<T>(false, di, d_o, n, st); }); \
     }                                                                                                     \
     int fl_##S##_untranspose_host(const T* in, T* out, size_t n)                                          \
     {                                                                                                     \
         return host_run<T>(in, n * 1024, nullptr, 0, out, n * 1024,                                       \
-                           [&](const T* di, const T*, T* d_o) { return dev_transpose<T>(true, di, d_o, n, nullptr); }); \
+                           [&](const T* di, const T*, T* d_o, void* st) { return dev_transpose<T>(true, di, d_o, n, st); }); \
     }
 
 FL_DEFINE_TYPE(uint8_t, u8)

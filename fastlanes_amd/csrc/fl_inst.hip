@@ -3,12 +3,12 @@
 // pairs x 5 width-parameterised kernels build in parallel:
 //   0 unpack (store)   1 unfor_pack   2 undelta_pack   3 pack   4 for_pack
 //   5 delta / undelta / transpose / untranspose / unpack_single
-//   6 unpack / 7 pack over a mixed-width plan (one launch, per-tile width dispatch)
+//   6 unpack / pack over per-block widths[] / offsets[] read on the device (wave-per-block, fl_widths.hpp)
 //   10 fused consumers: unpack_block_sums, block_min_max   11 / 12 unpack_compare (selection masks: x <= k / x == k)
 //   8 undelta_pack+untranspose (fused decode to original order)   9 transpose+delta+pack (fused encode)
 #include "fl_kernels.hpp"
 #include "fl_misc.hpp"
-#include "fl_mixed.hpp"
+#include "fl_widths.hpp"
 #include "fl_consume.hpp"
 
 namespace fl {
@@ -44,14 +44,9 @@ template <> hipError_t unpack_single_launch<T>(const SingleArgs& a, hipStream_t 
     return launch_unpack_single<T>(a, s);
 }
 #elif FL_FAMILY == 6
-template <> mixed_launch_t mixed_unpack_launcher<T>(bool window)
+template <> widths_launch_t widths_launcher<T>(bool pack)
 {
-    return window ? &launch_mixed<T, false, true> : &launch_mixed<T, false, false>;
-}
-#elif FL_FAMILY == 7
-template <> mixed_launch_t mixed_pack_launcher<T>(bool window)
-{
-    return window ? &launch_mixed<T, true, true> : &launch_mixed<T, true, false>;
+    return pack ? &launch_widths<T, true> : &launch_widths<T, false>;
 }
 #elif FL_FAMILY == 8
 static constexpr WidthTable<T> t_undelta_untr = make_unpack_table<T, BODY_UNDELTA_UNTRANSPOSE>(Ws{});
@@ -70,6 +65,6 @@ template <> const CompareTable<T>& compare_table_impl<T, false>() { return t_com
 static constexpr CompareTable<T> t_compare_eq = make_compare_table<T, true>(Ws{});
 template <> const CompareTable<T>& compare_table_impl<T, true>() { return t_compare_eq; }
 #else
-#error "FL_FAMILY must be 0..12"
+#error "FL_FAMILY must be 0..6 or 8..12"
 #endif
 }  // namespace fl

@@ -1,0 +1,115 @@
+// fl_scan.hpp -- widths[] -> offsets[] on the device (the exclusive prefix sum a caller of
+// bitpacking.rs:109-129 keeps implicitly by advancing its packed slice by 128*W bytes per block).
+// Included by exactly one translation unit of the library (fl_capi.hip): the kernels are not templates.
+#pragma once
+#include "fl_kernels.hpp"
+
+namespace fl {
+
+// ---------------------------------------------------------------------------
+// widths -> offsets: exclusive prefix sum of 128*widths[b] (bytes), entirely on the device and
+// without scratch memory.  Three launches over chunks of SCAN_CHUNK blocks:
+//   A: every chunk writes its LOCAL exclusive prefix; the slot of the chunk's first block (whose
+//      local prefix is 0 by definition) temporarily holds the chunk TOTAL;
+//   B: one workgroup turns the chunk totals (strided slots) into chunk base offsets, in place,
+//      and writes the column's total packed bytes;
+//   C: every chunk adds its base to its other slots.
+// ---------------------------------------------------------------------------
+constexpr int SCAN_PER_THREAD = 16;
+constexpr int SCAN_CHUNK = WG * SCAN_PER_THREAD;   // 4096 blocks
+
+struct ScanArgs {
+    const uint8_t* widths;
+    uint64_t* offsets;
+    uint64_t* total;       // may be nullptr
+    uint32_t* err_flag;    // may be nullptr
+    uint64_t n_blocks;
+    unsigned type_bits;
+};
+
+__device__ __forceinline__ uint64_t wave_incl_scan(uint64_t v, unsigned lane)
+{
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t o = __shfl_up(v, d, 64);
+        if (lane >= (unsigned)d) v += o;
+    }
+    return v;
+}
+
+// workgroup-wide exclusive scan of one value per thread; returns the exclusive prefix, *total = sum
+__device__ __forceinline__ uint64_t wg_excl_scan(uint64_t v, uint64_t* total)
+{
+    __shared__ uint64_t wave_sum[WG / 64];
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t inc = wave_incl_scan(v, lane);
+    __syncthreads();                       // protect wave_sum against the previous call's readers
+    if (lane == 63) wave_sum[wave] = inc;
+    __syncthreads();
+    uint64_t base = 0, tot = 0;
+    for (unsigned k = 0; k < WG / 64; ++k) {
+        if (k < wave) base += wave_sum[k];
+        tot += wave_sum[k];
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(WG) void k_scan_local(ScanArgs a)
+{
+    const uint64_t chunk0 = (uint64_t)blockIdx.x * SCAN_CHUNK;
+    const uint64_t t0 = chunk0 + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
+    unsigned w[SCAN_PER_THREAD];
+    uint64_t sum = 0;
+    bool bad = false;
+    for (int e = 0; e < SCAN_PER_THREAD; ++e) {
+        w[e] = (t0 + e < a.n_blocks) ? a.widths[t0 + e] : 0u;
+        bad |= w[e] > a.type_bits;
+        sum += 128ull * w[e];
+    }
+    if (bad && a.err_flag) *a.err_flag = 1u;
+    uint64_t total;
+    uint64_t run = wg_excl_scan(sum, &total);
+    for (int e = 0; e < SCAN_PER_THREAD; ++e) {
+        if (t0 + e < a.n_blocks) a.offsets[t0 + e] = (threadIdx.x == 0 && e == 0) ? total : run;
+        run += 128ull * w[e];
+    }
+}
+
+__global__ __launch_bounds__(WG) void k_scan_chunks(ScanArgs a)
+{
+    const uint64_t n_chunks = (a.n_blocks + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    uint64_t carry = 0;
+    for (uint64_t c0 = 0; c0 < n_chunks; c0 += WG) {
+        const uint64_t c = c0 + threadIdx.x;
+        const uint64_t v = c < n_chunks ? a.offsets[c * SCAN_CHUNK] : 0;
+        uint64_t total;
+        const uint64_t ex = wg_excl_scan(v, &total);
+        if (c < n_chunks) a.offsets[c * SCAN_CHUNK] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0 && a.total) *a.total = carry;
+}
+
+__global__ __launch_bounds__(WG) void k_scan_add(ScanArgs a)
+{
+    const uint64_t chunk0 = (uint64_t)blockIdx.x * SCAN_CHUNK;
+    const uint64_t base = a.offsets[chunk0];
+    const uint64_t t0 = chunk0 + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
+    for (int e = 0; e < SCAN_PER_THREAD; ++e)
+        if (t0 + e < a.n_blocks && !(threadIdx.x == 0 && e == 0)) a.offsets[t0 + e] += base;
+}
+
+inline hipError_t launch_widths_to_offsets(const ScanArgs& a, hipStream_t s)
+{
+    if (a.n_blocks == 0) {
+        if (a.total) return hipMemsetAsync(a.total, 0, sizeof(uint64_t), s);
+        return hipSuccess;
+    }
+    const unsigned n_chunks = (unsigned)((a.n_blocks + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    hipLaunchKernelGGL(k_scan_local, dim3(n_chunks), dim3(WG), 0, s, a);
+    hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(WG), 0, s, a);
+    hipLaunchKernelGGL(k_scan_add, dim3(n_chunks), dim3(WG), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace fl

@@ -1,0 +1,303 @@
+// fl_widths.hpp -- device-resident mixed-width columns: the caller loop of the reference,
+//     for b in 0..n_blocks { T::unchecked_unpack(widths[b], &packed[offsets[b]..], &mut out[b*1024..]) }
+// (bitpacking.rs:109-129; pack: bitpacking.rs:76-96; loop shape benches/bitpacking.rs:80-97) with
+// `widths[n_blocks]` (u8) and `offsets[n_blocks]` (u64 byte offsets) read ON THE DEVICE -- the
+// surface SURVEY.md 8(b) names.  No host plan, no sort, no 32-bit window, any block count.
+//
+// Mapping: ONE WAVEFRONT PER 1024-VALUE BLOCK, blocks in natural column order (a wavefront walks
+// BPW consecutive blocks, a workgroup 4*BPW).  The width is wave-uniform (an SGPR), so the width
+// dispatch of bitpacking.rs:115-128 is plain scalar arithmetic -- one kernel per element type, no
+// per-width code:
+//   * the packed block (128*W bytes, W rows of 8 cells) is fetched with 1-KiB-contiguous 16-byte
+//     loads (cell g*64+lane) and parked in a wave-private LDS image;
+//   * lane (i = lane/8, c = lane%8) then produces, for each 1-KiB group k of the unpacked block,
+//     the cell of address-row 8k+i, column c: logical row r = row_at(8k+i) starts at bit r*W of every
+//     FL lane's stream, so the lane reads packed cells (r*W/T, c) and (r*W/T + 1, c) from LDS and
+//     funnel-shifts / masks all 16/sizeof(T) lanes of the cell at once (macros.rs:144-164 with
+//     the shift in a register instead of a constant);
+//   * every global store instruction is 1 KiB contiguous (`sc1 nt`), every load 1 KiB contiguous.
+// LDS is wave-local (in-order per wave): no s_barrier.
+#pragma once
+#include "fl_kernels.hpp"
+
+namespace fl {
+
+struct WidthsArgs {
+    const char* packed;        // packed column base (unpack: in, pack: out)
+    char* unpacked;            // unpacked column base
+    const uint8_t* widths;     // [n_blocks]; nullptr = every block has `uniform_width`
+    const uint64_t* offsets;   // [n_blocks] byte offsets into `packed`; nullptr = b * 128 * uniform_width
+    uint32_t* err_flag;        // set to 1 if some widths[b] > T (that block is skipped); may be nullptr
+    uint64_t n_blocks;
+    uint64_t tiles_per_xcd;
+    unsigned uniform_width;
+};
+
+template <typename T> struct WaveBlock {
+    static constexpr int TB = Elem<T>::BITS;
+    static constexpr int LOG_TB = TB == 8 ? 3 : TB == 16 ? 4 : TB == 32 ? 5 : 6;
+    static constexpr int GROUPS = TB / 8;                  // 1-KiB groups of an unpacked block (and of a W=T packed block)
+    static constexpr unsigned BLOCK_BYTES = TB * 128;
+    static constexpr int PER_S = TB / 8;
+    static constexpr int KSTEP = 8 / PER_S;                // logical-row step between consecutive 1-KiB groups
+    using word_t = typename Cell<T>::word_t;
+
+    // logical row stored at address-row i (0..7) of 1-KiB group 0; group k adds k*KSTEP
+    // (address-row j <-> row FL_ORDER[(j % PER_S) * KSTEP] * 8 + j / PER_S; FL_ORDER is its own inverse, lib.rs:53-59)
+    __device__ __forceinline__ static unsigned row_base(unsigned i)
+    {
+        return ((0x73516240u >> (4 * ((i % PER_S) * KSTEP))) & 7u) * 8u + i / PER_S;
+    }
+    // cell index (16-byte units) of logical row r inside an unpacked block (macros.rs:20-24)
+    __device__ __forceinline__ static unsigned row_cell_rt(unsigned r)
+    {
+        return (r & 7u) * TB + ((0x73516240u >> (4 * (r >> 3))) & 7u) * (unsigned)sizeof(T);
+    }
+    // element mask of `bits` bits: u64/u32 plain; u16 one 16-bit field; u8 replicated into the two 16-bit fields
+    __device__ __forceinline__ static word_t field_mask(unsigned bits)
+    {
+        if constexpr (sizeof(T) == 8) return bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
+        else if constexpr (sizeof(T) == 4) return bits >= 32 ? ~0u : ((1u << bits) - 1u);
+        else if constexpr (sizeof(T) == 2) return (1u << bits) - 1u;
+        else return ((1u << bits) - 1u) * 0x00010001u;
+    }
+    // element-replicated mask (SWAR) -- Cell<T>::rep with a runtime width
+    __device__ __forceinline__ static word_t rep_mask(unsigned bits)
+    {
+        if constexpr (sizeof(T) == 8) return bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
+        else if constexpr (sizeof(T) == 4) return bits >= 32 ? ~0u : ((1u << bits) - 1u);
+        else if constexpr (sizeof(T) == 2) return ((1u << bits) - 1u) * 0x00010001u;
+        else return ((1u << bits) - 1u) * 0x01010101u;
+    }
+    // all elements of the cell:  ((nxt:cur) >> sh) & mask   -- the straddle of macros.rs:149-161
+    // (when the field does not straddle, nxt's bits land above the mask and vanish)
+    __device__ __forceinline__ static Cell<T> funnel(const Cell<T>& cur, const Cell<T>& nxt, unsigned sh, word_t m)
+    {
+        Cell<T> r;
+        if constexpr (sizeof(T) == 8) {
+            for (int i = 0; i < 2; ++i) r.x[i] = ((cur.x[i] >> sh) | ((nxt.x[i] << 1) << (63u - sh))) & m;
+        } else if constexpr (sizeof(T) == 4) {
+            for (int i = 0; i < 4; ++i) r.x[i] = __builtin_amdgcn_alignbit(nxt.x[i], cur.x[i], sh) & m;
+        } else if constexpr (sizeof(T) == 2) {
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t lo = __builtin_amdgcn_perm(nxt.x[i], cur.x[i], 0x05040100u);   // nxt.h0 : cur.h0
+                const uint32_t hi = __builtin_amdgcn_perm(nxt.x[i], cur.x[i], 0x07060302u);   // nxt.h1 : cur.h1
+                r.x[i] = ((lo >> sh) & m) | (((hi >> sh) & m) << 16);
+            }
+        } else {
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t ev = __builtin_amdgcn_perm(nxt.x[i], cur.x[i], 0x06020400u);   // nxt.b2:cur.b2 | nxt.b0:cur.b0
+                const uint32_t od = __builtin_amdgcn_perm(nxt.x[i], cur.x[i], 0x07030501u);   // nxt.b3:cur.b3 | nxt.b1:cur.b1
+                r.x[i] = ((ev >> sh) & m) | (((od >> sh) & m) << 8);
+            }
+        }
+        return r;
+    }
+};
+
+// Per-wavefront metadata of its BPW blocks: lane j holds widths[first+j] / offsets[first+j]; the loop
+// broadcasts them with v_readlane (wave-uniform SGPR values).
+template <int BPW>
+struct WaveMeta {
+    unsigned w;
+    uint64_t off;
+    __device__ __forceinline__ WaveMeta(const WidthsArgs& a, uint64_t first_blk, unsigned nb, unsigned lane)
+    {
+        static_assert(BPW <= 64, "one lane per block of the wavefront");
+        w = a.uniform_width;
+        off = (first_blk + lane) * (uint64_t)(128u * a.uniform_width);
+        if (lane < nb) {
+            if (a.widths) w = a.widths[first_blk + lane];
+            if (a.offsets) off = a.offsets[first_blk + lane];
+        }
+    }
+    __device__ __forceinline__ unsigned width(unsigned j) const { return __builtin_amdgcn_readlane(w, j); }
+    __device__ __forceinline__ uint64_t offset(unsigned j) const
+    {
+        const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)off, j), hi = __builtin_amdgcn_readlane((uint32_t)(off >> 32), j);
+        return ((uint64_t)hi << 32) | lo;
+    }
+};
+
+// unchecked_unpack over per-block widths (bitpacking.rs:109-129).
+template <typename T, int BPW, int MAXWAVES, bool PREFETCH>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, MAXWAVES)))
+void k_unpack_widths(WidthsArgs a)
+{
+    using G = WaveBlock<T>;
+    constexpr int TB = G::TB;
+    constexpr int TILE = BPW * (WG / 64);
+    __shared__ __attribute__((aligned(16))) char lds_all[(WG / 64) * G::BLOCK_BYTES];
+    const uint64_t n_tiles = (a.n_blocks + TILE - 1) / TILE;
+    const uint64_t tile = (uint64_t)(blockIdx.x & 7u) * a.tiles_per_xcd + (blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
+    const unsigned tid = threadIdx.x;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
+    const uint64_t first_blk = tile * TILE + (uint64_t)wave * BPW;
+    if (first_blk >= a.n_blocks) return;
+    const uint64_t left = a.n_blocks - first_blk;
+    const unsigned nb = left < (uint64_t)BPW ? (unsigned)left : (unsigned)BPW;
+    char* lds = lds_all + wave * G::BLOCK_BYTES;
+    const WaveMeta<BPW> meta(a, first_blk, nb, lane);
+
+    const unsigned c16 = (lane & 7u) * 16u;
+    const unsigned rbase = G::row_base(lane >> 3);
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(
+        a.unpacked + first_blk * G::BLOCK_BYTES, 0, nb * G::BLOCK_BYTES, 0x00020000);
+
+    u32x4 pk[G::GROUPS];
+    auto fetch = [&](unsigned j) {
+        const unsigned w = meta.width(j);
+        if (w > (unsigned)TB) return;
+        // wave-uniform descriptor over exactly this block's 128*w bytes: cells past it read as 0, no fault
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(a.packed) + meta.offset(j), 0, 128u * w, 0x00020000);
+        static_for<G::GROUPS>([&](auto Gi) {
+            constexpr int g = decltype(Gi)::value;
+            if (8u * g < w) pk[g] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16u + g * 1024u, 0, 0);
+        });
+    };
+    if constexpr (PREFETCH) fetch(0);
+    for (unsigned j = 0; j < nb; ++j) {
+        const unsigned w = meta.width(j);
+        if constexpr (!PREFETCH) fetch(j);
+        if (w > (unsigned)TB) {                               // bitpacking.rs:126 unreachable!()
+            if (a.err_flag && lane == 0) *a.err_flag = 1u;
+            if constexpr (PREFETCH) { if (j + 1 < nb) fetch(j + 1); }
+            continue;
+        }
+        const unsigned out_base = j * G::BLOCK_BYTES + lane * 16u;
+        if (w == 0) {                                         // macros.rs:118-125: 1024 zeros
+            if constexpr (PREFETCH) { if (j + 1 < nb) fetch(j + 1); }
+            const u32x4 z = {0, 0, 0, 0};
+            static_for<G::GROUPS>([&](auto K) {
+                __builtin_amdgcn_raw_buffer_store_b128(z, out_rs, out_base + decltype(K)::value * 1024u, 0, STORE_AUX);
+            });
+            continue;
+        }
+        static_for<G::GROUPS>([&](auto Gi) {
+            constexpr int g = decltype(Gi)::value;
+            if (8u * g < w) *reinterpret_cast<u32x4*>(lds + lane * 16u + g * 1024u) = pk[g];
+        });
+        wave_lds_fence();
+        if constexpr (PREFETCH) { if (j + 1 < nb) fetch(j + 1); }
+        const typename G::word_t m = G::field_mask(w);
+        unsigned bit = rbase * w;
+        const unsigned step = G::KSTEP * w;
+        const unsigned last = (w - 1u) * 128u;
+        static_for<G::GROUPS>([&](auto K) {
+            const unsigned word = bit >> G::LOG_TB, sh = bit & (TB - 1u);
+            const unsigned a0 = word * 128u;
+            const unsigned a1 = a0 + 128u < last ? a0 + 128u : last;        // the last row never reads past the end (macros.rs:156)
+            const Cell<T> cur = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(lds + a0 + c16));
+            const Cell<T> nxt = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(lds + a1 + c16));
+            const Cell<T> v = G::funnel(cur, nxt, sh, m);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rs, out_base + decltype(K)::value * 1024u, 0, STORE_AUX);
+            bit += step;
+        });
+        wave_lds_fence();
+    }
+}
+
+// unchecked_pack over per-block widths (bitpacking.rs:76-96).  The unpacked block is parked in the
+// wave's LDS image; lane (i, c) then assembles packed cells (w = i + 8m, c): word w of an FL lane's
+// stream holds bits [w*T, (w+1)*T), i.e. the fields of rows floor(w*T/W) .. floor(((w+1)*T-1)/W)
+// (macros.rs:72-92 regrouped by destination word instead of by source row).
+template <typename T, int BPW, int MAXWAVES>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, MAXWAVES)))
+void k_pack_widths(WidthsArgs a)
+{
+    using G = WaveBlock<T>;
+    using word_t = typename G::word_t;
+    constexpr int TB = G::TB;
+    constexpr int TILE = BPW * (WG / 64);
+    __shared__ __attribute__((aligned(16))) char lds_all[(WG / 64) * G::BLOCK_BYTES];
+    const uint64_t n_tiles = (a.n_blocks + TILE - 1) / TILE;
+    const uint64_t tile = (uint64_t)(blockIdx.x & 7u) * a.tiles_per_xcd + (blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
+    const unsigned tid = threadIdx.x;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
+    const uint64_t first_blk = tile * TILE + (uint64_t)wave * BPW;
+    if (first_blk >= a.n_blocks) return;
+    const uint64_t left = a.n_blocks - first_blk;
+    const unsigned nb = left < (uint64_t)BPW ? (unsigned)left : (unsigned)BPW;
+    char* lds = lds_all + wave * G::BLOCK_BYTES;
+    const WaveMeta<BPW> meta(a, first_blk, nb, lane);
+    const unsigned c16 = (lane & 7u) * 16u, i = lane >> 3;
+    const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(
+        a.unpacked + first_blk * G::BLOCK_BYTES, 0, nb * G::BLOCK_BYTES, 0x00020000);
+
+    u32x4 un[G::GROUPS];
+    auto fetch = [&](unsigned j) {
+        static_for<G::GROUPS>([&](auto K) {
+            un[decltype(K)::value] = __builtin_amdgcn_raw_buffer_load_b128(in_rs, j * G::BLOCK_BYTES + decltype(K)::value * 1024u + lane * 16u, 0, 2 /* nt */);
+        });
+    };
+    fetch(0);
+    for (unsigned j = 0; j < nb; ++j) {
+        const unsigned w = meta.width(j);
+        static_for<G::GROUPS>([&](auto K) { *reinterpret_cast<u32x4*>(lds + lane * 16u + decltype(K)::value * 1024u) = un[decltype(K)::value]; });
+        wave_lds_fence();
+        if (j + 1 < nb) fetch(j + 1);
+        if (w > (unsigned)TB) {                               // bitpacking.rs:93 unreachable!()
+            if (a.err_flag && lane == 0) *a.err_flag = 1u;
+        } else if (w != 0) {                                  // macros.rs:52-53: W == 0 writes nothing
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(a.packed) + meta.offset(j), 0, 128u * w, 0x00020000);
+            for (unsigned m8 = 0; m8 < w; m8 += 8) {          // wave-uniform trip count: ceil(w/8) groups of 8 packed rows
+                const unsigned wd = m8 + i;                   // this lane's packed word-row
+                const unsigned lo_bit = wd * TB;
+                unsigned r = lo_bit / w;                      // first row with bits in this word
+                const unsigned r_end = wd < w ? (lo_bit + TB - 1u) / w : r;   // last such row (inclusive); idle lanes: empty
+                Cell<T> acc = Cell<T>::zero();
+                if (wd < w) {
+                    for (; r <= r_end; ++r) {
+                        const Cell<T> s = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(lds + G::row_cell_rt(r) * 16u + c16));
+                        const unsigned fb = r * w;            // first stream bit of row r's field
+                        if (fb >= lo_bit) {                   // field starts in this word: (src & mask(keep)) << shift  (macros.rs:73,79)
+                            const unsigned sh = fb - lo_bit;
+                            const unsigned keep = w < TB - sh ? w : TB - sh;
+                            const word_t mk = G::rep_mask(keep);
+                            for (int x = 0; x < Cell<T>::NW; ++x) acc.x[x] |= (s.x[x] & mk) << sh;
+                        } else {                              // carry of a straddling field: (src & mask(W)) >> (W - rem)  (macros.rs:92)
+                            const unsigned sh = lo_bit - fb;
+                            const word_t mk = G::rep_mask(w - sh);
+                            for (int x = 0; x < Cell<T>::NW; ++x) acc.x[x] |= (s.x[x] >> sh) & mk;
+                        }
+                    }
+                }
+                // rows past the block's 128*w bytes fall outside the descriptor and are dropped
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rs, wd * 128u + c16, 0, STORE_AUX);
+            }
+        }
+        wave_lds_fence();
+    }
+}
+
+typedef hipError_t (*widths_launch_t)(const WidthsArgs&, hipStream_t);
+
+// Shipped shape (profiles/abmixed_r02a.txt, abmixed_r02b.txt; u32, 9 765 625 blocks, widths 1 + b mod 32 and
+// seeded-random): one block per wavefront, <= 6 waves/SIMD.  More blocks per wavefront with a register
+// prefetch of the next block (BPW 2..16) measured 1-5 % slower; the round-1 bucketed plan kernel 5-10 % slower;
+// a bare 33:64 read:write stream of the same bytes reaches 6.23-6.53 TB/s where this kernel reaches 6.37-6.66.
+constexpr int WIDTHS_BPW = 1;
+constexpr int WIDTHS_MAXWAVES = 6;
+
+template <typename T, bool PACK>
+hipError_t launch_widths(const WidthsArgs& a0, hipStream_t s)
+{
+    if (a0.n_blocks == 0) return hipSuccess;
+    WidthsArgs a = a0;
+    constexpr int TILE = WIDTHS_BPW * (WG / 64);
+    const uint64_t n_tiles = (a.n_blocks + TILE - 1) / TILE;
+    a.tiles_per_xcd = (n_tiles + 7) / 8;
+    if (a.tiles_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;   // > 2^33 blocks in one launch
+    const dim3 grid((unsigned)(a.tiles_per_xcd * 8));
+    if constexpr (PACK) hipLaunchKernelGGL((k_pack_widths<T, WIDTHS_BPW, WIDTHS_MAXWAVES>), grid, dim3(WG), 0, s, a);
+    else hipLaunchKernelGGL((k_unpack_widths<T, WIDTHS_BPW, WIDTHS_MAXWAVES, false>), grid, dim3(WG), 0, s, a);
+    return hipGetLastError();
+}
+
+template <typename T> widths_launch_t widths_launcher(bool pack);
+
+}  // namespace fl

@@ -24,10 +24,13 @@
  *       synchronises, never allocates, retains no pointer.
  *   HOST tier    fl_<ty>_<method>_host(..., n_blocks)
  *       Same semantics with HOST pointers (the trait methods' `&[T]` slices,
- *       e.g. bitpacking.rs:19,33): stages through device memory, runs the same
- *       kernels, synchronises before returning.  n_blocks = 1 is the exact
- *       shape of one trait-method call.  There is no CPU code path: without a
- *       GPU these return FL_ERR_HIP.
+ *       e.g. bitpacking.rs:19,33): runs the same kernels on the calling
+ *       thread's current device and synchronises before returning.  n_blocks = 1
+ *       is the exact shape of one trait-method call.  Small calls are zero-copy
+ *       (the kernel reads/writes a pinned host buffer over PCIe); large calls
+ *       stage through a cached device buffer; after a thread's first call
+ *       nothing is allocated (fl_host_release).  There is no CPU code path:
+ *       without a GPU these return FL_ERR_HIP.
  *
  * Preconditions.  Device pointers 16-byte aligned (every block is a multiple
  * of 128 bytes, so block starts stay aligned; 128-byte alignment of the
@@ -75,19 +78,41 @@ const char *fl_status_string(int status);
 int fl_last_hip_error(void);
 /* Elements in one packed block: 1024*width/T (bitpacking.rs:77); 0 if width > T. */
 size_t fl_packed_len(unsigned type_bits, unsigned width);
+/* The host tier keeps one cached context per calling thread (a private stream, a pinned staging
+ * buffer, a device scratch buffer; see "HOST tier" above) so that its calls allocate nothing after
+ * the first one, like the allocation-free reference (lib.rs:3).  It is freed at thread exit; this
+ * frees the calling thread's context early. */
+void fl_host_release(void);
 
 /*
  * Mixed-width columns (BASELINE.json config 5): block b has its own width widths[b].
  * The reference has no multi-block API; this is its caller loop
  *     for b in blocks { T::unchecked_unpack(widths[b], &packed[off[b]..], &mut out[b*1024..]) }
- * (bitpacking.rs:109-129; loop shape of benches/bitpacking.rs:90-97) moved on-device.
- * Packed blocks are laid out back to back: off[b] = sum_{i<b} 128*widths[i] bytes.
- * A plan is built ONCE per column from the HOST widths array (bucket blocks by width,
- * prefix-sum the offsets, cut the buckets into 32-block tiles, upload to the current
- * device); the pack/unpack calls are then allocation-free and asynchronous like every other
- * device-tier call: ONE kernel launch on `stream`, each workgroup dispatching on its tile's
- * width.  The plan must be used on the device it was
- * created on and destroyed by the caller.
+ * (bitpacking.rs:109-129; pack: bitpacking.rs:76-96; loop shape of benches/bitpacking.rs:80-97)
+ * moved on-device.  The surface is the one SURVEY.md 8(b) names: two DEVICE arrays,
+ *     widths [n_blocks]  uint8   width of block b (<= T)
+ *     offsets[n_blocks]  uint64  byte offset of block b's 128*widths[b] bytes in the packed column
+ *                                (multiples of 16; back-to-back blocks give multiples of 128)
+ * read by the kernel itself (fl_<ty>_unpack_widths / fl_<ty>_pack_widths below): one wavefront per
+ * block, blocks in column order, ONE launch, no host pass over the column, no allocation, any
+ * block count.  A block whose width exceeds T is skipped and *err_flag (a device uint32, may be
+ * NULL) is set to 1 -- the device-side form of bitpacking.rs:93/126 unreachable!().
+ *
+ * fl_widths_to_offsets builds the back-to-back offsets on the device: offsets[b] = sum_{i<b}
+ * 128*widths[i] (exclusive prefix sum, three small launches on `stream`, no scratch memory),
+ * *total_bytes (device uint64, may be NULL) = the packed column's size, *err_flag set to 1 if
+ * some width exceeds type_bits.
+ */
+int fl_widths_to_offsets(unsigned type_bits, const uint8_t *widths, size_t n_blocks,
+                         uint64_t *offsets, uint64_t *total_bytes, uint32_t *err_flag,
+                         void *stream);
+
+/*
+ * Convenience owner of the two device arrays for callers that hold the widths on the HOST:
+ * create validates the widths (FL_ERR_WIDTH), uploads them to the current device, runs
+ * fl_widths_to_offsets and reads back the packed size.  fl_<ty>_unpack_mixed / pack_mixed are
+ * fl_<ty>_unpack_widths / pack_widths over the plan's arrays.  The plan must be used on the
+ * device it was created on and destroyed by the caller.
  */
 typedef struct fl_mixed_plan fl_mixed_plan;
 int fl_mixed_plan_create(unsigned type_bits, const uint8_t *widths, size_t n_blocks,
@@ -96,8 +121,9 @@ void fl_mixed_plan_destroy(fl_mixed_plan *plan);
 size_t fl_mixed_plan_n_blocks(const fl_mixed_plan *plan);
 /* total packed bytes of the column = sum 128*widths[b] */
 uint64_t fl_mixed_plan_packed_bytes(const fl_mixed_plan *plan);
-/* device pointer to the uint64 byte offsets [n_blocks] (owned by the plan) */
+/* device pointers to the plan's uint64 byte offsets / uint8 widths [n_blocks] (owned by the plan) */
 const uint64_t *fl_mixed_plan_offsets(const fl_mixed_plan *plan);
+const uint8_t *fl_mixed_plan_widths(const fl_mixed_plan *plan);
 
 #define FL_DECLARE_TYPE(T, S)                                                                   \
     /* BitPacking::unchecked_pack (bitpacking.rs:30,76-96) -> pack::<W> (:65-74) */             \
@@ -154,7 +180,13 @@ const uint64_t *fl_mixed_plan_offsets(const fl_mixed_plan *plan);
     int fl_##S##_transpose(const T *in, T *out, size_t n_blocks, void *stream);                 \
     /* Transpose::untranspose (transpose.rs:6,17-22) */                                         \
     int fl_##S##_untranspose(const T *in, T *out, size_t n_blocks, void *stream);               \
-    /* unchecked_unpack / unchecked_pack over a mixed-width plan (see fl_mixed_plan) */          \
+    /* unchecked_unpack / unchecked_pack (bitpacking.rs:109-129, :76-96) looped over blocks with    \
+     * per-block device widths[] / offsets[] (see "Mixed-width columns" above) */                  \
+    int fl_##S##_unpack_widths(const uint8_t *widths, const uint64_t *offsets, const T *packed,  \
+                               T *out, size_t n_blocks, uint32_t *err_flag, void *stream);       \
+    int fl_##S##_pack_widths(const uint8_t *widths, const uint64_t *offsets, const T *in,        \
+                             T *packed, size_t n_blocks, uint32_t *err_flag, void *stream);      \
+    /* the same over a mixed-width plan (see fl_mixed_plan) */                                     \
     int fl_##S##_unpack_mixed(const fl_mixed_plan *plan, const T *packed, T *out, void *stream); \
     int fl_##S##_pack_mixed(const fl_mixed_plan *plan, const T *in, T *packed, void *stream);    \
     /* ---- host-pointer tier: the trait methods' own slice arguments ---- */                   \

@@ -60,6 +60,8 @@ template <typename T> struct Abi;
         static constexpr auto unpack_compare = fl_##S##_unpack_compare;                              \
         static constexpr auto unpack_mixed = fl_##S##_unpack_mixed;                                  \
         static constexpr auto pack_mixed = fl_##S##_pack_mixed;                                      \
+        static constexpr auto unpack_widths = fl_##S##_unpack_widths;                                \
+        static constexpr auto pack_widths = fl_##S##_pack_widths;                                    \
         static constexpr auto pack_host = fl_##S##_pack_host;                                        \
         static constexpr auto unpack_host = fl_##S##_unpack_host;                                    \
         static constexpr auto unpack_single_host = fl_##S##_unpack_single_host;                      \
@@ -234,8 +236,25 @@ public:
     { detail::check(detail::Abi<T>::unpack_mixed(plan_, d_packed, d_out, stream), "unpack_mixed"); }
     void pack_device(const T* d_in, T* d_packed, void* stream = nullptr) const
     { detail::check(detail::Abi<T>::pack_mixed(plan_, d_in, d_packed, stream), "pack_mixed"); }
+    const std::uint8_t* widths_device() const { return fl_mixed_plan_widths(plan_); }
+    const std::uint64_t* offsets_device() const { return fl_mixed_plan_offsets(plan_); }
 private:
     fl_mixed_plan* plan_ = nullptr;
 };
+
+// The same loop with the per-block widths / byte offsets already resident in HBM:
+// nothing is built on the host.  A width > T skips that block and sets *d_err_flag (device uint32, may be null).
+template <typename T>
+inline void unpack_widths_device(const std::uint8_t* d_widths, const std::uint64_t* d_offsets, const T* d_packed, T* d_out,
+                                 std::size_t n_blocks, std::uint32_t* d_err_flag = nullptr, void* stream = nullptr)
+{ detail::check(detail::Abi<T>::unpack_widths(d_widths, d_offsets, d_packed, d_out, n_blocks, d_err_flag, stream), "unpack_widths"); }
+template <typename T>
+inline void pack_widths_device(const std::uint8_t* d_widths, const std::uint64_t* d_offsets, const T* d_in, T* d_packed,
+                               std::size_t n_blocks, std::uint32_t* d_err_flag = nullptr, void* stream = nullptr)
+{ detail::check(detail::Abi<T>::pack_widths(d_widths, d_offsets, d_in, d_packed, n_blocks, d_err_flag, stream), "pack_widths"); }
+template <typename T>
+inline void widths_to_offsets_device(const std::uint8_t* d_widths, std::size_t n_blocks, std::uint64_t* d_offsets,
+                                     std::uint64_t* d_total_bytes = nullptr, std::uint32_t* d_err_flag = nullptr, void* stream = nullptr)
+{ detail::check(fl_widths_to_offsets(sizeof(T) * 8, d_widths, n_blocks, d_offsets, d_total_bytes, d_err_flag, stream), "widths_to_offsets"); }
 
 }  // namespace fastlanes

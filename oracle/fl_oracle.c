@@ -100,7 +100,15 @@ enum { FL_BODY_STORE = 0, FL_BODY_ADD_REF = 1, FL_BODY_UNDELTA = 2 };
 /* BASELINE.json configs 2 and 4 (+ W=10 of bitpacking.rs:248-256) */
 #define FL_FAST_LIST_ FL_FAST_(0, 7) FL_FAST_(1, 7) FL_FAST_(2, 7) FL_FAST_(1, 10) \
     FL_FAST_(0, 12) FL_FAST_(1, 12) FL_FAST_(3, 12)
+/* BASELINE.json config 5 (u32, every width): fl_oracle_fast_unpack_mixed_u32 */
+#define FL_MIXED_CASES_ \
+    FL_MIXED_(0) FL_MIXED_(1) FL_MIXED_(2) FL_MIXED_(3) FL_MIXED_(4) FL_MIXED_(5) FL_MIXED_(6) FL_MIXED_(7)       \
+    FL_MIXED_(8) FL_MIXED_(9) FL_MIXED_(10) FL_MIXED_(11) FL_MIXED_(12) FL_MIXED_(13) FL_MIXED_(14) FL_MIXED_(15)  \
+    FL_MIXED_(16) FL_MIXED_(17) FL_MIXED_(18) FL_MIXED_(19) FL_MIXED_(20) FL_MIXED_(21) FL_MIXED_(22) FL_MIXED_(23) \
+    FL_MIXED_(24) FL_MIXED_(25) FL_MIXED_(26) FL_MIXED_(27) FL_MIXED_(28) FL_MIXED_(29) FL_MIXED_(30) FL_MIXED_(31) \
+    FL_MIXED_(32)
 #include "fl_oracle_impl.inc"
+#undef FL_MIXED_CASES_
 #undef T_
 #undef S_
 #undef TB_

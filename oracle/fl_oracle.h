@@ -80,6 +80,13 @@ int fl_oracle_parallel_fill(void *base, size_t bytes_per_block, size_t n_blocks,
     int fl_oracle_block_hashes_##S(const T *v, size_t n_blocks, uint64_t *sum,            \
                                    uint64_t *wsum, unsigned nthreads);
 
+/* CPU-baseline helper for BASELINE.json config 5 (u32 only): the reference's caller loop over
+ * per-block widths (bitpacking.rs:109-129), every width 0..=32 specialised like the fast family;
+ * offsets are byte offsets into `packed`; returns 1 on a width > 32. */
+int fl_oracle_fast_unpack_mixed_u32(const uint8_t *widths, const uint64_t *offsets,
+                                    const uint32_t *packed, uint32_t *out, size_t n_blocks,
+                                    unsigned nthreads);
+
 FL_ORACLE_DECL(uint8_t, u8)
 FL_ORACLE_DECL(uint16_t, u16)
 FL_ORACLE_DECL(uint32_t, u32)

@@ -4,6 +4,7 @@
 //   g++ -std=c++17 -I include -I /opt/rocm/include tests/cpp/test_trait_mirror.cpp -L fastlanes_amd -lfastlanes_amd -L /opt/rocm/lib -lamdhip64
 #include <cstdio>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #define __HIP_PLATFORM_AMD__ 1
@@ -14,6 +15,7 @@
 using namespace fastlanes;
 
 static int failures = 0;
+static int round_trips = 0;
 #define EXPECT(cond) do { if (!(cond)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #cond); ++failures; } } while (0)
 
 // lib.rs:53-59
@@ -56,10 +58,39 @@ static void test_unpack_single()
     static uint32_t values[1024], packed[512];
     for (int i = 0; i < 1024; ++i) values[i] = i;
     BitPacking<uint32_t>::pack<16>(values, packed);
-    for (int i = 0; i < 1024; i += 53) {
+    for (int i = 0; i < 1024; ++i) {        // every index, as bitpacking.rs:264
         EXPECT(BitPacking<uint32_t>::unpack_single<16>(packed, i) == values[i]);
         EXPECT(BitPacking<uint32_t>::unchecked_unpack_single(16, packed, 512, i) == values[i]);
     }
+}
+
+// bitpacking.rs:273-315: try_round_trip::<T, W>() for every (T, W) -- the reference's 124-case matrix
+// (seq!(W in 0..=8) for u8 ... seq!(W in 0..=64) for u64), unpack_single for EVERY index, through the trait mirror.
+template <typename T, size_t W> static void try_round_trip()
+{
+    constexpr size_t TB = sizeof(T) * 8;
+    static T values[1024], packed[W ? 1024 * W / TB : 1], unpacked[1024];
+    for (size_t i = 0; i < 1024; ++i) values[i] = (T)(i % ((size_t)1 << (W % TB)));   // bitpacking.rs:281
+    BitPacking<T>::template pack<W>(values, packed);
+    std::memset(unpacked, 0xEE, sizeof unpacked);
+    BitPacking<T>::template unpack<W>(packed, unpacked);
+    EXPECT(std::memcmp(unpacked, values, sizeof values) == 0);
+    int bad = 0;
+    for (size_t i = 0; i < 1024; ++i) {
+        bad += BitPacking<T>::template unpack_single<W>(packed, i) != values[i];
+        bad += BitPacking<T>::unchecked_unpack_single(W, packed, 1024 * W / TB, i) != values[i];
+    }
+    if (bad) { std::printf("FAIL try_round_trip<u%zu, %zu>: %d unpack_single mismatches\n", TB, W, bad); ++failures; }
+    ++round_trips;
+}
+template <typename T, size_t... Ws> static void round_trip_all(std::index_sequence<Ws...>) { (try_round_trip<T, Ws>(), ...); }
+static void test_round_trip_matrix()
+{
+    round_trip_all<uint8_t>(std::make_index_sequence<9>{});
+    round_trip_all<uint16_t>(std::make_index_sequence<17>{});
+    round_trip_all<uint32_t>(std::make_index_sequence<33>{});
+    round_trip_all<uint64_t>(std::make_index_sequence<65>{});
+    EXPECT(round_trips == 124);
 }
 
 // delta.rs:80-107
@@ -178,6 +209,19 @@ static void test_device_tier()
     plan.pack_device(dv.p, dm.p);
     plan.unpack_device(dm.p, dmu.p);
     EXPECT(dmu.down() == v);
+    // the same column through the device-resident widths[] / offsets[] surface (nothing built on the host)
+    DevVec<uint8_t> dw(N);
+    dw.up(widths);
+    DevVec<uint64_t> doff(N), dtot(1);
+    DevVec<uint32_t> derr(1), dm2(plan.packed_bytes() / 4), dmu2(N * 1024);
+    (void)hipMemset(derr.p, 0, 4);
+    widths_to_offsets_device<uint32_t>(dw.p, N, doff.p, dtot.p, derr.p);
+    pack_widths_device<uint32_t>(dw.p, doff.p, dv.p, dm2.p, N, derr.p);
+    unpack_widths_device<uint32_t>(dw.p, doff.p, dm2.p, dmu2.p, N, derr.p);
+    EXPECT(dtot.down()[0] == plan.packed_bytes());
+    EXPECT(dm2.down() == dm.down());
+    EXPECT(dmu2.down() == v);
+    EXPECT(derr.down()[0] == 0u);
     EXPECT(hipDeviceSynchronize() == hipSuccess);
 }
 
@@ -188,6 +232,7 @@ int main()
         pack_u16_into_u3_no_unsafe();
         test_unchecked_pack();
         test_unpack_single();
+        test_round_trip_matrix();
         test_delta();
         test_ffor();
         test_panics();

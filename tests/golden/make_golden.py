@@ -9,7 +9,8 @@ counter-based generator in tests/datagen.py, expected outputs are SHA-256
 digests of the oracle's little-endian output bytes.  The oracle itself is
 pinned separately (tests/test_oracle_reference_tests.py).  The fixture lets
 the GPU parity tests run against committed data, independent of oracle/ at
-run time, and makes any future oracle change visible as a diff.
+run time, and makes any future oracle change visible as a diff.  Committed
+digests are immutable: the script refuses to overwrite one that changed.
 """
 import json
 import os
@@ -59,6 +60,18 @@ def main():
             "transpose": sha(o.batch("transpose", ty, None, i["values"])),
             "untranspose": sha(o.batch("untranspose", ty, None, i["values"])),
         }
+    # unpack_single (bitpacking.rs:132-179): the closed-form reader, EVERY index of two blocks per (T, W)
+    # -- the matrix of the reference's try_round_trip (bitpacking.rs:273-315)
+    out["unpack_single"] = {}
+    for ty in ("u8", "u16", "u32", "u64"):
+        T = tbits(ty)
+        dt = values(ty, 1, 0).dtype
+        for w in range(T + 1):
+            pl = packed_len(ty, w)
+            pk = values(ty, 2 * pl, 3300 + 64 * T + w)
+            got = np.array([o.unpack_single(ty, w, pk[(i // 1024) * pl:(i // 1024 + 1) * pl], i % 1024)
+                            for i in range(2048)], dtype=dt)
+            out["unpack_single"][f"{ty}_w{w}"] = sha(got)
     # Known-answer vectors of SURVEY.md section 8(c) (independently model-derived there)
     out["survey_kats"] = {
         "KAT-2 u16 W=3 v[i]=i%8": "f949547d2b920f409dc21441e8ce7d412965a9ff3eac94d551362f689372db20",
@@ -67,9 +80,30 @@ def main():
         "KAT-5 u64 W=17 v[i]=(i*2654435761)&0x1FFFF": "6f2ff76d32f1ac12771043c4d884b8a7972fa1a6e5f15b18e9cd3ce3f8b510f5",
         "KAT-7 u16 W=9 delta bench": "7123aa8cd64fba3555abb4cf3180f8b273745ba6cf244314f7901bfcdf9db2a4",
     }
-    with open(os.path.join(HERE, "golden.json"), "w") as f:
+    # Committed vectors are IMMUTABLE: a regenerated digest that differs from the committed one means the
+    # oracle changed behaviour -- that must fail loudly, not silently rewrite the fixture.  New keys may be
+    # added; `--force` is for a deliberate, reviewed change only.
+    path = os.path.join(HERE, "golden.json")
+    if os.path.exists(path) and "--force" not in sys.argv:
+        old = json.load(open(path))
+
+        def changed(a, b, where):
+            bad = []
+            for k, v in a.items():
+                if k not in b:
+                    bad.append(f"{where}{k} (removed)")
+                elif isinstance(v, dict):
+                    bad += changed(v, b[k], f"{where}{k}/")
+                elif v != b[k]:
+                    bad.append(f"{where}{k}")
+            return bad
+        bad = changed(old, out, "")
+        if bad:
+            sys.exit(f"refusing to overwrite {len(bad)} committed golden vector(s): {bad[:8]} ... "
+                     "(the oracle's output changed; rerun with --force only after reviewing why)")
+    with open(path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
-    print("wrote golden.json with", len(out["cases"]), "cases")
+    print("wrote golden.json with", len(out["cases"]), "cases +", len(out["unpack_single"]), "unpack_single digests")
 
 
 if __name__ == "__main__":

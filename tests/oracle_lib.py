@@ -231,6 +231,20 @@ class Oracle:
         return out
 
 
+    def fast_unpack_mixed_u32(self, widths, offsets, packed, n_blocks=None, nthreads=1, out=None):
+        """CPU baseline of BASELINE config 5: the caller loop over per-block widths (bitpacking.rs:109-129)."""
+        widths = np.ascontiguousarray(widths, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        packed = np.ascontiguousarray(packed, dtype=np.uint32)
+        n = widths.size if n_blocks is None else n_blocks
+        out = np.zeros(n * 1024, dtype=np.uint32) if out is None else out
+        rc = self.lib.fl_oracle_fast_unpack_mixed_u32(self._p(widths), self._p(offsets), self._p(packed), self._p(out),
+                                                      ctypes.c_size_t(n), ctypes.c_uint(nthreads))
+        if rc:
+            raise ValueError(f"oracle fast mixed rc={rc}")
+        return out
+
+
 def load_native_oracle():
     """-march=native build for the CPU-baseline leg (falls back to the portable build)."""
     try:

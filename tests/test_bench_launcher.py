@@ -1,0 +1,68 @@
+"""CPU: `bench.py --gpus N` really runs N ranks.  With no torchrun environment it spawns them itself (one process
+per rank, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), under torch.distributed.run it is one of N.  --dry-run
+keeps every piece of launcher plumbing real (spawn, gloo rendezvous, barrier, max-reduce, all_gather, the
+block-range sharding of the 10 B-integer column) and skips only the GPU work -- its line says so and carries no
+number, so it can never be mistaken for a measurement."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _clean_env():
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+
+
+def _one_json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout          # rank 0 prints ONE line, the other ranks nothing
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_self_spawn_runs_n_ranks(n):
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--backend", "gloo", "--dry-run", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=_clean_env())
+    assert r.returncode == 0, r.stderr
+    out = _one_json_line(r.stdout)
+    assert out["n_gpus"] == n and out["dry_run"] is True and out["value"] is None
+    assert out["ranks"] == list(range(n))
+    assert out["blocks_per_rank"] == [10_000_000] * n                     # weak-scaled headline: 10 M blocks per GPU
+    c5 = out["config5_strong"]["per_rank"]                                # strong-scaled 10 B-integer column
+    assert [p["rank"] for p in c5] == list(range(n))
+    assert sum(p["blocks"] for p in c5) == 9_765_625
+    assert all(c5[i]["first_block"] + c5[i]["blocks"] == c5[i + 1]["first_block"] for i in range(n - 1))
+    if n == 8:
+        assert [p["blocks"] for p in c5] == [1_220_704] + [1_220_703] * 7
+
+
+def test_under_torch_distributed_run():
+    """The driver's launch line: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH,
+                        "--gpus", "2", "--backend", "gloo", "--dry-run", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=_clean_env())
+    assert r.returncode == 0, r.stderr
+    out = _one_json_line(r.stdout)
+    assert out["n_gpus"] == 2 and out["ranks"] == [0, 1]
+
+
+def test_a_failing_rank_fails_the_launch():
+    """No GPU here: without --dry-run every rank must exit loudly (there is no CPU path) and the launcher must
+    return non-zero instead of hanging on the survivors."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=_clean_env())
+    assert r.returncode != 0
+    assert "needs a GPU" in r.stderr

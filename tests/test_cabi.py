@@ -24,14 +24,14 @@ def _header_symbols():
     body = text.split("#define FL_DECLARE_TYPE(T, S)")[1].split("FL_DECLARE_TYPE(uint8_t, u8)")[0]
     per_type = re.findall(r"fl_##S##_(\w+)\(", body)
     syms = [f"fl_{ty}_{m}" for ty in ("u8", "u16", "u32", "u64") for m in per_type]
-    syms += re.findall(r"\b(fl_(?:version|status_string|last_hip_error|packed_len|mixed_plan_\w+))\(", text)
+    syms += re.findall(r"\b(fl_(?:version|status_string|last_hip_error|packed_len|widths_to_offsets|host_release|mixed_plan_\w+))\(", text)
     return sorted(set(syms))
 
 
 def test_every_declared_symbol_is_exported(lib):
     import fastlanes_amd
     syms = _header_symbols()
-    assert len(syms) == 4 * 27 + 9
+    assert len(syms) == 4 * 29 + 12
     assert sorted(fastlanes_amd.exported_symbols()) == syms
     for s in syms:
         assert hasattr(lib, s), s
@@ -69,6 +69,36 @@ def test_python_mirror_raises_like_the_reference():
         fl.BitPacking.pack(17, np.zeros(1024, dtype=np.uint16))
     with pytest.raises(ValueError):
         fl.BitPacking.pack(3, np.zeros(1000, dtype=np.uint16))
+
+
+def test_python_mirror_checks_every_output_length():
+    """A short caller-supplied `output` would be overrun by the kernel (it sizes its stores from n_blocks):
+    every method checks it like the reference's length asserts (bitpacking.rs:78-80,111-113), before any call
+    into the library (so this needs no GPU)."""
+    import fastlanes_amd as fl
+    v = np.zeros(2048, dtype=np.uint16)
+    pk = np.zeros(2 * 192, dtype=np.uint16)
+    base = np.zeros(2 * 64, dtype=np.uint16)
+    short_un, short_pk = np.zeros(2047, dtype=np.uint16), np.zeros(191, dtype=np.uint16)
+    calls = [
+        lambda: fl.BitPacking.pack(3, v, output=short_pk),
+        lambda: fl.BitPacking.unpack(3, pk, output=short_un),
+        lambda: fl.FoR.for_pack(3, v, 5, output=short_pk),
+        lambda: fl.FoR.unfor_pack(3, pk, 5, output=short_un),
+        lambda: fl.Delta.delta(v, base, output=short_un),
+        lambda: fl.Delta.undelta(v, base, output=short_un),
+        lambda: fl.Delta.undelta_pack(3, pk, base, output=short_un),
+        lambda: fl.Transpose.transpose(v, output=short_un),
+        lambda: fl.Transpose.untranspose(v, output=short_un),
+        lambda: fl.BitPacking.unpack(3, pk, output=np.zeros(2048, dtype=np.uint32)),      # wrong element type
+    ]
+    for i, c in enumerate(calls):
+        with pytest.raises((ValueError, TypeError)):
+            c()
+    with pytest.raises(fl.FastLanesError):           # 300 must not wrap to 44 in a uint8 cast (bitpacking.rs:93)
+        fl.MixedWidthPlan("u32", np.array([3, 300]))
+    with pytest.raises(fl.FastLanesError):
+        fl.MixedWidthPlan("u16", np.array([17], dtype=np.uint8))
 
 
 def test_product_never_touches_the_oracle():

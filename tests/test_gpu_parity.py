@@ -82,18 +82,34 @@ def test_delta_transpose_vs_oracle(fl, oracle, ty):
 
 
 @pytest.mark.parametrize("ty", TYS)
-def test_unpack_single_vs_oracle(fl, oracle, ty):
+def test_unpack_single_every_width_every_index(fl, oracle, ty):
+    """The reference's try_round_trip (bitpacking.rs:273-315) checks unpack_single for EVERY index of
+    every (T, W).  Same matrix here, two blocks per (T, W), one batched call each: against the oracle's
+    closed-form reader (bitpacking.rs:132-179), against the oracle's unpack()[i], against the GPU's own
+    unpack()[i] -- and the digest of the values against the committed golden fixture."""
     import torch
     T = tbits(ty)
-    n = 5
-    rng = np.random.default_rng(5 + T)
-    for w in sorted({0, 1, 3, T // 2, T - 1, T}):
-        pk = values(ty, n * packed_len(ty, w), 300 + w)
-        idx = rng.integers(0, n * 1024, size=777, dtype=np.int64)
-        idx[:4] = [0, 1023, 1024, n * 1024 - 1]
-        got = to_np(fl.BitPacking.unpack_single(w, to_dev(pk), torch.from_numpy(idx).cuda(), n_blocks=n), ty)
+    n = 2
+    idx = np.arange(n * 1024, dtype=np.int64)
+    didx = torch.from_numpy(idx).cuda()
+    for w in range(T + 1):
         pl = packed_len(ty, w)
-        want = [oracle.unpack_single(ty, w, pk[(i // 1024) * pl:(i // 1024 + 1) * pl], int(i % 1024)) for i in idx]
+        pk = values(ty, n * pl, 3300 + 64 * T + w)
+        dpk = to_dev(pk)
+        got = to_np(fl.BitPacking.unpack_single(w, dpk, didx, n_blocks=n), ty)
+        full = oracle.batch("unpack", ty, w, pk, n_blocks=n)
+        assert np.array_equal(got, full), (ty, w, "unpack()[i]")
+        assert np.array_equal(got, to_np(fl.BitPacking.unpack(w, dpk, n_blocks=n), ty)), (ty, w, "gpu unpack()[i]")
+        for i in (0, 1, 15, 16, 127, 128, 1023, 1024, 1500, 2047):       # closed form, spot indices of both blocks
+            b = i // 1024
+            assert int(got[i]) == oracle.unpack_single(ty, w, pk[b * pl:(b + 1) * pl], i % 1024), (ty, w, i)
+        assert sha(got) == GOLDEN["unpack_single"][f"{ty}_w{w}"], (ty, w, "golden")
+    # closed form for every index at a few widths (the per-index ctypes loop is the slow part)
+    for w in sorted({1, 3, T // 2 + 1, T - 1, T}):
+        pl = packed_len(ty, w)
+        pk = values(ty, pl, 3400 + w)
+        got = to_np(fl.BitPacking.unpack_single(w, to_dev(pk), didx[:1024], n_blocks=1), ty)
+        want = [oracle.unpack_single(ty, w, pk, i) for i in range(1024)]
         assert [int(x) for x in got] == want, (ty, w)
     # out-of-range index: the reference asserts (bitpacking.rs:152)
     with pytest.raises(fl.FastLanesError):
@@ -322,6 +338,120 @@ def test_mixed_width_plan_vs_oracle(fl, oracle, ty):
         fl.MixedWidthPlan(ty, np.array([T + 1], dtype=np.uint8))
 
 
+@pytest.mark.parametrize("ty", TYS)
+def test_unpack_pack_widths_device_resident(fl, oracle, ty):
+    """SURVEY 8(b) surface: widths[n_blocks] (u8) and offsets[n_blocks] (u64 byte offsets) live in HBM and are
+    read by the kernel; nothing is built on the host.  Against the oracle's per-block loop
+    (bitpacking.rs:76-96,109-129): every width 0..T, ragged block counts, over-wide pack inputs,
+    offsets with gaps / in a permuted order, and the device-side error flag for a width > T."""
+    import torch
+    T = tbits(ty)
+    esz = T // 8
+    tdt = {"u8": torch.uint8, "u16": torch.uint16, "u32": torch.uint32, "u64": torch.uint64}[ty]
+    rng = np.random.default_rng(4242 + T)
+    for n, widths in ((T + 1, np.arange(T + 1)), (1, np.array([T // 2])), (263, rng.integers(0, T + 1, size=263))):
+        widths = widths.astype(np.uint8)
+        dw = torch.from_numpy(widths).cuda()
+        doff, dtotal = fl.widths_to_offsets(ty, dw)
+        off = np.concatenate([[0], np.cumsum(widths.astype(np.int64) * 128)])
+        assert np.array_equal(doff.cpu().numpy(), off[:-1]) and int(dtotal.item()) == off[-1]
+        col = values(ty, int(off[-1]) // esz, 5100 + n)
+        dcol = to_dev(col)
+        got = to_np(fl.unpack_widths(dw, doff, dcol), ty)
+        want = np.concatenate([oracle.unpack(ty, int(w), col[off[b] // esz:off[b + 1] // esz]) for b, w in enumerate(widths)])
+        assert np.array_equal(got, want), (ty, n, "unpack_widths")
+        # pack: over-wide inputs must be truncated exactly like pack::<W> does (macros.rs:73; not for W == T, :58)
+        v = values(ty, n * 1024, 5200 + n)
+        dpk = torch.full((int(off[-1]) // esz,), 0, dtype=tdt, device="cuda:0")
+        fl.pack_widths(dw, doff, to_dev(v), dpk)
+        wantp = np.concatenate([oracle.pack(ty, int(w), v[b * 1024:(b + 1) * 1024]) for b, w in enumerate(widths)]
+                               + [np.zeros(0, dtype=TYPES[ty][0])])
+        assert np.array_equal(to_np(dpk, ty), wantp), (ty, n, "pack_widths")
+    # offsets are honoured as given: blocks in reverse order with a 256-byte gap after each
+    n = 40
+    widths = rng.integers(1, T + 1, size=n).astype(np.uint8)
+    sizes = widths.astype(np.int64) * 128 + 256
+    off = (np.cumsum(sizes[::-1])[::-1] - sizes).astype(np.int64)          # block 0 last
+    total = int(sizes.sum())
+    col = values(ty, total // esz, 5300)
+    dw, doff = torch.from_numpy(widths).cuda(), torch.from_numpy(off).cuda()
+    got = to_np(fl.unpack_widths(dw, doff, to_dev(col)), ty)
+    want = np.concatenate([oracle.unpack(ty, int(w), col[off[b] // esz:off[b] // esz + packed_len(ty, int(w))])
+                           for b, w in enumerate(widths)])
+    assert np.array_equal(got, want)
+    v = values(ty, n * 1024, 5301)
+    guard = torch.full((total // esz,), 0x5A if ty == "u8" else 0x5A5A, dtype=tdt, device="cuda:0")
+    before = to_np(guard, ty).copy()
+    fl.pack_widths(dw, doff, to_dev(v), guard)
+    after = to_np(guard, ty)
+    for b, w in enumerate(widths):
+        lo = off[b] // esz
+        k = packed_len(ty, int(w))
+        assert np.array_equal(after[lo:lo + k], oracle.pack(ty, int(w), v[b * 1024:(b + 1) * 1024])), b
+        assert np.array_equal(after[lo + k:lo + k + 256 // esz], before[lo + k:lo + k + 256 // esz]), "gap bytes were written"
+    # width > T: that block is skipped and the flag raised (bitpacking.rs:93,126 unreachable!())
+    bad = widths.copy()
+    bad[7] = T + 1
+    dbad = torch.from_numpy(bad).cuda()
+    with pytest.raises(fl.FastLanesError):
+        fl.unpack_widths(dbad, doff, to_dev(col))
+    with pytest.raises(fl.FastLanesError):
+        fl.widths_to_offsets(ty, dbad)
+    out = torch.zeros(n * 1024, dtype=tdt, device="cuda:0")
+    fl.unpack_widths(dbad, doff, to_dev(col), output=out, check=False)     # asynchronous form: no flag read-back
+    g = to_np(out, ty)
+    assert np.array_equal(g[:7 * 1024], want[:7 * 1024]) and np.array_equal(g[8 * 1024:], want[8 * 1024:])
+    assert not g[7 * 1024:8 * 1024].any()
+    # empty column
+    e8 = torch.empty(0, dtype=torch.uint8, device="cuda:0")
+    o0, t0 = fl.widths_to_offsets(ty, e8)
+    assert o0.numel() == 0 and int(t0.item()) == 0
+    assert fl.unpack_widths(e8, o0, torch.empty(0, dtype=tdt, device="cuda:0")).numel() == 0
+
+
+def test_widths_to_offsets_large(fl):
+    """The three-launch device scan across many 4096-block chunks, ragged tail, against numpy."""
+    import torch
+    for n in (4095, 4096, 4097, 3 * 4096 + 17, 1_000_003):
+        w = np.random.default_rng(n).integers(0, 33, size=n).astype(np.uint8)
+        off, total = fl.widths_to_offsets("u32", torch.from_numpy(w).cuda())
+        want = np.concatenate([[0], np.cumsum(w.astype(np.int64) * 128)])
+        assert np.array_equal(off.cpu().numpy(), want[:-1]), n
+        assert int(total.item()) == want[-1]
+
+
+def test_second_gpu_if_present(fl, oracle):
+    """Multi-GPU path on real devices: a rank's slice decoded on cuda:1 (device switch of the Python
+    mirror, a plan bound to device 1, device-resident widths on device 1).  Skipped on 1-GPU boxes."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    from fastlanes_amd.sharding import shard_mixed
+    dev = torch.device("cuda:1")
+    n = 1000
+    widths = (1 + np.arange(n) % 32).astype(np.uint8)
+    s, c, b0, nb = shard_mixed(widths, 2, 1)
+    off = np.concatenate([[0], np.cumsum(widths.astype(np.int64) * 128)])
+    col = values("u32", int(off[-1]) // 4, 77)
+    sl = torch.from_numpy(col[b0 // 4:(b0 + nb) // 4].view(np.uint8)).to(dev).view(torch.uint32)
+    want = np.concatenate([oracle.unpack("u32", int(w), col[off[b] // 4:off[b + 1] // 4]) for b, w in enumerate(widths)])[s * 1024:]
+    plan = fl.MixedWidthPlan("u32", widths[s:s + c], device=dev)
+    out = plan.unpack(sl)
+    assert out.device == dev
+    assert np.array_equal(out.view(torch.uint8).cpu().numpy().view(np.uint32), want)
+    dw = torch.from_numpy(widths[s:s + c]).to(dev)
+    doff, _ = fl.widths_to_offsets("u32", dw)
+    out2 = fl.unpack_widths(dw, doff, sl)
+    assert torch.equal(out2.view(torch.int32), out.view(torch.int32))
+    pk7 = values("u32", 50 * 224, 78)
+    got = fl.BitPacking.unpack(7, torch.from_numpy(pk7.view(np.uint8)).to(dev).view(torch.uint32))   # current device stays 0
+    assert got.device == dev and torch.cuda.current_device() == 0
+    assert np.array_equal(got.view(torch.uint8).cpu().numpy().view(np.uint32), oracle.batch("unpack", "u32", 7, pk7))
+    with pytest.raises(ValueError):                                       # tensors of two devices in one call
+        fl.BitPacking.unpack(7, to_dev(pk7), output=torch.empty(50 * 1024, dtype=torch.uint32, device=dev))
+    plan.close()
+
+
 def test_config5_u32_mixed_widths_10B_integers(fl, oracle):
     """u32, width[b] = 1 + b % 32, 9 765 625 blocks (10 B integers): the per-GPU slices of the
     8-way sharding are exercised on one GPU one after the other; pack(unpack(x)) == x and
@@ -503,9 +633,9 @@ def test_streams_and_graph_capture(fl, oracle):
     plan.close()
 
 
-def test_mixed_plan_sparse_bucket_uses_fallback_stores(fl, oracle):
-    """A bucket whose tile spans more than a 32-bit store window (two width-2 u64 blocks
-    600 000 blocks = 4.9 GB apart) must take the non-windowed store path and stay exact."""
+def test_mixed_plan_column_beyond_4GiB(fl, oracle):
+    """A 4.9 GB unpacked column (600 001 u64 blocks; two width-2 blocks at its ends among width-1 blocks):
+    64-bit block addressing -- nothing in the mixed path may assume a 32-bit window."""
     import torch
     n = 600_001
     widths = np.ones(n, dtype=np.uint8)
@@ -688,6 +818,50 @@ def test_concurrent_host_threads(fl, oracle):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_host_tier_threads_large_calls_and_release(fl, oracle):
+    """The host tier keeps a per-thread cached context (private stream, pinned + device buffers): concurrent
+    host threads get exact results, calls on either side of the zero-copy limit agree with the oracle, growing
+    and releasing the cache (fl_host_release) is safe, and a thread's context dies with the thread."""
+    import threading
+    lib = fl.load()
+    jobs = [("u32", 7, 1), ("u64", 17, 1), ("u16", 3, 1), ("u8", 5, 9), ("u32", 12, 300), ("u64", 33, 70)]
+    data = {j: values(j[0], j[2] * packed_len(j[0], j[1]), 170 + i) for i, j in enumerate(jobs)}
+    want = {j: oracle.batch("unpack", j[0], j[1], data[j]) for j in jobs}
+    errors = []
+
+    def worker(j):
+        try:
+            for it in range(40):
+                out = fl.BitPacking.unpack(j[1], data[j])
+                back = fl.BitPacking.pack(j[1], out)
+                if not np.array_equal(out, want[j]) or not np.array_equal(back, data[j]):
+                    errors.append((j, it))
+                    return
+                if it == 20:
+                    lib.fl_host_release()            # the next call rebuilds the context
+            i = (j[2] - 1) * 1024 + 513
+            pl = packed_len(j[0], j[1])
+            if fl.BitPacking.unpack_single(j[1], data[j], i) != oracle.unpack_single(j[0], j[1], data[j][(j[2] - 1) * pl:], 513):
+                errors.append((j, "unpack_single"))
+        except Exception as e:  # pragma: no cover
+            errors.append((j, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    # sizes straddling the zero-copy limit (256 KiB of in + out), then shrinking again
+    for n in (1, 55, 56, 57, 2000, 3):
+        pk = values("u32", n * 224, 190 + n)
+        assert np.array_equal(fl.BitPacking.unpack(7, pk), oracle.batch("unpack", "u32", 7, pk)), n
+        bases = values("u32", n * 32, 191 + n)
+        assert np.array_equal(fl.Delta.undelta_pack(7, pk, bases), oracle.batch("undelta_pack", "u32", 7, pk, aux=bases, n_blocks=n)), n
+    lib.fl_host_release()
+    lib.fl_host_release()                            # idempotent
 
 
 @pytest.mark.parametrize("ty", TYS)

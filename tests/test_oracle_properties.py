@@ -172,3 +172,18 @@ def test_fast_family_equals_literal(oracle, ty, op, w, nthreads):
 def test_fast_family_unspecialised_width_is_loud(oracle):
     with pytest.raises(ValueError):
         oracle.fast("unpack", "u32", 5, np.zeros(160, dtype=np.uint32))
+
+
+@pytest.mark.parametrize("nthreads", [1, 3])
+def test_fast_mixed_unpack_equals_literal(oracle, nthreads):
+    """The mixed-width CPU baseline (all 33 u32 widths specialised, bitpacking.rs:115-128) produces exactly what the
+    literal per-block oracle does; a width > 32 is refused (bitpacking.rs:126)."""
+    rng = np.random.default_rng(9)
+    widths = np.concatenate([np.arange(33), rng.integers(0, 33, size=40)]).astype(np.uint8)
+    off = np.concatenate([[0], np.cumsum(widths.astype(np.uint64) * 128)]).astype(np.uint64)
+    col = rng.integers(0, 2**32, size=int(off[-1]) // 4, dtype=np.uint64).astype(np.uint32)
+    got = oracle.fast_unpack_mixed_u32(widths, off[:-1], col, nthreads=nthreads)
+    want = np.concatenate([oracle.unpack("u32", int(w), col[int(off[b]) // 4:int(off[b + 1]) // 4]) for b, w in enumerate(widths)])
+    assert np.array_equal(got, want)
+    with pytest.raises(ValueError):
+        oracle.fast_unpack_mixed_u32(np.array([33], dtype=np.uint8), np.zeros(1, dtype=np.uint64), col)

@@ -1,0 +1,227 @@
+// abmixed.hip -- within-process interleaved A/B for mixed-width columns (BASELINE.json config 5):
+// the shipped host-planned bucket kernel (fl_u32_unpack_mixed) vs the device-resident
+// wave-per-block kernel of fl_widths.hpp in several launch shapes, next to a bare tuned stream of
+// the same read:write mix (the ceiling of the memory system for this traffic).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I fastlanes_amd/csrc -I include tools/abmixed.hip
+//        -L fastlanes_amd -lfastlanes_amd -Wl,-rpath,'$ORIGIN/../fastlanes_amd' -o tools/abmixed
+// Run on the GPU box: tools/abmixed [n_blocks] [rounds]
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <vector>
+#include "fastlanes_amd.h"
+#include "fl_widths.hpp"
+#include "fl_scan.hpp"
+
+using namespace fl;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+#define FLCK(x) do { int r_ = (x); if (r_ != 0) { printf("fl error %d at %s:%d\n", r_, __FILE__, __LINE__); exit(1); } } while (0)
+
+__global__ void k_fill(uint64_t* p, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t z = (i + 1) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        p[i] = z ^ (z >> 31);
+    }
+}
+
+__global__ void k_count_diff(const u32x4* a, const u32x4* b, uint64_t n_cells, unsigned long long* count)
+{
+    unsigned long long bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cells; i += (uint64_t)gridDim.x * blockDim.x) {
+        const u32x4 x = a[i], y = b[i];
+        bad += (x.x != y.x) | (x.y != y.y) | (x.z != y.z) | (x.w != y.w);
+    }
+    if (bad) atomicAdd(count, bad);
+}
+
+// bare stream of RD:WR cells per thread, XCD-contiguous tiles, sc1|nt stores, wave cap
+template <int RD, int WR, int MAXW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, MAXW)))
+void k_stream_tuned(const u32x4* in, u32x4* out, uint64_t n_tiles, uint64_t tiles_per_xcd, u32x4* sink)
+{
+    const uint64_t tile = (uint64_t)(blockIdx.x & 7u) * tiles_per_xcd + (blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
+    const unsigned tid = threadIdx.x;
+    u32x4 acc = {0, 0, 0, 0};
+    const u32x4* src = in + tile * (uint64_t)(256 * RD);
+#pragma unroll
+    for (int i = 0; i < RD; ++i) acc += src[i * 256 + tid];
+    auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(out + tile * (uint64_t)(256 * WR)), 0, 256 * WR * 16, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < WR; ++i) __builtin_amdgcn_raw_buffer_store_b128(acc + (unsigned)i, rs, (i * 256 + tid) * 16, 0, 18);
+    if (WR == 0 && acc.x == 0x12345678u) *sink = acc;
+}
+
+template <typename T, int BPW, int MAXW, bool PF>
+void launch_v(WidthsArgs a)
+{
+    constexpr int TILE = BPW * 4;
+    const uint64_t n_tiles = (a.n_blocks + TILE - 1) / TILE;
+    a.tiles_per_xcd = (n_tiles + 7) / 8;
+    hipLaunchKernelGGL((k_unpack_widths<T, BPW, MAXW, PF>), dim3((unsigned)(a.tiles_per_xcd * 8)), dim3(256), 0, 0, a);
+}
+template <typename T, int BPW, int MAXW>
+void launch_p(WidthsArgs a)
+{
+    constexpr int TILE = BPW * 4;
+    const uint64_t n_tiles = (a.n_blocks + TILE - 1) / TILE;
+    a.tiles_per_xcd = (n_tiles + 7) / 8;
+    hipLaunchKernelGGL((k_pack_widths<T, BPW, MAXW>), dim3((unsigned)(a.tiles_per_xcd * 8)), dim3(256), 0, 0, a);
+}
+
+struct Variant { std::string name; double bytes; std::function<void()> launch; std::vector<float> ms; };
+
+static uint64_t diff(const void* a, const void* b, uint64_t bytes, unsigned long long* d_count)
+{
+    CK(hipMemset(d_count, 0, 8));
+    hipLaunchKernelGGL(k_count_diff, dim3(8192), dim3(256), 0, 0, (const u32x4*)a, (const u32x4*)b, bytes / 16, d_count);
+    unsigned long long h = 0;
+    CK(hipMemcpy(&h, d_count, 8, hipMemcpyDeviceToHost));
+    return h;
+}
+
+int main(int argc, char** argv)
+{
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    const uint64_t n = argc > 1 ? strtoull(argv[1], 0, 10) : 9765625ull;
+    const int rounds = argc > 2 ? atoi(argv[2]) : 7;
+    const int pattern = argc > 3 ? atoi(argv[3]) : 0;   // 0: 1 + b%32   1: seeded random 1..32   2: uniform 7   3: random 0..32
+    std::vector<uint8_t> hw(n);
+    uint64_t rng = 42;
+    for (uint64_t b = 0; b < n; ++b) {
+        rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+        hw[b] = pattern == 0 ? (uint8_t)(1 + b % 32) : pattern == 1 ? (uint8_t)(1 + (rng >> 33) % 32) : pattern == 2 ? 7 : (uint8_t)((rng >> 33) % 33);
+    }
+    fl_mixed_plan* plan = nullptr;
+    FLCK(fl_mixed_plan_create(32, hw.data(), n, &plan));
+    const uint64_t pbytes = fl_mixed_plan_packed_bytes(plan);
+    printf("n_blocks %llu  pattern %d  packed %llu B  unpacked %llu B\n", (unsigned long long)n, pattern,
+           (unsigned long long)pbytes, (unsigned long long)(n * 4096));
+
+    char *packed, *out_ref, *out_new, *repacked;
+    uint8_t* d_w;
+    uint64_t *d_off, *d_total;
+    uint32_t* d_err;
+    unsigned long long* d_count;
+    u32x4* sink;
+    CK(hipMalloc(&packed, pbytes + (64 << 20)));
+    CK(hipMalloc(&repacked, pbytes + (64 << 20)));
+    CK(hipMalloc(&out_ref, n * 4096 + (64 << 20)));
+    CK(hipMalloc(&out_new, n * 4096 + (64 << 20)));
+    CK(hipMalloc(&d_w, n + 64));
+    CK(hipMalloc(&d_off, n * 8 + 64));
+    CK(hipMalloc(&d_total, 8));
+    CK(hipMalloc(&d_err, 4));
+    CK(hipMalloc(&d_count, 8));
+    CK(hipMalloc(&sink, 64));
+    CK(hipMemset(d_err, 0, 4));
+    CK(hipMemcpy(d_w, hw.data(), n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_fill, dim3(65536), dim3(256), 0, 0, (uint64_t*)packed, (pbytes + (64 << 20)) / 8);
+    hipLaunchKernelGGL(k_fill, dim3(65536), dim3(256), 0, 0, (uint64_t*)out_ref, (n * 4096) / 8);
+    hipLaunchKernelGGL(k_fill, dim3(65536), dim3(256), 0, 0, (uint64_t*)out_new, (n * 4096) / 8);
+    CK(hipDeviceSynchronize());
+
+    // device-side offsets vs the plan's host-built offsets
+    ScanArgs sa{d_w, d_off, d_total, d_err, n, 32};
+    CK(launch_widths_to_offsets(sa, 0));
+    CK(hipDeviceSynchronize());
+    uint64_t h_total = 0;
+    CK(hipMemcpy(&h_total, d_total, 8, hipMemcpyDeviceToHost));
+    {
+        std::vector<uint64_t> a(n), b(n);
+        CK(hipMemcpy(a.data(), d_off, n * 8, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(b.data(), fl_mixed_plan_offsets(plan), n * 8, hipMemcpyDeviceToHost));
+        printf("device scan: total %s, offsets %s\n", h_total == pbytes ? "ok" : "WRONG", a == b ? "identical to the host plan" : "DIFFERENT");
+    }
+
+    WidthsArgs wa{packed, out_new, d_w, d_off, d_err, n, 0, 0};
+    // correctness: plan kernel (shipped in round 1, parity-tested) vs every new shape
+    FLCK(fl_u32_unpack_mixed(plan, (const uint32_t*)packed, (uint32_t*)out_ref, nullptr));
+    CK(hipDeviceSynchronize());
+    auto check = [&](const char* name, std::function<void()> f) {
+        CK(hipMemset(out_new, 0xA5, n * 4096));
+        f();
+        CK(hipDeviceSynchronize());
+        CK(hipGetLastError());
+        printf("  %-44s output %s\n", name, diff(out_ref, out_new, n * 4096, d_count) == 0 ? "== plan kernel" : "MISMATCH");
+    };
+    check("wave-per-block bpw8 maxw3 pf", [&] { launch_v<uint32_t, 8, 3, true>(wa); });
+    check("wave-per-block bpw8 maxw3 nopf", [&] { launch_v<uint32_t, 8, 3, false>(wa); });
+    check("wave-per-block bpw4 maxw4 pf", [&] { launch_v<uint32_t, 4, 4, true>(wa); });
+    check("wave-per-block bpw16 maxw2 pf", [&] { launch_v<uint32_t, 16, 2, true>(wa); });
+    // pack round trip: pack_widths(unpack) must reproduce the packed column where the values fit
+    {
+        WidthsArgs pa{repacked, out_ref, d_w, d_off, d_err, n, 0, 0};
+        CK(hipMemset(repacked, 0x5A, pbytes));
+        launch_p<uint32_t, 8, 2>(pa);
+        CK(hipDeviceSynchronize());
+        CK(hipGetLastError());
+        printf("  %-44s packed  %s\n", "pack_widths(unpack_mixed(x))", diff(packed, repacked, pbytes & ~15ull, d_count) == 0 ? "== x" : "MISMATCH");
+        uint32_t herr = 0;
+        CK(hipMemcpy(&herr, d_err, 4, hipMemcpyDeviceToHost));
+        printf("  err_flag %u\n", herr);
+    }
+
+    std::vector<Variant> vs;
+    const double bytes = (double)pbytes + (double)n * 4096;
+    auto add = [&](const std::string& name, std::function<void()> f, double by) { vs.push_back({name, by, f, {}}); };
+    add("plan kernel (round 1, bucketed tiles)", [=] { fl_u32_unpack_mixed(plan, (const uint32_t*)packed, (uint32_t*)out_ref, nullptr); }, bytes);
+#define V(BPW, MW, PF) add(std::string("wave-per-block bpw" #BPW " maxw" #MW) + (PF ? " pf" : " nopf"), [=] { launch_v<uint32_t, BPW, MW, PF>(wa); }, bytes)
+    V(8, 3, true); V(8, 4, true); V(8, 5, true); V(8, 8, true);
+    V(4, 4, true); V(4, 6, true);
+    V(2, 4, true); V(2, 6, true); V(2, 8, true); V(2, 4, false); V(2, 8, false);
+    V(1, 3, false); V(1, 4, false); V(1, 5, false); V(1, 6, false); V(1, 8, false);
+    {
+        WidthsArgs pa{repacked, out_ref, d_w, d_off, d_err, n, 0, 0};
+#define P(BPW, MW) add("pack_widths bpw" #BPW " maxw" #MW, [=] { launch_p<uint32_t, BPW, MW>(pa); }, bytes)
+        P(8, 3); P(8, 4); P(8, 6); P(8, 8); P(4, 4); P(4, 8); P(2, 4); P(2, 8); P(1, 4); P(1, 6); P(1, 8);
+        add("plan pack kernel (round 1)", [=] { fl_u32_pack_mixed(plan, (const uint32_t*)out_ref, (uint32_t*)repacked, nullptr); }, bytes);
+    }
+    add("widths->offsets device scan (3 launches)", [=] { launch_widths_to_offsets(sa, 0); }, (double)n * (1 + 8 + 16));
+    {
+        // bare stream of the same byte mix: 33 cells read : 64 cells written per thread (16.5 : 32)
+        const uint64_t n_tiles = n / 64;    // a tile = 256 threads x (33+64) cells = 64 blocks' worth at the average width
+        const uint64_t tpx = (n_tiles + 7) / 8;
+        const double by = (double)n_tiles * 256 * 97 * 16;
+        add("bare stream 33rd:64wr maxw2", [=] { hipLaunchKernelGGL((k_stream_tuned<33, 64, 2>), dim3((unsigned)(tpx * 8)), dim3(256), 0, 0, (const u32x4*)out_ref, (u32x4*)out_new, n_tiles, tpx, sink); }, by);
+        add("bare stream 33rd:64wr maxw3", [=] { hipLaunchKernelGGL((k_stream_tuned<33, 64, 3>), dim3((unsigned)(tpx * 8)), dim3(256), 0, 0, (const u32x4*)out_ref, (u32x4*)out_new, n_tiles, tpx, sink); }, by);
+        const uint64_t n_tiles2 = n / 32;
+        const uint64_t tpx2 = (n_tiles2 + 7) / 8;
+        const double by2 = (double)n_tiles2 * 256 * 49 * 16;   // 16.5:32 ~ 17:32
+        add("bare stream 17rd:32wr maxw3", [=] { hipLaunchKernelGGL((k_stream_tuned<17, 32, 3>), dim3((unsigned)(tpx2 * 8)), dim3(256), 0, 0, (const u32x4*)out_ref, (u32x4*)out_new, n_tiles2, tpx2, sink); }, by2);
+    }
+    if (pattern == 2) {
+        add("uniform k_unpack<u32,7> (shipped)", [=] { fl_u32_unpack(7, (const uint32_t*)packed, (uint32_t*)out_ref, n, nullptr); }, bytes);
+        add("uniform k_pack<u32,7> (shipped)", [=] { fl_u32_pack(7, (const uint32_t*)out_ref, (uint32_t*)repacked, n, nullptr); }, bytes);
+    }
+
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (auto& v : vs) v.launch();
+    CK(hipDeviceSynchronize());
+    CK(hipGetLastError());
+    for (int r = 0; r < rounds; ++r)
+        for (auto& v : vs) {
+            CK(hipEventRecord(e0, 0));
+            v.launch();
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            v.ms.push_back(ms);
+        }
+    CK(hipGetLastError());
+    printf("%-46s %9s %9s %9s %9s\n", "variant", "med_ms", "min_ms", "GB/s_med", "GB/s_max");
+    for (auto& v : vs) {
+        std::sort(v.ms.begin(), v.ms.end());
+        float med = v.ms[v.ms.size() / 2], mn = v.ms[0];
+        printf("%-46s %9.4f %9.4f %9.1f %9.1f\n", v.name.c_str(), med, mn, v.bytes / med / 1e6, v.bytes / mn / 1e6);
+    }
+    fl_mixed_plan_destroy(plan);
+    return 0;
+}
