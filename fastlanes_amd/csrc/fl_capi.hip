@@ -7,8 +7,10 @@
 #include "fl_misc.hpp"
 #include "fl_widths.hpp"
 #include "fl_scan.hpp"
+#include "fl_dispatch.hpp"
 #include "fl_consume.hpp"
 
+#include <atomic>
 #include <cstring>
 #include <new>
 
@@ -17,6 +19,18 @@ namespace {
 using namespace fl;
 
 thread_local int g_last_hip_error = 0;
+
+// fl_set_kernel_policy: 0 = measured choice (fl_dispatch.hpp), 1 = cell-column kernels only, 2 = wave-per-block
+// kernels wherever they exist.  Results are bit-identical; only speed differs.
+std::atomic<int> g_kernel_policy{0};
+
+inline int chosen_waves(unsigned type_bits, unsigned w, fl::WaveOp op)
+{
+    const int p = g_kernel_policy.load(std::memory_order_relaxed);
+    if (p == 1) return 0;
+    const int waves = fl::wave_policy(type_bits, w, op);
+    return (p == 2 && waves == 0) ? (op == fl::WAVE_PACK ? fl::WIDTHS_MIXED_PACK_WAVES : fl::WIDTHS_MIXED_UNPACK_WAVES) : waves;
+}
 
 inline int hip_fail(hipError_t e)
 {
@@ -44,26 +58,63 @@ int run_stream(stream_launch_t fn, const T* in, T* out, const void* aux, size_t 
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
 
+// Uniform-width call served by the wave-per-block kernels (fl_dispatch.hpp decides; 0 waves = cell-column kernel).
+template <typename T>
+int run_wave_uniform(bool pack, int waves, unsigned w, const T* packed, T* unpacked, const T* refs, size_t ref_stride,
+                     size_t n_blocks, void* stream)
+{
+    if (n_blocks == 0 || (pack && w == 0)) return FL_OK;
+    if (!unpacked || (w != 0 && !packed)) return FL_ERR_NULL;
+    if (misaligned(packed) || misaligned(unpacked)) return FL_ERR_ALIGN;
+    WidthsArgs a;
+    a.packed = reinterpret_cast<const char*>(packed);
+    a.unpacked = reinterpret_cast<char*>(unpacked);
+    a.widths = nullptr;
+    a.offsets = nullptr;
+    a.err_flag = nullptr;
+    a.refs = refs;
+    a.ref_stride = ref_stride;
+    a.n_blocks = n_blocks;
+    a.tiles_per_xcd = 0;
+    a.uniform_width = w;
+    hipError_t e = widths_launcher<T>(pack)(a, waves, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? FL_OK : hip_fail(e);
+}
+
 template <typename T> int dev_pack(unsigned w, const T* in, T* out, size_t n, void* s)
 {
     if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
+    if (const int waves = chosen_waves(Elem<T>::BITS, w, WAVE_PACK)) {
+        if (n && !in) return FL_ERR_NULL;
+        return run_wave_uniform<T>(true, waves, w, out, const_cast<T*>(in), nullptr, 0, n, s);
+    }
     return run_stream<T>(pack_table_impl<T, PACK_PLAIN>().fn[w], in, out, nullptr, 0, n, true, w != 0, false, s);
 }
 template <typename T> int dev_unpack(unsigned w, const T* in, T* out, size_t n, void* s)
 {
     if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
+    if (const int waves = chosen_waves(Elem<T>::BITS, w, WAVE_UNPACK))
+        return run_wave_uniform<T>(false, waves, w, in, out, nullptr, 0, n, s);
     return run_stream<T>(unpack_table_impl<T, BODY_STORE>().fn[w], in, out, nullptr, 0, n, w != 0, true, false, s);
 }
 template <typename T>
 int dev_for_pack(unsigned w, const T* in, const T* refs, size_t stride, T* out, size_t n, void* s)
 {
     if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
+    if (const int waves = chosen_waves(Elem<T>::BITS, w, WAVE_PACK)) {
+        if (n && (!in || !refs)) return FL_ERR_NULL;
+        return run_wave_uniform<T>(true, waves, w, out, const_cast<T*>(in), refs, stride, n, s);
+    }
     return run_stream<T>(pack_table_impl<T, PACK_FOR>().fn[w], in, out, refs, stride, n, true, w != 0, true, s);
 }
 template <typename T>
 int dev_unfor_pack(unsigned w, const T* in, const T* refs, size_t stride, T* out, size_t n, void* s)
 {
     if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
+    if (const int waves = chosen_waves(Elem<T>::BITS, w, WAVE_UNPACK)) {
+        if (n && !refs) return FL_ERR_NULL;
+        return run_wave_uniform<T>(false, waves, w, in, out, refs, stride, n, s);
+    }
     return run_stream<T>(unpack_table_impl<T, BODY_ADD_REF>().fn[w], in, out, refs, stride, n, w != 0, true, true, s);
 }
 template <typename T>
@@ -323,10 +374,12 @@ int run_widths(bool pack, const uint8_t* widths, const uint64_t* offsets, const 
     a.widths = widths;
     a.offsets = offsets;
     a.err_flag = err_flag;
+    a.refs = nullptr;
+    a.ref_stride = 0;
     a.n_blocks = n_blocks;
     a.tiles_per_xcd = 0;
     a.uniform_width = 0;
-    hipError_t e = widths_launcher<T>(pack)(a, static_cast<hipStream_t>(stream));
+    hipError_t e = widths_launcher<T>(pack)(a, pack ? WIDTHS_MIXED_PACK_WAVES : WIDTHS_MIXED_UNPACK_WAVES, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
 
@@ -402,6 +455,8 @@ const uint64_t* fl_mixed_plan_offsets(const fl_mixed_plan* p) { return p ? p->d_
 const uint8_t* fl_mixed_plan_widths(const fl_mixed_plan* p) { return p ? p->d_widths : nullptr; }
 
 void fl_host_release(void) { g_host.release(); }
+void fl_set_kernel_policy(int policy) { g_kernel_policy.store(policy < 0 || policy > 2 ? 0 : policy, std::memory_order_relaxed); }
+int fl_get_kernel_policy(void) { return g_kernel_policy.load(std::memory_order_relaxed); }
 
 const char* fl_version(void) { return "fastlanes_amd 0.2.0 (gfx950; wire format of spiraldb/fastlanes 0.1.8)"; }
 

@@ -4,8 +4,8 @@
 // `widths[n_blocks]` (u8) and `offsets[n_blocks]` (u64 byte offsets) read ON THE DEVICE -- the
 // surface SURVEY.md 8(b) names.  No host plan, no sort, no 32-bit window, any block count.
 //
-// Mapping: ONE WAVEFRONT PER 1024-VALUE BLOCK, blocks in natural column order (a wavefront walks
-// BPW consecutive blocks, a workgroup 4*BPW).  The width is wave-uniform (an SGPR), so the width
+// Mapping: ONE WAVEFRONT PER 1024-VALUE BLOCK, blocks in natural column order (a workgroup takes 4
+// consecutive blocks).  The width is wave-uniform (an SGPR), so the width
 // dispatch of bitpacking.rs:115-128 is plain scalar arithmetic -- one kernel per element type, no
 // per-width code:
 //   * the packed block (128*W bytes, W rows of 8 cells) is fetched with 1-KiB-contiguous 16-byte
@@ -17,6 +17,10 @@
 //     the shift in a register instead of a constant);
 //   * every global store instruction is 1 KiB contiguous (`sc1 nt`), every load 1 KiB contiguous.
 // LDS is wave-local (in-order per wave): no s_barrier.
+//
+// The same two kernels serve UNIFORM-width columns (widths == nullptr: every block has `uniform_width`, offsets are
+// b*128*W) and the FoR bodies (refs != nullptr): for most (T, W) of the 16/32/64-bit types they out-run the
+// per-(T,W) cell-column kernels of fl_kernels.hpp (profiles/abuniform_r02*.txt); fl_dispatch.hpp holds the choice.
 #pragma once
 #include "fl_kernels.hpp"
 
@@ -28,6 +32,8 @@ struct WidthsArgs {
     const uint8_t* widths;     // [n_blocks]; nullptr = every block has `uniform_width`
     const uint64_t* offsets;   // [n_blocks] byte offsets into `packed`; nullptr = b * 128 * uniform_width
     uint32_t* err_flag;        // set to 1 if some widths[b] > T (that block is skipped); may be nullptr
+    const void* refs;          // FoR: references[b * ref_stride] (ffor.rs:24-50); nullptr = plain BitPacking
+    uint64_t ref_stride;
     uint64_t n_blocks;
     uint64_t tiles_per_xcd;
     unsigned uniform_width;
@@ -95,206 +101,219 @@ template <typename T> struct WaveBlock {
     }
 };
 
-// Per-wavefront metadata of its BPW blocks: lane j holds widths[first+j] / offsets[first+j]; the loop
-// broadcasts them with v_readlane (wave-uniform SGPR values).
-template <int BPW>
-struct WaveMeta {
-    unsigned w;
-    uint64_t off;
-    __device__ __forceinline__ WaveMeta(const WidthsArgs& a, uint64_t first_blk, unsigned nb, unsigned lane)
-    {
-        static_assert(BPW <= 64, "one lane per block of the wavefront");
-        w = a.uniform_width;
-        off = (first_blk + lane) * (uint64_t)(128u * a.uniform_width);
-        if (lane < nb) {
-            if (a.widths) w = a.widths[first_blk + lane];
-            if (a.offsets) off = a.offsets[first_blk + lane];
-        }
-    }
-    __device__ __forceinline__ unsigned width(unsigned j) const { return __builtin_amdgcn_readlane(w, j); }
-    __device__ __forceinline__ uint64_t offset(unsigned j) const
-    {
-        const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)off, j), hi = __builtin_amdgcn_readlane((uint32_t)(off >> 32), j);
-        return ((uint64_t)hi << 32) | lo;
-    }
-};
+// A lane-uniform value the compiler cannot prove uniform: loads indexed with it go through the vector memory path
+// (returned in order behind the loads issued before them) instead of a scalar load, whose `s_waitcnt lgkmcnt(0)`
+// would serialise it in FRONT of the data loads (measured: unfor_pack with per-block references -6 %).
+__device__ __forceinline__ unsigned opaque_zero()
+{
+    unsigned z = 0;
+    asm volatile("" : "+v"(z));
+    return z;
+}
 
-// unchecked_unpack over per-block widths (bitpacking.rs:109-129).
-template <typename T, int BPW, int MAXWAVES, bool PREFETCH>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, MAXWAVES)))
-void k_unpack_widths(WidthsArgs a)
+// widths[blk] and offsets[blk] of the wavefront's block: two independent vector loads in flight together, one
+// wait, then broadcast to SGPRs (wave-uniform) -- instead of a byte load, a wait, a dependent scalar load, a wait.
+__device__ __forceinline__ uint64_t wave_uniform_u64(uint64_t v)
+{
+    // readfirstlane returns int: widen through uint32_t or a low word with bit 31 set sign-extends into the high one
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ void block_meta(const WidthsArgs& a, uint64_t blk, unsigned& w, uint64_t& off)
+{
+    w = a.uniform_width;
+    off = blk * (uint64_t)(128u * a.uniform_width);
+    if (a.widths) {
+        const unsigned z = opaque_zero();
+        const unsigned wv = a.widths[blk + z];
+        uint64_t ov = 0;
+        if (a.offsets) ov = a.offsets[blk + z];
+        w = (unsigned)__builtin_amdgcn_readfirstlane(wv);
+        if (a.offsets)
+            off = wave_uniform_u64(ov);
+        else
+            off = blk * (uint64_t)(128u * w);     // offsets == nullptr with widths: only meaningful for equal widths
+    } else if (a.offsets) {
+        off = wave_uniform_u64(a.offsets[blk + opaque_zero()]);
+    }
+}
+
+// FoR reference of the block, through the vector path (see opaque_zero); issue it AFTER the block's data loads.
+template <typename T> __device__ __forceinline__ Cell<T> block_ref(const WidthsArgs& a, uint64_t blk)
+{
+    return Cell<T>::splat(static_cast<const T*>(a.refs)[blk * a.ref_stride + opaque_zero()]);
+}
+
+// unchecked_unpack over per-block widths (bitpacking.rs:109-129); with a.refs also FoR::unfor_pack's body
+// `out[idx] = elem + reference` (ffor.rs:46-48).  One block per wavefront, 4 per workgroup; the wave's LDS image
+// is BLOCK_BYTES of the DYNAMIC shared memory -- the launcher pads the request to steer occupancy (fewer,
+// or more, concurrent DRAM streams) without compiling per-occupancy variants.
+template <typename T>
+__global__ __launch_bounds__(WG) void k_unpack_widths(WidthsArgs a)
 {
     using G = WaveBlock<T>;
     constexpr int TB = G::TB;
-    constexpr int TILE = BPW * (WG / 64);
-    __shared__ __attribute__((aligned(16))) char lds_all[(WG / 64) * G::BLOCK_BYTES];
-    const uint64_t n_tiles = (a.n_blocks + TILE - 1) / TILE;
+    extern __shared__ __attribute__((aligned(16))) char lds_all[];
+    const uint64_t n_tiles = (a.n_blocks + (WG / 64) - 1) / (WG / 64);
     const uint64_t tile = (uint64_t)(blockIdx.x & 7u) * a.tiles_per_xcd + (blockIdx.x >> 3);
     if (tile >= n_tiles) return;
     const unsigned tid = threadIdx.x;
     const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
-    const uint64_t first_blk = tile * TILE + (uint64_t)wave * BPW;
-    if (first_blk >= a.n_blocks) return;
-    const uint64_t left = a.n_blocks - first_blk;
-    const unsigned nb = left < (uint64_t)BPW ? (unsigned)left : (unsigned)BPW;
+    const uint64_t blk = tile * (WG / 64) + wave;
+    if (blk >= a.n_blocks) return;
     char* lds = lds_all + wave * G::BLOCK_BYTES;
-    const WaveMeta<BPW> meta(a, first_blk, nb, lane);
-
-    const unsigned c16 = (lane & 7u) * 16u;
-    const unsigned rbase = G::row_base(lane >> 3);
-    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(
-        a.unpacked + first_blk * G::BLOCK_BYTES, 0, nb * G::BLOCK_BYTES, 0x00020000);
-
-    u32x4 pk[G::GROUPS];
-    auto fetch = [&](unsigned j) {
-        const unsigned w = meta.width(j);
-        if (w > (unsigned)TB) return;
-        // wave-uniform descriptor over exactly this block's 128*w bytes: cells past it read as 0, no fault
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char*>(a.packed) + meta.offset(j), 0, 128u * w, 0x00020000);
-        static_for<G::GROUPS>([&](auto Gi) {
-            constexpr int g = decltype(Gi)::value;
-            if (8u * g < w) pk[g] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16u + g * 1024u, 0, 0);
-        });
-    };
-    if constexpr (PREFETCH) fetch(0);
-    for (unsigned j = 0; j < nb; ++j) {
-        const unsigned w = meta.width(j);
-        if constexpr (!PREFETCH) fetch(j);
-        if (w > (unsigned)TB) {                               // bitpacking.rs:126 unreachable!()
-            if (a.err_flag && lane == 0) *a.err_flag = 1u;
-            if constexpr (PREFETCH) { if (j + 1 < nb) fetch(j + 1); }
-            continue;
-        }
-        const unsigned out_base = j * G::BLOCK_BYTES + lane * 16u;
-        if (w == 0) {                                         // macros.rs:118-125: 1024 zeros
-            if constexpr (PREFETCH) { if (j + 1 < nb) fetch(j + 1); }
-            const u32x4 z = {0, 0, 0, 0};
-            static_for<G::GROUPS>([&](auto K) {
-                __builtin_amdgcn_raw_buffer_store_b128(z, out_rs, out_base + decltype(K)::value * 1024u, 0, STORE_AUX);
-            });
-            continue;
-        }
-        static_for<G::GROUPS>([&](auto Gi) {
-            constexpr int g = decltype(Gi)::value;
-            if (8u * g < w) *reinterpret_cast<u32x4*>(lds + lane * 16u + g * 1024u) = pk[g];
-        });
-        wave_lds_fence();
-        if constexpr (PREFETCH) { if (j + 1 < nb) fetch(j + 1); }
-        const typename G::word_t m = G::field_mask(w);
-        unsigned bit = rbase * w;
-        const unsigned step = G::KSTEP * w;
-        const unsigned last = (w - 1u) * 128u;
-        static_for<G::GROUPS>([&](auto K) {
-            const unsigned word = bit >> G::LOG_TB, sh = bit & (TB - 1u);
-            const unsigned a0 = word * 128u;
-            const unsigned a1 = a0 + 128u < last ? a0 + 128u : last;        // the last row never reads past the end (macros.rs:156)
-            const Cell<T> cur = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(lds + a0 + c16));
-            const Cell<T> nxt = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(lds + a1 + c16));
-            const Cell<T> v = G::funnel(cur, nxt, sh, m);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rs, out_base + decltype(K)::value * 1024u, 0, STORE_AUX);
-            bit += step;
-        });
-        wave_lds_fence();
+    unsigned w;
+    uint64_t off;
+    block_meta(a, blk, w, off);                               // wave-uniform
+    if (w > (unsigned)TB) {                                   // bitpacking.rs:126 unreachable!()
+        if (a.err_flag && lane == 0) *a.err_flag = 1u;
+        return;
     }
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(
+        a.unpacked + blk * G::BLOCK_BYTES, 0, G::BLOCK_BYTES, 0x00020000);
+    const unsigned out_base = lane * 16u;
+    if (w == 0) {                                             // macros.rs:118-125: every position gets 0 (+ reference)
+        const Cell<T> ref = a.refs ? block_ref<T>(a, blk) : Cell<T>::zero();
+        static_for<G::GROUPS>([&](auto K) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ref), out_rs, out_base + decltype(K)::value * 1024u, 0, STORE_AUX);
+        });
+        return;
+    }
+    // wave-uniform descriptor over exactly this block's 128*w bytes: cells past it read as 0, no fault
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.packed) + off, 0, 128u * w, 0x00020000);
+    u32x4 pk[G::GROUPS];
+    static_for<G::GROUPS>([&](auto Gi) {
+        constexpr int g = decltype(Gi)::value;
+        if (8u * g < w) pk[g] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16u + g * 1024u, 0, 0);
+    });
+    const Cell<T> ref = a.refs ? block_ref<T>(a, blk) : Cell<T>::zero();   // behind the data loads
+    static_for<G::GROUPS>([&](auto Gi) {
+        constexpr int g = decltype(Gi)::value;
+        if (8u * g < w) *reinterpret_cast<u32x4*>(lds + lane * 16u + g * 1024u) = pk[g];
+    });
+    wave_lds_fence();
+    const unsigned c16 = (lane & 7u) * 16u;
+    const typename G::word_t m = G::field_mask(w);
+    unsigned bit = G::row_base(lane >> 3) * w;
+    const unsigned step = G::KSTEP * w;
+    const unsigned last = (w - 1u) * 128u;
+    static_for<G::GROUPS>([&](auto K) {
+        const unsigned word = bit >> G::LOG_TB, sh = bit & (TB - 1u);
+        const unsigned a0 = word * 128u;
+        const unsigned a1 = a0 + 128u < last ? a0 + 128u : last;            // the last row never reads past the end (macros.rs:156)
+        const Cell<T> cur = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(lds + a0 + c16));
+        const Cell<T> nxt = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(lds + a1 + c16));
+        Cell<T> v = G::funnel(cur, nxt, sh, m);
+        if (a.refs) v = v.add(ref);                                         // ffor.rs:46-48
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rs, out_base + decltype(K)::value * 1024u, 0, STORE_AUX);
+        bit += step;
+    });
 }
 
-// unchecked_pack over per-block widths (bitpacking.rs:76-96).  The unpacked block is parked in the
-// wave's LDS image; lane (i, c) then assembles packed cells (w = i + 8m, c): word w of an FL lane's
-// stream holds bits [w*T, (w+1)*T), i.e. the fields of rows floor(w*T/W) .. floor(((w+1)*T-1)/W)
-// (macros.rs:72-92 regrouped by destination word instead of by source row).
-template <typename T, int BPW, int MAXWAVES>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, MAXWAVES)))
-void k_pack_widths(WidthsArgs a)
+// unchecked_pack over per-block widths (bitpacking.rs:76-96); with a.refs also FoR::for_pack's body
+// `input[idx] - reference` (ffor.rs:32-34).  The unpacked block is parked in the wave's LDS image; lane (i, c)
+// then assembles packed cells (w = i + 8m, c): word w of an FL lane's stream holds bits [w*T, (w+1)*T), i.e. the
+// fields of rows floor(w*T/W) .. floor(((w+1)*T-1)/W) (macros.rs:72-92 regrouped by destination word instead of by
+// source row).
+template <typename T>
+__global__ __launch_bounds__(WG) void k_pack_widths(WidthsArgs a)
 {
     using G = WaveBlock<T>;
     using word_t = typename G::word_t;
     constexpr int TB = G::TB;
-    constexpr int TILE = BPW * (WG / 64);
-    __shared__ __attribute__((aligned(16))) char lds_all[(WG / 64) * G::BLOCK_BYTES];
-    const uint64_t n_tiles = (a.n_blocks + TILE - 1) / TILE;
+    extern __shared__ __attribute__((aligned(16))) char lds_all[];
+    const uint64_t n_tiles = (a.n_blocks + (WG / 64) - 1) / (WG / 64);
     const uint64_t tile = (uint64_t)(blockIdx.x & 7u) * a.tiles_per_xcd + (blockIdx.x >> 3);
     if (tile >= n_tiles) return;
     const unsigned tid = threadIdx.x;
     const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
-    const uint64_t first_blk = tile * TILE + (uint64_t)wave * BPW;
-    if (first_blk >= a.n_blocks) return;
-    const uint64_t left = a.n_blocks - first_blk;
-    const unsigned nb = left < (uint64_t)BPW ? (unsigned)left : (unsigned)BPW;
+    const uint64_t blk = tile * (WG / 64) + wave;
+    if (blk >= a.n_blocks) return;
     char* lds = lds_all + wave * G::BLOCK_BYTES;
-    const WaveMeta<BPW> meta(a, first_blk, nb, lane);
+    unsigned w;
+    uint64_t off;
+    block_meta(a, blk, w, off);                               // wave-uniform
+    if (w > (unsigned)TB) {                                   // bitpacking.rs:93 unreachable!()
+        if (a.err_flag && lane == 0) *a.err_flag = 1u;
+        return;
+    }
+    if (w == 0) return;                                       // macros.rs:52-53: W == 0 writes nothing
     const unsigned c16 = (lane & 7u) * 16u, i = lane >> 3;
     const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(
-        a.unpacked + first_blk * G::BLOCK_BYTES, 0, nb * G::BLOCK_BYTES, 0x00020000);
-
+        a.unpacked + blk * G::BLOCK_BYTES, 0, G::BLOCK_BYTES, 0x00020000);
     u32x4 un[G::GROUPS];
-    auto fetch = [&](unsigned j) {
-        static_for<G::GROUPS>([&](auto K) {
-            un[decltype(K)::value] = __builtin_amdgcn_raw_buffer_load_b128(in_rs, j * G::BLOCK_BYTES + decltype(K)::value * 1024u + lane * 16u, 0, 2 /* nt */);
-        });
-    };
-    fetch(0);
-    for (unsigned j = 0; j < nb; ++j) {
-        const unsigned w = meta.width(j);
-        static_for<G::GROUPS>([&](auto K) { *reinterpret_cast<u32x4*>(lds + lane * 16u + decltype(K)::value * 1024u) = un[decltype(K)::value]; });
-        wave_lds_fence();
-        if (j + 1 < nb) fetch(j + 1);
-        if (w > (unsigned)TB) {                               // bitpacking.rs:93 unreachable!()
-            if (a.err_flag && lane == 0) *a.err_flag = 1u;
-        } else if (w != 0) {                                  // macros.rs:52-53: W == 0 writes nothing
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<char*>(a.packed) + meta.offset(j), 0, 128u * w, 0x00020000);
-            for (unsigned m8 = 0; m8 < w; m8 += 8) {          // wave-uniform trip count: ceil(w/8) groups of 8 packed rows
-                const unsigned wd = m8 + i;                   // this lane's packed word-row
-                const unsigned lo_bit = wd * TB;
-                unsigned r = lo_bit / w;                      // first row with bits in this word
-                const unsigned r_end = wd < w ? (lo_bit + TB - 1u) / w : r;   // last such row (inclusive); idle lanes: empty
-                Cell<T> acc = Cell<T>::zero();
-                if (wd < w) {
-                    for (; r <= r_end; ++r) {
-                        const Cell<T> s = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(lds + G::row_cell_rt(r) * 16u + c16));
-                        const unsigned fb = r * w;            // first stream bit of row r's field
-                        if (fb >= lo_bit) {                   // field starts in this word: (src & mask(keep)) << shift  (macros.rs:73,79)
-                            const unsigned sh = fb - lo_bit;
-                            const unsigned keep = w < TB - sh ? w : TB - sh;
-                            const word_t mk = G::rep_mask(keep);
-                            for (int x = 0; x < Cell<T>::NW; ++x) acc.x[x] |= (s.x[x] & mk) << sh;
-                        } else {                              // carry of a straddling field: (src & mask(W)) >> (W - rem)  (macros.rs:92)
-                            const unsigned sh = lo_bit - fb;
-                            const word_t mk = G::rep_mask(w - sh);
-                            for (int x = 0; x < Cell<T>::NW; ++x) acc.x[x] |= (s.x[x] >> sh) & mk;
-                        }
-                    }
+    static_for<G::GROUPS>([&](auto K) {
+        un[decltype(K)::value] = __builtin_amdgcn_raw_buffer_load_b128(in_rs, decltype(K)::value * 1024u + lane * 16u, 0, 2 /* nt */);
+    });
+    const Cell<T> ref = a.refs ? block_ref<T>(a, blk) : Cell<T>::zero();   // behind the data loads
+    static_for<G::GROUPS>([&](auto K) {
+        Cell<T> v = __builtin_bit_cast(Cell<T>, un[decltype(K)::value]);
+        if (a.refs) v = v.sub(ref);                                         // ffor.rs:32-34 (before the mask of macros.rs:73)
+        *reinterpret_cast<u32x4*>(lds + lane * 16u + decltype(K)::value * 1024u) = __builtin_bit_cast(u32x4, v);
+    });
+    wave_lds_fence();
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.packed) + off, 0, 128u * w, 0x00020000);
+    for (unsigned m8 = 0; m8 < w; m8 += 8) {                  // wave-uniform trip count: ceil(w/8) groups of 8 packed rows
+        const unsigned wd = m8 + i;                           // this lane's packed word-row
+        Cell<T> acc = Cell<T>::zero();
+        if (wd < w) {
+            const unsigned lo_bit = wd * TB;
+            unsigned r = lo_bit / w;                          // first row with bits in this word
+            const unsigned r_end = (lo_bit + TB - 1u) / w;    // last such row (inclusive)
+            for (; r <= r_end; ++r) {
+                const Cell<T> s = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(lds + G::row_cell_rt(r) * 16u + c16));
+                const unsigned fb = r * w;                    // first stream bit of row r's field
+                if (fb >= lo_bit) {                           // field starts in this word: (src & mask(keep)) << shift  (macros.rs:73,79)
+                    const unsigned sh = fb - lo_bit;
+                    const unsigned keep = w < TB - sh ? w : TB - sh;
+                    const word_t mk = G::rep_mask(keep);
+                    for (int x = 0; x < Cell<T>::NW; ++x) acc.x[x] |= (s.x[x] & mk) << sh;
+                } else {                                      // carry of a straddling field: (src & mask(W)) >> (W - rem)  (macros.rs:92)
+                    const unsigned sh = lo_bit - fb;
+                    const word_t mk = G::rep_mask(w - sh);
+                    for (int x = 0; x < Cell<T>::NW; ++x) acc.x[x] |= (s.x[x] >> sh) & mk;
                 }
-                // rows past the block's 128*w bytes fall outside the descriptor and are dropped
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rs, wd * 128u + c16, 0, STORE_AUX);
             }
         }
-        wave_lds_fence();
+        // rows past the block's 128*w bytes fall outside the descriptor and are dropped
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rs, wd * 128u + c16, 0, STORE_AUX);
     }
 }
 
-typedef hipError_t (*widths_launch_t)(const WidthsArgs&, hipStream_t);
+typedef hipError_t (*widths_launch_t)(const WidthsArgs&, int waves, hipStream_t);
 
-// Shipped shape (profiles/abmixed_r02a.txt, abmixed_r02b.txt; u32, 9 765 625 blocks, widths 1 + b mod 32 and
-// seeded-random): one block per wavefront, <= 6 waves/SIMD.  More blocks per wavefront with a register
-// prefetch of the next block (BPW 2..16) measured 1-5 % slower; the round-1 bucketed plan kernel 5-10 % slower;
-// a bare 33:64 read:write stream of the same bytes reaches 6.23-6.53 TB/s where this kernel reaches 6.37-6.66.
-constexpr int WIDTHS_BPW = 1;
-constexpr int WIDTHS_MAXWAVES = 6;
+// Occupancy is steered at launch: the kernels use BLOCK_BYTES of dynamic LDS per wavefront, and the launcher
+// pads the request so that exactly `waves` wavefronts per SIMD (= workgroups per CU) fit the CU's 160 KiB.
+// Mixed-width columns (profiles/abmixed_r02a.txt, abmixed_r02b.txt; u32, 9 765 625 blocks, widths 1 + b mod 32 and
+// seeded-random): one block per wavefront at 5-6 waves/SIMD; more blocks per wavefront with a register prefetch of
+// the next block measured 1-5 % slower, the round-1 bucketed plan kernel 5-10 % slower; a bare 33:64 read:write
+// stream of the same bytes reaches 6.23-6.53 TB/s where this kernel reaches 6.37-6.66.
+constexpr unsigned CU_LDS_BYTES = 160 * 1024;
+constexpr int WIDTHS_MIXED_UNPACK_WAVES = 6;   // 4-8 within 3 %, 3: -27 % (profiles/abuniform_r02b.txt tail, abmixed_r02d.txt)
+constexpr int WIDTHS_MIXED_PACK_WAVES = 8;     // 6: -2 %, 4-5: -20 %
+
+template <typename T> inline unsigned widths_lds_bytes(int waves)
+{
+    const unsigned need = (WG / 64) * WaveBlock<T>::BLOCK_BYTES;
+    if (waves < 3) waves = 3;                     // 53 KiB per workgroup: stays below the 64 KiB default dynamic-LDS limit
+    unsigned pad = (CU_LDS_BYTES / (unsigned)waves) & ~1023u;
+    return pad > need ? pad : need;
+}
 
 template <typename T, bool PACK>
-hipError_t launch_widths(const WidthsArgs& a0, hipStream_t s)
+hipError_t launch_widths(const WidthsArgs& a0, int waves, hipStream_t s)
 {
     if (a0.n_blocks == 0) return hipSuccess;
     WidthsArgs a = a0;
-    constexpr int TILE = WIDTHS_BPW * (WG / 64);
-    const uint64_t n_tiles = (a.n_blocks + TILE - 1) / TILE;
+    const uint64_t n_tiles = (a.n_blocks + (WG / 64) - 1) / (WG / 64);
     a.tiles_per_xcd = (n_tiles + 7) / 8;
     if (a.tiles_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;   // > 2^33 blocks in one launch
     const dim3 grid((unsigned)(a.tiles_per_xcd * 8));
-    if constexpr (PACK) hipLaunchKernelGGL((k_pack_widths<T, WIDTHS_BPW, WIDTHS_MAXWAVES>), grid, dim3(WG), 0, s, a);
-    else hipLaunchKernelGGL((k_unpack_widths<T, WIDTHS_BPW, WIDTHS_MAXWAVES, false>), grid, dim3(WG), 0, s, a);
+    const unsigned lds = widths_lds_bytes<T>(waves);
+    if constexpr (PACK) hipLaunchKernelGGL((k_pack_widths<T>), grid, dim3(WG), lds, s, a);
+    else hipLaunchKernelGGL((k_unpack_widths<T>), grid, dim3(WG), lds, s, a);
     return hipGetLastError();
 }
 

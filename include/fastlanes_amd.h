@@ -83,6 +83,14 @@ size_t fl_packed_len(unsigned type_bits, unsigned width);
  * the first one, like the allocation-free reference (lib.rs:3).  It is freed at thread exit; this
  * frees the calling thread's context early. */
 void fl_host_release(void);
+/* Two kernel designs serve uniform-width pack / unpack / for_pack / unfor_pack and produce identical
+ * bytes: per-(T,W) "cell-column" kernels and runtime-width "wave-per-block" kernels (the ones the
+ * mixed-width entry points use).  By default each (T, W, direction) runs the one measured faster
+ * (fastlanes_amd/csrc/fl_dispatch.hpp).  For A/B measurements and for testing both designs on every
+ * (T, W): policy 0 = automatic, 1 = cell-column only, 2 = wave-per-block wherever it exists.
+ * Process-wide; affects speed only. */
+void fl_set_kernel_policy(int policy);
+int fl_get_kernel_policy(void);
 
 /*
  * Mixed-width columns (BASELINE.json config 5): block b has its own width widths[b].

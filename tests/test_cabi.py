@@ -24,14 +24,14 @@ def _header_symbols():
     body = text.split("#define FL_DECLARE_TYPE(T, S)")[1].split("FL_DECLARE_TYPE(uint8_t, u8)")[0]
     per_type = re.findall(r"fl_##S##_(\w+)\(", body)
     syms = [f"fl_{ty}_{m}" for ty in ("u8", "u16", "u32", "u64") for m in per_type]
-    syms += re.findall(r"\b(fl_(?:version|status_string|last_hip_error|packed_len|widths_to_offsets|host_release|mixed_plan_\w+))\(", text)
+    syms += re.findall(r"\b(fl_(?:version|status_string|last_hip_error|packed_len|widths_to_offsets|host_release|[sg]et_kernel_policy|mixed_plan_\w+))\(", text)
     return sorted(set(syms))
 
 
 def test_every_declared_symbol_is_exported(lib):
     import fastlanes_amd
     syms = _header_symbols()
-    assert len(syms) == 4 * 29 + 12
+    assert len(syms) == 4 * 29 + 14
     assert sorted(fastlanes_amd.exported_symbols()) == syms
     for s in syms:
         assert hasattr(lib, s), s

@@ -45,10 +45,27 @@ def to_np(t, ty):
 # ---------------------------------------------------------------------------
 # every (T, W): all width-parameterised ops vs the oracle, ragged block count
 # ---------------------------------------------------------------------------
+@pytest.fixture
+def kernel_policy(fl):
+    """fl_set_kernel_policy for one test, restored afterwards (0 automatic, 1 cell-column kernels, 2 wave-per-block)."""
+    lib = fl.load()
+
+    def set_policy(p):
+        lib.fl_set_kernel_policy(p)
+        assert lib.fl_get_kernel_policy() == p
+    yield set_policy
+    lib.fl_set_kernel_policy(0)
+
+
+@pytest.mark.parametrize("policy", [0, 1, 2])
 @pytest.mark.parametrize("ty", TYS)
-def test_all_widths_vs_oracle(fl, oracle, ty):
+def test_all_widths_vs_oracle(fl, oracle, kernel_policy, ty, policy):
+    """Every (T, W) x {pack, unpack, for_pack, unfor_pack, undelta_pack} against the oracle -- under the automatic
+    kernel choice and with each of the two kernel designs forced, so BOTH are parity-tested on all 124 pairs
+    whatever fl_dispatch.hpp currently prefers."""
+    kernel_policy(policy)
     T = tbits(ty)
-    n = 37  # not a multiple of the 32-block workgroup, nor of the 8-block wavefront
+    n = 37  # not a multiple of the 32-block workgroup, nor of the 8-block wavefront, nor of the 4-block one
     for w in range(T + 1):
         seed = 7000 + 64 * T + w
         v = values(ty, n * 1024, seed)                       # over-wide: pack must truncate
@@ -65,8 +82,13 @@ def test_all_widths_vs_oracle(fl, oracle, ty):
         assert np.array_equal(got, oracle.batch("for_pack", ty, w, v, aux=refs)), (ty, w, "for_pack")
         got = to_np(fl.FoR.unfor_pack(w, dpk, drefs, n_blocks=n), ty)
         assert np.array_equal(got, oracle.batch("unfor_pack", ty, w, pk, aux=refs, n_blocks=n)), (ty, w, "unfor_pack")
-        got = to_np(fl.Delta.undelta_pack(w, dpk, dbases), ty)
-        assert np.array_equal(got, oracle.batch("undelta_pack", ty, w, pk, aux=bases, n_blocks=n)), (ty, w, "undelta_pack")
+        # one reference broadcast to every block (reference_stride 0): the scalar form of ffor.rs:5-17
+        one = drefs[:1]
+        got = to_np(fl.FoR.unfor_pack(w, dpk, one, n_blocks=n), ty)
+        assert np.array_equal(got, oracle.batch("unfor_pack", ty, w, pk, aux=np.full(n, refs[0], dtype=refs.dtype), n_blocks=n)), (ty, w, "unfor_pack bcast")
+        if policy == 0:
+            got = to_np(fl.Delta.undelta_pack(w, dpk, dbases), ty)
+            assert np.array_equal(got, oracle.batch("undelta_pack", ty, w, pk, aux=bases, n_blocks=n)), (ty, w, "undelta_pack")
 
 
 @pytest.mark.parametrize("ty", TYS)
@@ -120,8 +142,10 @@ def test_unpack_single_every_width_every_index(fl, oracle, ty):
 # ---------------------------------------------------------------------------
 # committed golden fixtures (no oracle involved at run time)
 # ---------------------------------------------------------------------------
+@pytest.mark.parametrize("policy", [1, 2])
 @pytest.mark.parametrize("ty", TYS)
-def test_golden_fixtures(fl, ty):
+def test_golden_fixtures(fl, kernel_policy, ty, policy):
+    kernel_policy(policy)
     T = tbits(ty)
     for w in range(T + 1):
         i = case_inputs(ty, w)

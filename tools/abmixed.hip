@@ -58,22 +58,8 @@ void k_stream_tuned(const u32x4* in, u32x4* out, uint64_t n_tiles, uint64_t tile
     if (WR == 0 && acc.x == 0x12345678u) *sink = acc;
 }
 
-template <typename T, int BPW, int MAXW, bool PF>
-void launch_v(WidthsArgs a)
-{
-    constexpr int TILE = BPW * 4;
-    const uint64_t n_tiles = (a.n_blocks + TILE - 1) / TILE;
-    a.tiles_per_xcd = (n_tiles + 7) / 8;
-    hipLaunchKernelGGL((k_unpack_widths<T, BPW, MAXW, PF>), dim3((unsigned)(a.tiles_per_xcd * 8)), dim3(256), 0, 0, a);
-}
-template <typename T, int BPW, int MAXW>
-void launch_p(WidthsArgs a)
-{
-    constexpr int TILE = BPW * 4;
-    const uint64_t n_tiles = (a.n_blocks + TILE - 1) / TILE;
-    a.tiles_per_xcd = (n_tiles + 7) / 8;
-    hipLaunchKernelGGL((k_pack_widths<T, BPW, MAXW>), dim3((unsigned)(a.tiles_per_xcd * 8)), dim3(256), 0, 0, a);
-}
+template <typename T> void launch_v(const WidthsArgs& a, int waves) { (void)launch_widths<T, false>(a, waves, 0); }
+template <typename T> void launch_p(const WidthsArgs& a, int waves) { (void)launch_widths<T, true>(a, waves, 0); }
 
 struct Variant { std::string name; double bytes; std::function<void()> launch; std::vector<float> ms; };
 
@@ -140,7 +126,7 @@ int main(int argc, char** argv)
         printf("device scan: total %s, offsets %s\n", h_total == pbytes ? "ok" : "WRONG", a == b ? "identical to the host plan" : "DIFFERENT");
     }
 
-    WidthsArgs wa{packed, out_new, d_w, d_off, d_err, n, 0, 0};
+    WidthsArgs wa{packed, out_new, d_w, d_off, d_err, nullptr, 0, n, 0, 0};
     // correctness: plan kernel (shipped in round 1, parity-tested) vs every new shape
     FLCK(fl_u32_unpack_mixed(plan, (const uint32_t*)packed, (uint32_t*)out_ref, nullptr));
     CK(hipDeviceSynchronize());
@@ -149,17 +135,15 @@ int main(int argc, char** argv)
         f();
         CK(hipDeviceSynchronize());
         CK(hipGetLastError());
-        printf("  %-44s output %s\n", name, diff(out_ref, out_new, n * 4096, d_count) == 0 ? "== plan kernel" : "MISMATCH");
+        printf("  %-44s output %s\n", name, diff(out_ref, out_new, n * 4096, d_count) == 0 ? "== library kernel" : "MISMATCH");
     };
-    check("wave-per-block bpw8 maxw3 pf", [&] { launch_v<uint32_t, 8, 3, true>(wa); });
-    check("wave-per-block bpw8 maxw3 nopf", [&] { launch_v<uint32_t, 8, 3, false>(wa); });
-    check("wave-per-block bpw4 maxw4 pf", [&] { launch_v<uint32_t, 4, 4, true>(wa); });
-    check("wave-per-block bpw16 maxw2 pf", [&] { launch_v<uint32_t, 16, 2, true>(wa); });
+    check("wave-per-block, 6 waves/SIMD", [&] { launch_v<uint32_t>(wa, 6); });
+    check("wave-per-block, 3 waves/SIMD", [&] { launch_v<uint32_t>(wa, 3); });
     // pack round trip: pack_widths(unpack) must reproduce the packed column where the values fit
     {
-        WidthsArgs pa{repacked, out_ref, d_w, d_off, d_err, n, 0, 0};
+        WidthsArgs pa{repacked, out_ref, d_w, d_off, d_err, nullptr, 0, n, 0, 0};
         CK(hipMemset(repacked, 0x5A, pbytes));
-        launch_p<uint32_t, 8, 2>(pa);
+        launch_p<uint32_t>(pa, 6);
         CK(hipDeviceSynchronize());
         CK(hipGetLastError());
         printf("  %-44s packed  %s\n", "pack_widths(unpack_mixed(x))", diff(packed, repacked, pbytes & ~15ull, d_count) == 0 ? "== x" : "MISMATCH");
@@ -171,17 +155,12 @@ int main(int argc, char** argv)
     std::vector<Variant> vs;
     const double bytes = (double)pbytes + (double)n * 4096;
     auto add = [&](const std::string& name, std::function<void()> f, double by) { vs.push_back({name, by, f, {}}); };
-    add("plan kernel (round 1, bucketed tiles)", [=] { fl_u32_unpack_mixed(plan, (const uint32_t*)packed, (uint32_t*)out_ref, nullptr); }, bytes);
-#define V(BPW, MW, PF) add(std::string("wave-per-block bpw" #BPW " maxw" #MW) + (PF ? " pf" : " nopf"), [=] { launch_v<uint32_t, BPW, MW, PF>(wa); }, bytes)
-    V(8, 3, true); V(8, 4, true); V(8, 5, true); V(8, 8, true);
-    V(4, 4, true); V(4, 6, true);
-    V(2, 4, true); V(2, 6, true); V(2, 8, true); V(2, 4, false); V(2, 8, false);
-    V(1, 3, false); V(1, 4, false); V(1, 5, false); V(1, 6, false); V(1, 8, false);
+    add("library fl_u32_unpack_mixed", [=] { fl_u32_unpack_mixed(plan, (const uint32_t*)packed, (uint32_t*)out_ref, nullptr); }, bytes);
+    for (int wv : {3, 4, 5, 6, 8}) add("wave-per-block, " + std::to_string(wv) + " waves/SIMD", [=] { launch_v<uint32_t>(wa, wv); }, bytes);
     {
-        WidthsArgs pa{repacked, out_ref, d_w, d_off, d_err, n, 0, 0};
-#define P(BPW, MW) add("pack_widths bpw" #BPW " maxw" #MW, [=] { launch_p<uint32_t, BPW, MW>(pa); }, bytes)
-        P(8, 3); P(8, 4); P(8, 6); P(8, 8); P(4, 4); P(4, 8); P(2, 4); P(2, 8); P(1, 4); P(1, 6); P(1, 8);
-        add("plan pack kernel (round 1)", [=] { fl_u32_pack_mixed(plan, (const uint32_t*)out_ref, (uint32_t*)repacked, nullptr); }, bytes);
+        WidthsArgs pa{repacked, out_ref, d_w, d_off, d_err, nullptr, 0, n, 0, 0};
+        for (int wv : {3, 4, 5, 6, 8}) add("pack_widths, " + std::to_string(wv) + " waves/SIMD", [=] { launch_p<uint32_t>(pa, wv); }, bytes);
+        add("library fl_u32_pack_mixed", [=] { fl_u32_pack_mixed(plan, (const uint32_t*)out_ref, (uint32_t*)repacked, nullptr); }, bytes);
     }
     add("widths->offsets device scan (3 launches)", [=] { launch_widths_to_offsets(sa, 0); }, (double)n * (1 + 8 + 16));
     {
@@ -197,6 +176,12 @@ int main(int argc, char** argv)
         add("bare stream 17rd:32wr maxw3", [=] { hipLaunchKernelGGL((k_stream_tuned<17, 32, 3>), dim3((unsigned)(tpx2 * 8)), dim3(256), 0, 0, (const u32x4*)out_ref, (u32x4*)out_new, n_tiles2, tpx2, sink); }, by2);
     }
     if (pattern == 2) {
+        const uint64_t nt = n / 32, tpx3 = (nt + 7) / 8;
+        const double by3 = (double)nt * 256 * 39 * 16;
+        add("bare stream 32rd:7wr maxw1", [=] { hipLaunchKernelGGL((k_stream_tuned<32, 7, 1>), dim3((unsigned)(tpx3 * 8)), dim3(256), 0, 0, (const u32x4*)out_ref, (u32x4*)repacked, nt, tpx3, sink); }, by3);
+        add("bare stream 32rd:7wr maxw2", [=] { hipLaunchKernelGGL((k_stream_tuned<32, 7, 2>), dim3((unsigned)(tpx3 * 8)), dim3(256), 0, 0, (const u32x4*)out_ref, (u32x4*)repacked, nt, tpx3, sink); }, by3);
+        add("bare stream 32rd:7wr maxw4", [=] { hipLaunchKernelGGL((k_stream_tuned<32, 7, 4>), dim3((unsigned)(tpx3 * 8)), dim3(256), 0, 0, (const u32x4*)out_ref, (u32x4*)repacked, nt, tpx3, sink); }, by3);
+        add("bare stream 32rd:7wr maxw8", [=] { hipLaunchKernelGGL((k_stream_tuned<32, 7, 8>), dim3((unsigned)(tpx3 * 8)), dim3(256), 0, 0, (const u32x4*)out_ref, (u32x4*)repacked, nt, tpx3, sink); }, by3);
         add("uniform k_unpack<u32,7> (shipped)", [=] { fl_u32_unpack(7, (const uint32_t*)packed, (uint32_t*)out_ref, n, nullptr); }, bytes);
         add("uniform k_pack<u32,7> (shipped)", [=] { fl_u32_pack(7, (const uint32_t*)out_ref, (uint32_t*)repacked, n, nullptr); }, bytes);
     }
