@@ -33,14 +33,11 @@ template <typename T> __device__ __forceinline__ uint64_t cell_hsum(const Cell<T
     else if constexpr (sizeof(T) == 4) return (uint64_t)c.x[0] + c.x[1] + c.x[2] + c.x[3];
     else if constexpr (sizeof(T) == 2) {
         uint32_t s = 0;
-        for (int i = 0; i < 4; ++i) s += (c.x[i] & 0xffffu) + (c.x[i] >> 16);
+        for (int i = 0; i < 4; ++i) s = __builtin_amdgcn_sad_u16(c.x[i], 0u, s);     // v_sad_u16: both halfwords + s, one op
         return s;
     } else {
         uint32_t s = 0;
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t p = (c.x[i] & 0x00ff00ffu) + ((c.x[i] >> 8) & 0x00ff00ffu);
-            s += (p & 0xffffu) + (p >> 16);
-        }
+        for (int i = 0; i < 4; ++i) s = __builtin_amdgcn_sad_u8(c.x[i], 0u, s);      // v_sad_u8: all four bytes + s, one op
         return s;
     }
 }
@@ -122,9 +119,9 @@ __global__ __launch_bounds__(WG) void k_block_min_max(ReduceArgs a)
 // unpacked (FastLanes index) order -- a selection vector straight from packed data: 128*W bytes
 // in, 128 bytes out per block.  Every predicate is reduced on the host to one of two primitives
 // (x == k, x <= k) plus a final complement.  Address-row j of a block is elements [j*LANES,
-// (j+1)*LANES): the 8 column threads OR their PER_CELL-bit pieces together with three DPP steps
-// (lane^1, lane^2, 7-lane) per 32-bit mask word, and thread c keeps words 4c..4c+3, so the mask
-// leaves as one coalesced 16-byte store per thread.
+// (j+1)*LANES) = mask bits [j*LANES, (j+1)*LANES); every column thread contributes PER_CELL contiguous bits
+// of each row.  The pieces are put together in a wave-private LDS image of the block's 128-byte mask
+// (u8/u16/u32) or with DPP OR-reductions (u64), and the mask leaves as one coalesced 16-byte store per thread.
 // ---------------------------------------------------------------------------
 struct CompareArgs {
     const u32x4* in;
@@ -144,46 +141,109 @@ __device__ __forceinline__ uint32_t or_allreduce8(uint32_t x)
     return x;
 }
 
+// Per-row predicate bits of one cell column: bit e of the result = cmp(element e of the cell, k), e < PER_CELL.
+//   u64 / u32 : one compare per element.
+//   u16 / u8  : SWAR -- all elements of a 32-bit word are compared at once, the verdicts land in the top bit of
+//               each element field (H), and the H bits of the cell's four words are squeezed together
+//               (per-element extraction cost ~4.5 VALU operations per value and capped these kernels at 0.47 of the
+//               HBM peak; this is ~2.5).
 template <typename T, int W, bool IS_EQ>
-__device__ __forceinline__ void compare_block(const Cell<T>* in, T k, unsigned c, uint32_t (&keep)[4])
+__device__ __forceinline__ uint32_t row_predicate_bits(const Cell<T>& v, T k)
 {
-    constexpr int TB = Elem<T>::BITS;
-    constexpr int N = Elem<T>::PER_CELL;              // bits this thread contributes per row
-    constexpr int LANES = Elem<T>::LANES;             // bits per address-row
-    constexpr int PER_S = TB / 8;
-    // per address-row bit pieces of this thread
-    uint32_t piece[TB];
-    static_for<TB>([&](auto J) {
-        constexpr int j = decltype(J)::value;
-        constexpr int row = fl_order((j % PER_S) * (8 / PER_S)) * 8 + j / PER_S;
-        const Cell<T> v = unpack_row<T, W, row>(in);
+    constexpr int N = Elem<T>::PER_CELL;
+    if constexpr (sizeof(T) >= 4) {
         uint32_t bits = 0;
         static_for<N>([&](auto E) {
             const T x = (T)cell_get<T>(v, decltype(E)::value);
             const uint32_t p = IS_EQ ? (x == k) : (x <= k);
             bits |= p << decltype(E)::value;
         });
-        piece[j] = bits;
+        return bits;
+    } else {
+        constexpr uint32_t H = sizeof(T) == 2 ? 0x80008000u : 0x80808080u;
+        constexpr uint32_t L = ~H;
+        const uint32_t kr = Cell<T>::splat(k).x[0];
+        uint32_t p[4];
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t x = v.x[i];
+            if constexpr (IS_EQ) {
+                const uint32_t y = x ^ kr;
+                p[i] = ~(((y & L) + L) | y) & H;                           // field == 0
+            } else if constexpr (W < (int)(sizeof(T) * 8)) {
+                // elements are < 2^W <= 2^(T-1): their top bit is clear, so x <= k  <=>  k's top bit | low(k) >= x
+                p[i] = (((kr | H) - x) | kr) & H;
+            } else {
+                const uint32_t ge_low = (kr | H) - (x & L);                // H bit: low(k) >= low(x), no borrow across fields
+                p[i] = ((~x & kr) | (~(x ^ kr) & ge_low)) & H;
+            }
+        }
+        if constexpr (sizeof(T) == 2) {
+            // H bits 15 / 31 of word i -> bits 2i / 16 + 2i, then fold the upper halfword in between
+            const uint32_t q = (p[0] >> 15) | (p[1] >> 13) | (p[2] >> 11) | (p[3] >> 9);
+            return (q & 0x55u) | ((q >> 15) & 0xAAu);
+        } else {
+            // H bits 7/15/23/31 of a word -> one nibble: (x * 0x01020408) >> 24 moves bit 8b to bit 24 + b (no two
+            // partial products share a bit position, so there are no carries)
+            uint32_t bits = 0;
+            for (int i = 0; i < 4; ++i) bits |= (((p[i] >> 7) * 0x01020408u) >> 24) << (4 * i);
+            return bits;
+        }
+    }
+}
+
+// u64: the 8 column threads OR their 2-bit pieces together with three DPP steps per 32-bit mask word.
+template <typename T, int W, bool IS_EQ>
+__device__ __forceinline__ void compare_block_dpp(const Cell<T>* in, T k, unsigned c, uint32_t (&keep)[4])
+{
+    constexpr int TB = Elem<T>::BITS;
+    constexpr int N = Elem<T>::PER_CELL;              // bits this thread contributes per row
+    constexpr int LANES = Elem<T>::LANES;             // bits per address-row
+    constexpr int PER_S = TB / 8;
+    static_assert(LANES <= 32, "one or more address-rows per mask word");
+    uint32_t piece[TB];
+    static_for<TB>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        constexpr int row = fl_order((j % PER_S) * (8 / PER_S)) * 8 + j / PER_S;
+        piece[j] = row_predicate_bits<T, W, IS_EQ>(unpack_row<T, W, row>(in), k);
     });
-    // 32 mask words per block; word d covers bits [32d, 32d+32) = rows (32d)/LANES ...
     static_for<32>([&](auto D) {
         constexpr int d = decltype(D)::value;
+        constexpr int RPW = 32 / LANES;               // address-rows per mask word
         uint32_t w = 0;
-        if constexpr (LANES <= 32) {
-            constexpr int RPW = 32 / LANES;           // address-rows per mask word (u32: 1, u64: 2)
-            static_for<RPW>([&](auto Q) {
-                constexpr int q = decltype(Q)::value;
-                w |= piece[d * RPW + q] << (q * LANES + c * N);
-            });
-        } else {
-            constexpr int WPR = LANES / 32;           // mask words per address-row (u16: 2, u8: 4)
-            constexpr int j = d / WPR, h = d % WPR;
-            const unsigned pos = c * N;               // bit position of this thread's piece in its row
-            w = (pos / 32 == (unsigned)h) ? piece[j] << (pos % 32) : 0u;
-        }
+        static_for<RPW>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            w |= piece[d * RPW + q] << (q * LANES + c * N);
+        });
         w = or_allreduce8(w);
         if (d / 4 == (int)c) keep[d % 4] = w;
     });
+}
+
+// u8 / u16 / u32: the block's 128-byte mask is assembled in a wave-private LDS image -- address-row j is bits
+// [j*LANES, (j+1)*LANES) and thread c owns PER_CELL contiguous bits of it (16 bits: ds_write_b16, 8 bits: ds_write_b8,
+// 4 bits: one DPP exchange with the neighbour column makes a byte) -- and read back as one 16-byte cell per thread.
+template <typename T, int W, bool IS_EQ>
+__device__ __forceinline__ void compare_block_lds(const Cell<T>* in, T k, unsigned c, char* lds_blk, uint32_t (&keep)[4])
+{
+    constexpr int TB = Elem<T>::BITS;
+    constexpr int PER_S = TB / 8;
+    static_for<TB>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        constexpr int row = fl_order((j % PER_S) * (8 / PER_S)) * 8 + j / PER_S;
+        const uint32_t bits = row_predicate_bits<T, W, IS_EQ>(unpack_row<T, W, row>(in), k);
+        if constexpr (sizeof(T) == 1) {
+            *reinterpret_cast<uint16_t*>(lds_blk + j * 16 + c * 2) = (uint16_t)bits;
+        } else if constexpr (sizeof(T) == 2) {
+            *reinterpret_cast<uint8_t*>(lds_blk + j * 8 + c) = (uint8_t)bits;
+        } else {
+            uint32_t w = bits << (4 * (c & 1u));
+            w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]: lane ^ 1
+            *reinterpret_cast<uint8_t*>(lds_blk + j * 4 + (c >> 1)) = (uint8_t)w;           // both columns of the pair write the same byte
+        }
+    });
+    wave_lds_fence();
+    const u32x4 m = *reinterpret_cast<const u32x4*>(lds_blk + c * 16);
+    keep[0] = m[0]; keep[1] = m[1]; keep[2] = m[2]; keep[3] = m[3];
 }
 
 template <typename T, int W, bool IS_EQ>
@@ -195,12 +255,17 @@ __global__ __launch_bounds__(WG) void k_unpack_compare(CompareArgs a)
     const unsigned tid = threadIdx.x;
     const uint64_t blk = tile * BLOCKS_PER_WG + (tid >> 3);
     const unsigned c = tid & 7u;
-    if (blk >= a.n_blocks) return;     // whole 8-thread groups leave together (DPP stays inside a group)
+    if (blk >= a.n_blocks) return;     // whole 8-thread groups leave together (DPP / LDS exchange stays inside a group)
     Cell<T> in[W ? W : 1];
     const u32x4* pk = a.in + blk * (uint64_t)(8 * W) + c;
     static_for<W>([&](auto Wd) { in[decltype(Wd)::value] = load_cell<T, true>(pk + 8 * decltype(Wd)::value); });
     uint32_t keep[4] = {0, 0, 0, 0};
-    compare_block<T, W, IS_EQ>(in, (T)a.constant, c, keep);
+    if constexpr (sizeof(T) == 8) {
+        compare_block_dpp<T, W, IS_EQ>(in, (T)a.constant, c, keep);
+    } else {
+        __shared__ __attribute__((aligned(16))) char lds[BLOCKS_PER_WG * 128];
+        compare_block_lds<T, W, IS_EQ>(in, (T)a.constant, c, lds + (tid >> 3) * 128, keep);
+    }
     const uint32_t flip = a.invert ? ~0u : 0u;
     u32x4 out = {keep[0] ^ flip, keep[1] ^ flip, keep[2] ^ flip, keep[3] ^ flip};
     a.mask[blk * 8 + c] = out;

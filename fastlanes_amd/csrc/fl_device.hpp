@@ -21,8 +21,9 @@
 //
 // This header is also the user-extensible "functor" surface corresponding to
 // the reference's exported pack!/unpack!/iterate! macros (macros.rs:11,34,100):
-// unpack_rows<T,W>(cells, f) calls f(row_constant, cell) in row order, and
-// pack_rows<T,W>(src_of_row, sink_of_word) is its inverse.
+// iterate_rows<T>(f) walks the rows in order (iterate!), unpack_rows<T,W>(cells, f)
+// calls f(row_constant, cell) in row order (unpack!), and pack_rows<T,W>(src_of_row,
+// sink_of_word) is its inverse (pack!).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -372,6 +373,23 @@ __device__ __forceinline__ void load_lane_runs_lines(char* lds_blk, unsigned c, 
             });
         }
         wave_lds_fence();
+    });
+}
+
+// ---------------------------------------------------------------------------
+// iterate_rows: the iterate! macro (macros.rs:11-32) on one cell column -- visits the block's T logical
+// rows IN ORDER (the order a stateful body such as Delta's running value needs, delta.rs:24-45), handing the
+// body the compile-time row and where that row's cell sits in an unpacked block:
+//   f(R, C):  R = integral_constant<int, row>,  C = integral_constant<int, Elem<T>::row_cell(row)>
+// i.e. the thread's column c of row `row` is cell `C::value + c` of the block (`idx = index(row, lane)` for the
+// 16/sizeof(T) lanes of that cell at once).  unpack_rows / pack_rows below are the same walk with the bit
+// (un)packing of unpack! / pack! spliced in.
+// ---------------------------------------------------------------------------
+template <typename T, typename F>
+__device__ __forceinline__ void iterate_rows(F&& f)
+{
+    static_for<Elem<T>::BITS>([&](auto R) {
+        f(R, std::integral_constant<int, Elem<T>::row_cell(decltype(R)::value)>{});
     });
 }
 

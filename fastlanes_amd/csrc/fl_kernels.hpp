@@ -292,7 +292,7 @@ void k_delta(StreamArgs a)
             rows[WaveRowStore<T>::row_at(decltype(J)::value)] = load_cell<T, true>(src + 8 * decltype(J)::value);
         });
     }
-    static_for<TB>([&](auto R) {
+    iterate_rows<T>([&](auto R, auto) {                                         // iterate!(T, lane, |idx| ..), delta.rs:26,38
         constexpr int row = decltype(R)::value;
         if constexpr (INVERSE) {
             prev = rows[row].add(prev);                                         // delta.rs:40-42

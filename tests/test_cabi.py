@@ -147,8 +147,9 @@ def test_functor_api_example_builds():
     """examples/fused_dict_decode.hip (a user-written fused kernel on fl_device.hpp, the
     counterpart of the reference's exported unpack! macro) cross-compiles for gfx950."""
     import __graft_entry__ as ge
-    so = ge.build_examples()
-    assert hasattr(ctypes.CDLL(so), "example_dict_unpack_u32_w8")
+    sos = ge.build_examples()
+    assert hasattr(ctypes.CDLL(sos["fused_dict_decode"]), "example_dict_unpack_u32_w8")
+    assert hasattr(ctypes.CDLL(sos["iterate_running_max"]), "example_running_max_u32")
 
 
 def test_python_mirror_rejects_mismatched_buffers():

@@ -570,7 +570,7 @@ def test_functor_api_user_kernel_dict_decode(fl, oracle):
     import ctypes
     import torch
     import __graft_entry__ as ge
-    lib = ctypes.CDLL(ge.build_examples())
+    lib = ctypes.CDLL(ge.build_examples()["fused_dict_decode"])
     lib.example_dict_unpack_u32_w8.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p]
     n = 70
     pk = values("u32", n * 256, 21)
@@ -583,6 +583,44 @@ def test_functor_api_user_kernel_dict_decode(fl, oracle):
     torch.cuda.synchronize()
     want = dic[oracle.batch("unpack", "u32", 8, pk)]
     assert np.array_equal(to_np(out, "u32"), want)
+
+
+def test_functor_api_user_kernel_on_iterate_rows(fl, oracle):
+    """examples/iterate_running_max.hip: a stateful body spliced into fl::iterate_rows (the iterate! counterpart,
+    macros.rs:11-32) -- a running maximum along every FastLanes lane in row order, the shape of Delta::undelta
+    (delta.rs:36-45) -- against the same walk written with the oracle's index(row, lane) (macros.rs:20-24)."""
+    import ctypes
+    import torch
+    import __graft_entry__ as ge
+    lib = ctypes.CDLL(ge.build_examples()["iterate_running_max"])
+    lib.example_running_max_u32.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p]
+    n = 45
+    v = values("u32", n * 1024, 31)
+    base = values("u32", n * 32, 32) >> np.uint32(1)       # about half of the lanes start above their first values
+    out = torch.empty(n * 1024, dtype=torch.uint32, device="cuda:0")
+    dv, dbase = to_dev(v), to_dev(base)                    # keep the device tensors alive across the raw-pointer call
+    rc = lib.example_running_max_u32(dv.data_ptr(), dbase.data_ptr(), out.data_ptr(), n,
+                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    idx = np.array([[oracle.index(r, l) for l in range(32)] for r in range(32)])      # [row][lane]
+    want = np.empty_like(v)
+    for b in range(n):
+        blk = v[b * 1024:(b + 1) * 1024]
+        run = base[b * 32:(b + 1) * 32].copy()
+        for r in range(32):
+            run = np.maximum(run, blk[idx[r]])
+            want[b * 1024 + idx[r]] = run
+    assert np.array_equal(to_np(out, "u32"), want)
+    # and the library's own user of iterate_rows: Delta::undelta == the same walk with a running sum
+    got = to_np(fl.Delta.undelta(to_dev(v), to_dev(base)), "u32")
+    wsum = np.empty_like(v)
+    for b in range(n):
+        run = base[b * 32:(b + 1) * 32].copy()
+        for r in range(32):
+            run = run + v[b * 1024 + idx[r]]
+            wsum[b * 1024 + idx[r]] = run
+    assert np.array_equal(got, wsum)
 
 
 # ---------------------------------------------------------------------------
