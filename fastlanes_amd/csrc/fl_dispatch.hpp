@@ -14,25 +14,27 @@ namespace fl {
 
 enum WaveOp { WAVE_UNPACK = 0, WAVE_PACK = 1 };
 
-// Rows of profiles/abuniform_r02b.txt (GB/s, same buffers, every (T, W), cell-column vs wave-per-block at 3/4/5/6/8
-// waves per SIMD); the wave-per-block kernel is chosen where it led by >= 2 %.  Broadly: it wins for the 32- and
-// 64-bit types except at the narrowest widths (few rows per packed word: pack leaves most lanes idle) and for the
-// widest 64-bit widths; wide widths like few waves in flight (3), narrow ones many (6-8).
+// profiles/abuniform_r02b.txt and abuniform_r02c.txt are two boxes' full sweeps (GB/s on the same buffers, every
+// (T, W), cell-column vs wave-per-block at 3/4/5/6/8 waves per SIMD; r02c packs full-entropy values).  The
+// wave-per-block kernel is chosen where it led on BOTH boxes (typically by 3-10 %); where the boxes disagree (e.g.
+// u32 unpack at W >= 21: +3 % on one, -2 % on the other) the cell-column kernel stays.  Broadly: wave-per-block wins
+// for the 32- and 64-bit types except at the narrowest widths of pack (few rows per packed word leave most lanes
+// idle) and the widest widths; wide widths like few waves in flight (3-4), narrow ones many (6-8).
 inline int wave_policy(unsigned type_bits, unsigned w, WaveOp op)
 {
     if (op == WAVE_UNPACK) {
         switch (type_bits) {
-        case 64: return w <= 1 ? 3 : w == 2 ? 4 : w <= 7 ? 0 : w <= 13 ? 4 : w <= 61 ? 3 : 0;
-        case 32: return w == 0 ? 3 : w <= 2 ? 8 : w <= 7 ? 0 : w <= 27 ? 4 : 3;
+        case 64: return w <= 1 ? 3 : w <= 14 ? 4 : w <= 48 ? 3 : 0;
+        case 32: return w == 0 ? 3 : w <= 4 ? 8 : w <= 7 ? 0 : w <= 20 ? 4 : 0;
         case 16: return w == 0 ? 5 : w <= 5 ? 0 : w <= 10 ? 6 : 4;
         default: return w == 0 ? 6 : w <= 3 ? 0 : 8;
         }
     }
     switch (type_bits) {
-    case 64: return w <= 8 ? 0 : (w % 32 == 0) ? 3 : 4;
-    case 32: return w <= 2 ? 0 : w == 3 ? 8 : w <= 5 ? 6 : 4;
+    case 64: return w <= 7 ? 0 : (w % 32 == 0) ? 3 : 4;
+    case 32: return w <= 4 ? 0 : w <= 7 ? 6 : 4;
     case 16: return w <= 3 ? 0 : w <= 6 ? 8 : w <= 15 ? 6 : 4;
-    default: return w == 8 ? 8 : 0;
+    default: return w >= 7 ? 8 : 0;
     }
 }
 
