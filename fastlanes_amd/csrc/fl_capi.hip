@@ -6,6 +6,7 @@
 #include "fl_kernels.hpp"
 #include "fl_misc.hpp"
 #include "fl_widths.hpp"
+#include "fl_chain.hpp"
 #include "fl_scan.hpp"
 #include "fl_dispatch.hpp"
 #include "fl_consume.hpp"
@@ -27,10 +28,14 @@ std::atomic<int> g_kernel_policy{0};
 inline int chosen_waves(unsigned type_bits, unsigned w, fl::WaveOp op)
 {
     const int p = g_kernel_policy.load(std::memory_order_relaxed);
-    if (p == 1) return 0;
+    if ((p & 0xff) == 1) return 0;
     const int waves = fl::wave_policy(type_bits, w, op);
-    return (p == 2 && waves == 0) ? (op == fl::WAVE_PACK ? fl::WIDTHS_MIXED_PACK_WAVES : fl::WIDTHS_MIXED_UNPACK_WAVES) : waves;
+    if ((p & 0xff) != 2) return waves;
+    if (p >> 8) return p >> 8;                       // A/B tools: policy 2 + 256 * waves forces the occupancy too
+    return waves ? waves : (op == fl::WAVE_PACK ? fl::WIDTHS_MIXED_PACK_WAVES : fl::WIDTHS_MIXED_UNPACK_WAVES);
 }
+
+
 
 inline int hip_fail(hipError_t e)
 {
@@ -55,6 +60,24 @@ int run_stream(stream_launch_t fn, const T* in, T* out, const void* aux, size_t 
     a.n_blocks = n_blocks;
     a.tiles_per_xcd = 0;   // filled by the launcher
     hipError_t e = fn(a, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? FL_OK : hip_fail(e);
+}
+
+// Delta chains on the wave-per-block kernels (fl_chain.hpp)
+template <typename T>
+int run_chain(int mode, int waves, unsigned w, const T* in, const T* bases, T* out, size_t n_blocks, void* stream)
+{
+    if (n_blocks == 0) return FL_OK;
+    if (!out || !bases || ((mode != fl::CHAIN_UNDELTA_PACK || w != 0) && !in)) return FL_ERR_NULL;
+    if (misaligned(in) || misaligned(out) || misaligned(bases)) return FL_ERR_ALIGN;
+    fl::ChainArgs a;
+    a.in = reinterpret_cast<const char*>(in);
+    a.out = reinterpret_cast<char*>(out);
+    a.bases = reinterpret_cast<const char*>(bases);
+    a.n_blocks = n_blocks;
+    a.tiles_per_xcd = 0;
+    a.width = w;
+    hipError_t e = fl::chain_launcher<T>(mode)(a, waves, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
 
@@ -122,6 +145,8 @@ int dev_undelta_pack(unsigned w, const T* in, const T* bases, T* out, size_t n, 
 {
     if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
     if (n && misaligned(bases)) return FL_ERR_ALIGN;
+    if (const int waves = chosen_waves(Elem<T>::BITS, w, WAVE_UNDELTA_PACK))
+        return run_chain<T>(CHAIN_UNDELTA_PACK, waves, w, in, bases, out, n, s);
     return run_stream<T>(unpack_table_impl<T, BODY_UNDELTA>().fn[w], in, out, bases, 0, n, w != 0, true, true, s);
 }
 template <typename T>
@@ -195,6 +220,8 @@ int dev_block_min_max(const T* in, size_t n, T* mins, T* maxs, void* s)
 template <typename T> int dev_delta(bool inverse, const T* in, const T* bases, T* out, size_t n, void* s)
 {
     if (n && misaligned(bases)) return FL_ERR_ALIGN;
+    if (const int waves = chosen_waves(Elem<T>::BITS, Elem<T>::BITS, inverse ? WAVE_UNDELTA : WAVE_DELTA))
+        return run_chain<T>(inverse ? CHAIN_UNDELTA : CHAIN_DELTA, waves, Elem<T>::BITS, in, bases, out, n, s);
     return run_stream<T>(delta_launcher<T>(inverse), in, out, bases, 0, n, true, true, true, s);
 }
 template <typename T> int dev_transpose(bool inverse, const T* in, T* out, size_t n, void* s)
@@ -455,7 +482,7 @@ const uint64_t* fl_mixed_plan_offsets(const fl_mixed_plan* p) { return p ? p->d_
 const uint8_t* fl_mixed_plan_widths(const fl_mixed_plan* p) { return p ? p->d_widths : nullptr; }
 
 void fl_host_release(void) { g_host.release(); }
-void fl_set_kernel_policy(int policy) { g_kernel_policy.store(policy < 0 || policy > 2 ? 0 : policy, std::memory_order_relaxed); }
+void fl_set_kernel_policy(int policy) { g_kernel_policy.store(policy < 0 || (policy & 0xff) > 2 ? 0 : policy, std::memory_order_relaxed); }
 int fl_get_kernel_policy(void) { return g_kernel_policy.load(std::memory_order_relaxed); }
 
 const char* fl_version(void) { return "fastlanes_amd 0.2.0 (gfx950; wire format of spiraldb/fastlanes 0.1.8)"; }

@@ -12,7 +12,7 @@
 
 namespace fl {
 
-enum WaveOp { WAVE_UNPACK = 0, WAVE_PACK = 1 };
+enum WaveOp { WAVE_UNPACK = 0, WAVE_PACK = 1, WAVE_UNDELTA_PACK = 2, WAVE_UNDELTA = 3, WAVE_DELTA = 4 };
 
 // profiles/abuniform_r02b.txt and abuniform_r02c.txt are two boxes' full sweeps (GB/s on the same buffers, every
 // (T, W), cell-column vs wave-per-block at 3/4/5/6/8 waves per SIMD; r02c packs full-entropy values).  The
@@ -20,8 +20,24 @@ enum WaveOp { WAVE_UNPACK = 0, WAVE_PACK = 1 };
 // u32 unpack at W >= 21: +3 % on one, -2 % on the other) the cell-column kernel stays.  Broadly: wave-per-block wins
 // for the 32- and 64-bit types except at the narrowest widths of pack (few rows per packed word leave most lanes
 // idle) and the widest widths; wide widths like few waves in flight (3-4), narrow ones many (6-8).
+// Delta's stateful bodies (fl_chain.hpp) -- profiles/abchain_r02*.txt
+// The chain kernels do more per block (a second pass through LDS and a cross-lane scan), so they only pay where
+// the cell-column kernels are furthest from the memory system's ceiling: delta / undelta of the 16-bit type (+6-7 %),
+// of u32 / u64 at 3 waves/SIMD (+1-4 %), u8 delta (+5 %), and undelta_pack of u64 at mid widths (+3 %).
+inline int chain_policy(unsigned type_bits, unsigned w, WaveOp op)
+{
+    if (op == WAVE_UNDELTA_PACK) return (type_bits == 64 && w >= 12 && w <= 48) ? (w >= 32 ? 3 : 4) : 0;
+    switch (type_bits) {
+    case 64: return 3;
+    case 32: return 3;
+    case 16: return 4;
+    default: return op == WAVE_DELTA ? 8 : 0;
+    }
+}
+
 inline int wave_policy(unsigned type_bits, unsigned w, WaveOp op)
 {
+    if (op >= WAVE_UNDELTA_PACK) return chain_policy(type_bits, w, op);
     if (op == WAVE_UNPACK) {
         switch (type_bits) {
         case 64: return w <= 1 ? 3 : w <= 14 ? 4 : w <= 48 ? 3 : 0;

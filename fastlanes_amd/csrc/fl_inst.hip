@@ -3,12 +3,13 @@
 // pairs x 5 width-parameterised kernels build in parallel:
 //   0 unpack (store)   1 unfor_pack   2 undelta_pack   3 pack   4 for_pack
 //   5 delta / undelta / transpose / untranspose / unpack_single
-//   6 unpack / pack over per-block widths[] / offsets[] read on the device (wave-per-block, fl_widths.hpp)
+//   6 wave-per-block kernels: unpack / pack over per-block (or uniform) widths (fl_widths.hpp), Delta chains (fl_chain.hpp)
 //   10 fused consumers: unpack_block_sums, block_min_max   11 / 12 unpack_compare (selection masks: x <= k / x == k)
 //   8 undelta_pack+untranspose (fused decode to original order)   9 transpose+delta+pack (fused encode)
 #include "fl_kernels.hpp"
 #include "fl_misc.hpp"
 #include "fl_widths.hpp"
+#include "fl_chain.hpp"
 #include "fl_consume.hpp"
 
 namespace fl {
@@ -47,6 +48,11 @@ template <> hipError_t unpack_single_launch<T>(const SingleArgs& a, hipStream_t 
 template <> widths_launch_t widths_launcher<T>(bool pack)
 {
     return pack ? &launch_widths<T, true> : &launch_widths<T, false>;
+}
+template <> chain_launch_t chain_launcher<T>(int mode)
+{
+    return mode == CHAIN_UNDELTA_PACK ? &launch_chain<T, CHAIN_UNDELTA_PACK>
+         : mode == CHAIN_UNDELTA    ? &launch_chain<T, CHAIN_UNDELTA> : &launch_chain<T, CHAIN_DELTA>;
 }
 #elif FL_FAMILY == 8
 static constexpr WidthTable<T> t_undelta_untr = make_unpack_table<T, BODY_UNDELTA_UNTRANSPOSE>(Ws{});

@@ -87,8 +87,9 @@ void fl_host_release(void);
  * bytes: per-(T,W) "cell-column" kernels and runtime-width "wave-per-block" kernels (the ones the
  * mixed-width entry points use).  By default each (T, W, direction) runs the one measured faster
  * (fastlanes_amd/csrc/fl_dispatch.hpp).  For A/B measurements and for testing both designs on every
- * (T, W): policy 0 = automatic, 1 = cell-column only, 2 = wave-per-block wherever it exists.
- * Process-wide; affects speed only. */
+ * (T, W): policy 0 = automatic, 1 = cell-column only, 2 = wave-per-block wherever it exists
+ * (pack, unpack, for_pack, unfor_pack, undelta_pack, delta, undelta); 2 + 256*n additionally runs those
+ * kernels at n wavefronts per SIMD (A/B tools).  Process-wide; affects speed only. */
 void fl_set_kernel_policy(int policy);
 int fl_get_kernel_policy(void);
 

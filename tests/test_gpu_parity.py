@@ -86,13 +86,14 @@ def test_all_widths_vs_oracle(fl, oracle, kernel_policy, ty, policy):
         one = drefs[:1]
         got = to_np(fl.FoR.unfor_pack(w, dpk, one, n_blocks=n), ty)
         assert np.array_equal(got, oracle.batch("unfor_pack", ty, w, pk, aux=np.full(n, refs[0], dtype=refs.dtype), n_blocks=n)), (ty, w, "unfor_pack bcast")
-        if policy == 0:
-            got = to_np(fl.Delta.undelta_pack(w, dpk, dbases), ty)
-            assert np.array_equal(got, oracle.batch("undelta_pack", ty, w, pk, aux=bases, n_blocks=n)), (ty, w, "undelta_pack")
+        got = to_np(fl.Delta.undelta_pack(w, dpk, dbases), ty)
+        assert np.array_equal(got, oracle.batch("undelta_pack", ty, w, pk, aux=bases, n_blocks=n)), (ty, w, "undelta_pack")
 
 
+@pytest.mark.parametrize("policy", [0, 1, 2])
 @pytest.mark.parametrize("ty", TYS)
-def test_delta_transpose_vs_oracle(fl, oracle, ty):
+def test_delta_transpose_vs_oracle(fl, oracle, kernel_policy, ty, policy):
+    kernel_policy(policy)
     n = 37
     v = values(ty, n * 1024, 91 + tbits(ty))
     bases = values(ty, n * lanes(ty), 92 + tbits(ty))

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""A/B on the GPU box: Delta's kernels (undelta_pack, undelta, delta) through the cell-column kernels vs the
+wave-per-block chain kernels (fl_chain.hpp) at several occupancies, interleaved on the SAME buffers via
+fl_set_kernel_policy (1 = cell-column; 2 + 256*n = wave-per-block at n waves/SIMD).  GB/s of algorithmic bytes."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import fastlanes_amd as fl  # noqa: E402
+from bench import rand_u8  # noqa: E402
+
+lib = fl.load()
+dev = torch.device("cuda", 0)
+TD = {"u8": (torch.uint8, 8), "u16": (torch.uint16, 16), "u32": (torch.uint32, 32), "u64": (torch.uint64, 64)}
+WAVES = (3, 4, 5, 6, 8)
+ROUNDS = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+cases = [("u32", 12), ("u32", 7), ("u32", 3), ("u32", 20), ("u32", 28), ("u64", 20), ("u64", 5), ("u64", 40), ("u64", 60),
+         ("u16", 9), ("u16", 3), ("u16", 14), ("u8", 4), ("u8", 7)]
+print("GB/s, median of %d; cc = cell-column, then wave-per-block at %s waves/SIMD" % (ROUNDS, " ".join(map(str, WAVES))))
+seen_plain = set()
+for ty, W in cases:
+    tdt, T = TD[ty]
+    esz = T // 8
+    n = (12 << 30) // (128 * W + 128 * T + 128)
+    pk = rand_u8(n * 128 * W, 2, dev).view(tdt)
+    un = rand_u8(n * 1024 * esz, 1, dev).view(tdt)
+    out = torch.empty(n * 1024, dtype=tdt, device=dev)
+    bases = rand_u8(n * 128, 3, dev).view(tdt)
+    ops = {"undelta_pack": (lambda: fl.Delta.undelta_pack(W, pk, bases, output=out), n * (128 * W + 128 + 128 * T))}
+    if ty not in seen_plain:
+        seen_plain.add(ty)
+        ops["undelta"] = (lambda: fl.Delta.undelta(un, bases, output=out), n * (256 * T + 128))
+        ops["delta"] = (lambda: fl.Delta.delta(un, bases, output=out), n * (256 * T + 128))
+    for name, (f, nbytes) in ops.items():
+        lib.fl_set_kernel_policy(1)
+        f()
+        ref = out.clone()
+        lib.fl_set_kernel_policy(2)
+        f()
+        same = torch.equal(ref.view(torch.uint8), out.view(torch.uint8))
+        del ref
+        res = {}
+        pols = [1] + [2 + 256 * w for w in WAVES]
+        for _ in range(ROUNDS):
+            for p in pols:
+                lib.fl_set_kernel_policy(p)
+                f()
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); f(); b.record()
+                torch.cuda.synchronize()
+                res.setdefault(p, []).append(a.elapsed_time(b))
+        g = [nbytes / sorted(res[p])[len(res[p]) // 2] / 1e6 for p in pols]
+        print(f"{ty:3s} W={W:<2d} {name:13s}{'' if same else ' MISMATCH'} | cc {g[0]:6.0f}  wpb " + " ".join(f"{x:6.0f}" for x in g[1:]), flush=True)
+    lib.fl_set_kernel_policy(0)
+    del pk, un, out, bases
