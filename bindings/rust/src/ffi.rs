@@ -54,7 +54,29 @@ declare_type!(u64, fl_u64_pack_host, fl_u64_unpack_host, fl_u64_unpack_single_ho
               fl_u64_pack, fl_u64_unpack, fl_u64_for_pack, fl_u64_unfor_pack, fl_u64_delta, fl_u64_undelta,
               fl_u64_undelta_pack, fl_u64_transpose, fl_u64_untranspose);
 
+// Mixed-width columns: the caller loop `for b { T::unchecked_unpack(widths[b], &packed[off[b]..], ..) }`
+// (bitpacking.rs:109-129) with widths[] (u8) and offsets[] (u64 byte offsets) resident in HBM.
+macro_rules! declare_widths {
+    ($T:ty, $unpack_widths:ident, $pack_widths:ident) => {
+        extern "C" {
+            pub fn $unpack_widths(d_widths: *const u8, d_offsets: *const u64, d_packed: *const $T, d_out: *mut $T,
+                                  n_blocks: usize, d_err_flag: *mut u32, stream: *mut c_void) -> i32;
+            pub fn $pack_widths(d_widths: *const u8, d_offsets: *const u64, d_in: *const $T, d_packed: *mut $T,
+                                n_blocks: usize, d_err_flag: *mut u32, stream: *mut c_void) -> i32;
+        }
+    };
+}
+declare_widths!(u8, fl_u8_unpack_widths, fl_u8_pack_widths);
+declare_widths!(u16, fl_u16_unpack_widths, fl_u16_pack_widths);
+declare_widths!(u32, fl_u32_unpack_widths, fl_u32_pack_widths);
+declare_widths!(u64, fl_u64_unpack_widths, fl_u64_pack_widths);
+
 extern "C" {
+    /// offsets[b] = sum_{i<b} 128 * widths[i] on the device (three small launches, no scratch memory)
+    pub fn fl_widths_to_offsets(type_bits: u32, d_widths: *const u8, n_blocks: usize, d_offsets: *mut u64,
+                                d_total_bytes: *mut u64, d_err_flag: *mut u32, stream: *mut c_void) -> i32;
+    /// frees the calling thread's cached host-tier context (stream, pinned + device staging buffers)
+    pub fn fl_host_release();
     pub fn fl_status_string(status: i32) -> *const c_char;
     pub fn fl_last_hip_error() -> i32;
 }

@@ -13,8 +13,9 @@
 //     full 128-byte row (one L2 line) of their block;
 //   * row, word index, shift and mask are compile-time constants for every
 //     thread -- exactly the property the reference gets from its unrolled macro;
-//   * Delta's per-lane serial chain (delta.rs:56-61) is thread-local: no LDS, no
-//     cross-lane traffic;
+//   * Delta's per-lane serial chain (delta.rs:56-61) is thread-local: no cross-lane
+//     traffic (LDS is used wave-locally, only to shape global accesses: the row-store
+//     staging of fl_kernels.hpp and the run exchange of the transposes below);
 //   * u8/u16 lanes are processed SWAR inside 32-bit registers (masks are chosen
 //     so no bit ever crosses an element boundary).
 // A 64-lane wavefront therefore processes 8 blocks, a 256-thread workgroup 32.

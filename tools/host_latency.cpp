@@ -1,11 +1,14 @@
 // host_latency.cpp -- what one trait-method call costs through the HOST tier of the C ABI (no Python in the loop),
 // and what a large host-slice call sustains.  Run on the GPU box.
-//   g++ -O2 -std=c++17 -I include tools/host_latency.cpp -L fastlanes_amd -lfastlanes_amd -Wl,-rpath,'$ORIGIN/../fastlanes_amd' -o tools/host_latency
+//   g++ -O2 -std=c++17 -I include -I /opt/rocm/include tools/host_latency.cpp -L fastlanes_amd -lfastlanes_amd -L /opt/rocm/lib -lamdhip64 \
+//       -Wl,-rpath,'$ORIGIN/../fastlanes_amd' -Wl,-rpath,/opt/rocm/lib -o tools/host_latency
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
 #include "fastlanes_amd.h"
 
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -51,5 +54,25 @@ int main()
                     n * 4992 / 1e6, best * 1e6, n * 4992 / best / 1e9, n * 1024 / best / 1e9);
     }
     fl_host_release();
+    // DEVICE tier on small columns (launch-bound): data resident in HBM, one call per column
+    {
+        uint32_t *d_in = nullptr, *d_out = nullptr;
+        hipStream_t st;
+        if (hipMalloc((void**)&d_in, 4096 * 896) != hipSuccess || hipMalloc((void**)&d_out, 4096 * 4096) != hipSuccess ||
+            hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { std::printf("hipMalloc failed\n"); return 2; }
+        (void)hipMemset(d_in, 0x5a, 4096 * 896);
+        for (size_t n : {1ul, 64ul, 1024ul, 4096ul}) {
+            const double sync_us = per_call_us(3000, [&] { fl_u32_unpack(7, d_in, d_out, n, st); (void)hipStreamSynchronize(st); });
+            for (int i = 0; i < 50; ++i) fl_u32_unpack(7, d_in, d_out, n, st);
+            (void)hipStreamSynchronize(st);
+            const double t0 = now();
+            for (int i = 0; i < 5000; ++i) fl_u32_unpack(7, d_in, d_out, n, st);
+            (void)hipStreamSynchronize(st);
+            const double async_us = (now() - t0) / 5000 * 1e6;
+            std::printf("device tier unpack u32 W=7, %5zu blocks: launch + sync %6.1f us;  back-to-back async %6.2f us per call  (%7.1f Gint/s)\n",
+                        n, sync_us, async_us, n * 1024 / async_us / 1e3);
+        }
+        (void)hipFree(d_in); (void)hipFree(d_out); (void)hipStreamDestroy(st);
+    }
     return 0;
 }
