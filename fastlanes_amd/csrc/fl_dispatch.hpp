@@ -40,7 +40,7 @@ inline int wave_policy(unsigned type_bits, unsigned w, WaveOp op)
     if (op >= WAVE_UNDELTA_PACK) return chain_policy(type_bits, w, op);
     if (op == WAVE_UNPACK) {
         switch (type_bits) {
-        case 64: return w <= 1 ? 3 : w <= 14 ? 4 : w <= 48 ? 3 : 0;
+        case 64: return w <= 1 ? 3 : w <= 17 ? 4 : w <= 48 ? 3 : 0;   // W = 15..17: 3 and 4 waves trade places with the column size; 4 at 10 M blocks
         case 32: return w == 0 ? 3 : w <= 4 ? 8 : w <= 7 ? 0 : w <= 20 ? 4 : 0;
         case 16: return w == 0 ? 5 : w <= 5 ? 0 : w <= 10 ? 6 : 4;
         default: return w == 0 ? 6 : w <= 3 ? 0 : 8;
