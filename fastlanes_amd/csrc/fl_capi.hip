@@ -31,8 +31,8 @@ inline int chosen_waves(unsigned type_bits, unsigned w, fl::WaveOp op)
     if ((p & 0xff) == 1) return 0;
     const int waves = fl::wave_policy(type_bits, w, op);
     if ((p & 0xff) != 2) return waves;
-    if (p >> 8) return p >> 8;                       // A/B tools: policy 2 + 256 * waves forces the occupancy too
-    return waves ? waves : (op == fl::WAVE_PACK ? fl::WIDTHS_MIXED_PACK_WAVES : fl::WIDTHS_MIXED_UNPACK_WAVES);
+    if ((p >> 8) & 0xff) return (p >> 8) & 0xff;     // A/B tools: policy 2 + 256 * waves forces the occupancy too
+    return waves ? waves : fl::mixed_waves(type_bits, op == fl::WAVE_PACK);
 }
 
 
@@ -100,6 +100,7 @@ int run_wave_uniform(bool pack, int waves, unsigned w, const T* packed, T* unpac
     a.n_blocks = n_blocks;
     a.tiles_per_xcd = 0;
     a.uniform_width = w;
+    a.bpw = 1;
     hipError_t e = widths_launcher<T>(pack)(a, waves, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
@@ -406,7 +407,12 @@ int run_widths(bool pack, const uint8_t* widths, const uint64_t* offsets, const 
     a.n_blocks = n_blocks;
     a.tiles_per_xcd = 0;
     a.uniform_width = 0;
-    hipError_t e = widths_launcher<T>(pack)(a, pack ? WIDTHS_MIXED_PACK_WAVES : WIDTHS_MIXED_UNPACK_WAVES, static_cast<hipStream_t>(stream));
+    a.bpw = mixed_blocks_per_wave(Elem<T>::BITS);
+    int waves = mixed_waves(Elem<T>::BITS, pack);
+    const int pol = g_kernel_policy.load(std::memory_order_relaxed);       // A/B tools: 2 + 256*waves + 65536*blocks-per-wavefront
+    if ((pol & 0xff) == 2 && ((pol >> 8) & 0xff)) waves = (pol >> 8) & 0xff;
+    if ((pol & 0xff) == 2 && ((pol >> 16) & 0xff)) a.bpw = (pol >> 16) & 0xff;
+    hipError_t e = widths_launcher<T>(pack)(a, waves, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
 

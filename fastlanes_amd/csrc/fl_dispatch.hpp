@@ -54,4 +54,11 @@ inline int wave_policy(unsigned type_bits, unsigned w, WaveOp op)
     }
 }
 
+// MIXED-width columns (profiles/abmixed_r02e.txt: every type, seeded-random widths 1..T, blocks per wavefront x waves/SIMD).
+// A u8 block is only 1 KiB -- too little work to amortise a wavefront's start-up -- so a u8 wavefront walks 8 consecutive
+// blocks (unpack 4 625 -> 5 673 GB/s, pack 4 342 -> 5 461); for the wider types one block per wavefront stays best
+// (u16 6 171, u32 6 193, u64 6 556 GB/s).  The narrow types want every wave slot (8), u32 / u64 unpack 6.
+inline unsigned mixed_blocks_per_wave(unsigned type_bits) { return type_bits == 8 ? 8u : 1u; }
+inline int mixed_waves(unsigned type_bits, bool pack) { return (pack || type_bits <= 16) ? 8 : 6; }
+
 }  // namespace fl

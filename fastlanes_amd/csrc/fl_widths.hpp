@@ -37,6 +37,7 @@ struct WidthsArgs {
     uint64_t n_blocks;
     uint64_t tiles_per_xcd;
     unsigned uniform_width;
+    unsigned bpw;              // consecutive blocks per wavefront (>= 1); a workgroup takes 4*bpw blocks
 };
 
 template <typename T> struct WaveBlock {
@@ -151,19 +152,10 @@ template <typename T> __device__ __forceinline__ Cell<T> block_ref(const WidthsA
 // is BLOCK_BYTES of the DYNAMIC shared memory -- the launcher pads the request to steer occupancy (fewer,
 // or more, concurrent DRAM streams) without compiling per-occupancy variants.
 template <typename T>
-__global__ __launch_bounds__(WG) void k_unpack_widths(WidthsArgs a)
+__device__ __forceinline__ void unpack_block_wave(const WidthsArgs& a, uint64_t blk, char* lds, unsigned lane)
 {
     using G = WaveBlock<T>;
     constexpr int TB = G::TB;
-    extern __shared__ __attribute__((aligned(16))) char lds_all[];
-    const uint64_t n_tiles = (a.n_blocks + (WG / 64) - 1) / (WG / 64);
-    const uint64_t tile = (uint64_t)(blockIdx.x & 7u) * a.tiles_per_xcd + (blockIdx.x >> 3);
-    if (tile >= n_tiles) return;
-    const unsigned tid = threadIdx.x;
-    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
-    const uint64_t blk = tile * (WG / 64) + wave;
-    if (blk >= a.n_blocks) return;
-    char* lds = lds_all + wave * G::BLOCK_BYTES;
     unsigned w;
     uint64_t off;
     block_meta(a, blk, w, off);                               // wave-uniform
@@ -210,6 +202,35 @@ __global__ __launch_bounds__(WG) void k_unpack_widths(WidthsArgs a)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rs, out_base + decltype(K)::value * 1024u, 0, STORE_AUX);
         bit += step;
     });
+    wave_lds_fence();                                         // the image is reused by the wavefront's next block
+}
+
+// Wavefront -> blocks: workgroup `tile` (XCD-contiguous map) owns 4*bpw consecutive blocks, wavefront `wave` the bpw
+// consecutive ones starting at tile*4*bpw + wave*bpw.
+template <typename T, typename F>
+__device__ __forceinline__ void for_each_block_of_wave(const WidthsArgs& a, F&& f)
+{
+    using G = WaveBlock<T>;
+    extern __shared__ __attribute__((aligned(16))) char lds_all[];
+    const unsigned tile_blocks = a.bpw * (WG / 64);
+    const uint64_t n_tiles = (a.n_blocks + tile_blocks - 1) / tile_blocks;
+    const uint64_t tile = (uint64_t)(blockIdx.x & 7u) * a.tiles_per_xcd + (blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
+    const unsigned tid = threadIdx.x;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
+    char* lds = lds_all + wave * G::BLOCK_BYTES;
+    const uint64_t first = tile * tile_blocks + (uint64_t)wave * a.bpw;
+    for (unsigned j = 0; j < a.bpw; ++j) {
+        const uint64_t blk = first + j;
+        if (blk >= a.n_blocks) return;
+        f(blk, lds, lane);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(WG) void k_unpack_widths(WidthsArgs a)
+{
+    for_each_block_of_wave<T>(a, [&](uint64_t blk, char* lds, unsigned lane) { unpack_block_wave<T>(a, blk, lds, lane); });
 }
 
 // unchecked_pack over per-block widths (bitpacking.rs:76-96); with a.refs also FoR::for_pack's body
@@ -218,20 +239,11 @@ __global__ __launch_bounds__(WG) void k_unpack_widths(WidthsArgs a)
 // fields of rows floor(w*T/W) .. floor(((w+1)*T-1)/W) (macros.rs:72-92 regrouped by destination word instead of by
 // source row).
 template <typename T>
-__global__ __launch_bounds__(WG) void k_pack_widths(WidthsArgs a)
+__device__ __forceinline__ void pack_block_wave(const WidthsArgs& a, uint64_t blk, char* lds, unsigned lane)
 {
     using G = WaveBlock<T>;
     using word_t = typename G::word_t;
     constexpr int TB = G::TB;
-    extern __shared__ __attribute__((aligned(16))) char lds_all[];
-    const uint64_t n_tiles = (a.n_blocks + (WG / 64) - 1) / (WG / 64);
-    const uint64_t tile = (uint64_t)(blockIdx.x & 7u) * a.tiles_per_xcd + (blockIdx.x >> 3);
-    if (tile >= n_tiles) return;
-    const unsigned tid = threadIdx.x;
-    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
-    const uint64_t blk = tile * (WG / 64) + wave;
-    if (blk >= a.n_blocks) return;
-    char* lds = lds_all + wave * G::BLOCK_BYTES;
     unsigned w;
     uint64_t off;
     block_meta(a, blk, w, off);                               // wave-uniform
@@ -280,20 +292,25 @@ __global__ __launch_bounds__(WG) void k_pack_widths(WidthsArgs a)
         // rows past the block's 128*w bytes fall outside the descriptor and are dropped
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rs, wd * 128u + c16, 0, STORE_AUX);
     }
+    wave_lds_fence();                                         // the image is reused by the wavefront's next block
+}
+
+template <typename T>
+__global__ __launch_bounds__(WG) void k_pack_widths(WidthsArgs a)
+{
+    for_each_block_of_wave<T>(a, [&](uint64_t blk, char* lds, unsigned lane) { pack_block_wave<T>(a, blk, lds, lane); });
 }
 
 typedef hipError_t (*widths_launch_t)(const WidthsArgs&, int waves, hipStream_t);
 
 // Occupancy is steered at launch: the kernels use BLOCK_BYTES of dynamic LDS per wavefront, and the launcher
 // pads the request so that exactly `waves` wavefronts per SIMD (= workgroups per CU) fit the CU's 160 KiB.
-// Mixed-width columns (profiles/abmixed_r02a.txt, abmixed_r02b.txt; u32, 9 765 625 blocks, widths 1 + b mod 32 and
-// seeded-random): one block per wavefront at 5-6 waves/SIMD; more blocks per wavefront with a register prefetch of
-// the next block measured 1-5 % slower, the round-1 bucketed plan kernel 5-10 % slower; a bare 33:64 read:write
-// stream of the same bytes reaches 6.23-6.53 TB/s where this kernel reaches 6.37-6.66.
+// Mixed-width columns (profiles/abmixed_r02a.txt, abmixed_r02b.txt, abmixed_r02d.txt; u32, 9 765 625 blocks, widths
+// 1 + b mod 32 and seeded-random): one block per wavefront at 5-6 waves/SIMD; more blocks per wavefront with a register
+// prefetch of the next block measured 1-5 % slower, the round-1 bucketed plan kernel 5-10 % slower; a bare 33:64
+// read:write stream of the same bytes reaches 6.23-6.53 TB/s where this kernel reaches 6.37-6.66.  The shipped
+// occupancy / blocks-per-wavefront per type live in fl_dispatch.hpp (mixed_waves, mixed_blocks_per_wave).
 constexpr unsigned CU_LDS_BYTES = 160 * 1024;
-constexpr int WIDTHS_MIXED_UNPACK_WAVES = 6;   // 4-8 within 3 %, 3: -27 % (profiles/abuniform_r02b.txt tail, abmixed_r02d.txt)
-constexpr int WIDTHS_MIXED_PACK_WAVES = 8;     // 6: -2 %, 4-5: -20 %
-
 template <typename T> inline unsigned widths_lds_bytes(int waves)
 {
     const unsigned need = (WG / 64) * WaveBlock<T>::BLOCK_BYTES;
@@ -307,7 +324,9 @@ hipError_t launch_widths(const WidthsArgs& a0, int waves, hipStream_t s)
 {
     if (a0.n_blocks == 0) return hipSuccess;
     WidthsArgs a = a0;
-    const uint64_t n_tiles = (a.n_blocks + (WG / 64) - 1) / (WG / 64);
+    if (a.bpw == 0) a.bpw = 1;
+    const uint64_t tile_blocks = (uint64_t)a.bpw * (WG / 64);
+    const uint64_t n_tiles = (a.n_blocks + tile_blocks - 1) / tile_blocks;
     a.tiles_per_xcd = (n_tiles + 7) / 8;
     if (a.tiles_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;   // > 2^33 blocks in one launch
     const dim3 grid((unsigned)(a.tiles_per_xcd * 8));

@@ -89,7 +89,7 @@ void fl_host_release(void);
  * (fastlanes_amd/csrc/fl_dispatch.hpp).  For A/B measurements and for testing both designs on every
  * (T, W): policy 0 = automatic, 1 = cell-column only, 2 = wave-per-block wherever it exists
  * (pack, unpack, for_pack, unfor_pack, undelta_pack, delta, undelta); 2 + 256*n additionally runs those
- * kernels at n wavefronts per SIMD (A/B tools).  Process-wide; affects speed only. */
+ * kernels at n wavefronts per SIMD, + 65536*m the mixed-width kernels at m blocks per wavefront (A/B tools).  Process-wide; affects speed only. */
 void fl_set_kernel_policy(int policy);
 int fl_get_kernel_policy(void);
 

@@ -66,8 +66,8 @@ template <typename T> void run(unsigned W, int rounds)
     const uint64_t n = (16ull << 30) / bpb;
     const double bytes = (double)n * bpb;
     T* un = (T*)g_un; T* pk = (T*)g_pk; T* pk2 = (T*)g_pk2;
-    WidthsArgs up{g_pk, g_un2, nullptr, nullptr, nullptr, nullptr, 0, n, 0, W};
-    WidthsArgs pa{g_pk2, g_un, nullptr, nullptr, nullptr, nullptr, 0, n, 0, W};
+    WidthsArgs up{g_pk, g_un2, nullptr, nullptr, nullptr, nullptr, 0, n, 0, W, 1};
+    WidthsArgs pa{g_pk2, g_un, nullptr, nullptr, nullptr, nullptr, 0, n, 0, W, 1};
     // correctness on these very buffers (library forced onto its cell-column kernels: policy 1)
     fl_set_kernel_policy(1);
     Abi<T>::unpack(W, pk, un, n, nullptr);
