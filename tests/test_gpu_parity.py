@@ -1015,6 +1015,43 @@ def test_full_column_content_hash_vs_cpu_oracle(fl, oracle, ty, w, op):
         del vals, out, dev_pk
 
 
+def test_config5_full_column_content_hash_vs_cpu_oracle(fl, oracle):
+    """SURVEY.md 8(d) 'correctness at scale' (2) for BASELINE config 5: ALL 10 B integers of the mixed-width column
+    (u32, width[b] = 1 + b mod 32, 9 765 625 blocks), slice by slice of the 8-GPU sharding.  The GPU decodes a
+    device-generated stream with device-resident widths / offsets; the multithreaded CPU oracle runs the reference's
+    caller loop over the same stream regenerated on the host; two 64-bit content hashes per block must agree."""
+    import torch
+    from fastlanes_amd.sharding import block_range
+    n_total = 9_765_625
+    threads = min(64, os.cpu_count() or 1)
+    w_idx = torch.arange(1, 1025, dtype=torch.int64, device="cuda:0")
+    done = 0
+    for r in range(8):
+        first, n = block_range(n_total, 8, r)
+        widths = (1 + (np.arange(n, dtype=np.int64) + first) % 32).astype(np.uint8)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(widths.astype(np.uint64) * np.uint64(128), out=off[1:])
+        nwords = int(off[-1]) // 8
+        seed = 0xC5 + 131 * r
+        host_pk = np.empty(nwords * 2, dtype=np.uint32)
+        oracle.parallel_fill(host_pk, 8, nwords, seed, threads)
+        dev_pk = _splitmix_on_device(nwords, seed).view(torch.uint32)
+        if r == 0:
+            assert np.array_equal(to_np(dev_pk[:4096], "u32"), host_pk[:4096])
+        dw = torch.from_numpy(widths).cuda()
+        doff, dtotal = fl.widths_to_offsets("u32", dw)
+        assert int(dtotal.item()) == int(off[-1])
+        out = fl.unpack_widths(dw, doff, dev_pk)
+        host_out = oracle.fast_unpack_mixed_u32(widths, off[:-1], host_pk, nthreads=threads)
+        s_cpu, w_cpu = oracle.block_hashes("u32", host_out, threads)
+        vals = out.view(torch.int32).view(n, 1024).to(torch.int64) & 0xFFFFFFFF
+        assert np.array_equal(vals.sum(dim=1).cpu().numpy().view(np.uint64), s_cpu), r
+        assert np.array_equal((vals * w_idx).sum(dim=1).cpu().numpy().view(np.uint64), w_cpu), r
+        done += n
+        del vals, out, dev_pk, host_out
+    assert done == n_total
+
+
 def test_for_reference_stride_through_the_c_abi(fl, oracle):
     """fl_<ty>_for_pack / unfor_pack read references[b * reference_stride]: 0 broadcasts one scalar,
     1 is one per block, larger strides pick every k-th element (e.g. a struct-of-stats array)."""
