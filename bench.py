@@ -345,7 +345,7 @@ def pmc_child(args):
     torch.cuda.synchronize()
 
 
-def live_pmc_traffic(args):
+def live_pmc_traffic(args, workload=None):
     """HBM bytes per launch of the workload's kernel from rocprofv3 PMC counters, collected as
     MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC slots), with
     --kernel-trace only, in KiB units, and FETCH_SIZE corrected by the factor a copy of known size
@@ -361,8 +361,8 @@ def live_pmc_traffic(args):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = tempfile.mkdtemp(prefix="fl_pmc_", dir="/tmp")
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
-                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload,
-                   "--blocks", str(args.blocks)]
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", workload or args.workload,
+                   "--blocks", str(args.blocks if workload is None else 10_000_000)]
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
             subprocess.run(cmd, cwd="/tmp", env=dict(env, TMPDIR="/tmp"), timeout=180,
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
@@ -429,6 +429,17 @@ def config5_leg(args, world, rank, dev, dist_ctx):
     check = w.check_against_oracle() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     if rank != 0:
         return None
+    traffic = source = None
+    if world == 1 and not args.no_pmc:
+        del w.src, w.dst                     # the PMC child builds its own copy of the column
+        import torch
+        torch.cuda.empty_cache()
+        live = live_pmc_traffic(args, "u32_mixed_unpack")
+        if live is not None:
+            traffic = int(live["bytes"])
+            source = ("live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of this workload; "
+                      f"FETCH x{live['fetch_factor']}, WRITE x{live['write_factor']} from a {PMC_CAL_BYTES >> 30} GiB copy in the same "
+                      "passes; includes the 9 B/block of widths[] / offsets[]")
     ranks = [{"rank": r, "first_block": block_range(CONFIG5_BLOCKS, world, r)[0], "blocks": int(v[0]),
               "kernel_ms_avg": round(v[1], 4), "GBps": round(v[2] / (v[1] / 1e3) / 1e9, 1),
               "frac": round(v[2] / (v[1] / 1e3) / 1e9 / HBM_PEAK_GBPS, 4)} for r, v in enumerate(per_rank)]
@@ -444,7 +455,7 @@ def config5_leg(args, world, rank, dev, dist_ctx):
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "aggregate_GBps": round(sum(v[2] for v in per_rank) * args.steps / elapsed / 1e9, 1),
         "per_rank": ranks,
-        "roofline_rank0": roofline(w, kern_ms),
+        "roofline_rank0": roofline(w, kern_ms, traffic, source),
         "correctness": check,
     }
 
