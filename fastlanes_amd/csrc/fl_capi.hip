@@ -63,12 +63,18 @@ int run_stream(stream_launch_t fn, const T* in, T* out, const void* aux, size_t 
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
 
-// Delta chains on the wave-per-block kernels (fl_chain.hpp)
+// Delta's bodies and the transposes on the wave-per-block kernels (fl_chain.hpp).  Returns -1 when that form does not
+// exist for T (the original-order forms of u8 / u16): the caller then uses the cell-column kernel.
 template <typename T>
-int run_chain(int mode, int waves, unsigned w, const T* in, const T* bases, T* out, size_t n_blocks, void* stream)
+int run_chain(int op, int waves, unsigned w, const T* in, const T* bases, T* out, size_t n_blocks, void* stream)
 {
+    const fl::chain_launch_t fn = fl::chain_launcher<T>(op);
+    if (!fn) return -1;
     if (n_blocks == 0) return FL_OK;
-    if (!out || !bases || ((mode != fl::CHAIN_UNDELTA_PACK || w != 0) && !in)) return FL_ERR_NULL;
+    const bool packed_in = op == fl::OP_UNDELTA_PACK || op == fl::OP_UNDELTA_PACK_UNTRANSPOSE;
+    const bool packed_out = op == fl::OP_TRANSPOSE_DELTA_PACK;
+    const bool needs_bases = op != fl::OP_TRANSPOSE && op != fl::OP_UNTRANSPOSE;
+    if ((!out && !(packed_out && w == 0)) || (needs_bases && !bases) || (!(packed_in && w == 0) && !in)) return FL_ERR_NULL;
     if (misaligned(in) || misaligned(out) || misaligned(bases)) return FL_ERR_ALIGN;
     fl::ChainArgs a;
     a.in = reinterpret_cast<const char*>(in);
@@ -77,7 +83,7 @@ int run_chain(int mode, int waves, unsigned w, const T* in, const T* bases, T* o
     a.n_blocks = n_blocks;
     a.tiles_per_xcd = 0;
     a.width = w;
-    hipError_t e = fl::chain_launcher<T>(mode)(a, waves, static_cast<hipStream_t>(stream));
+    hipError_t e = fn(a, waves, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
 
@@ -147,7 +153,7 @@ int dev_undelta_pack(unsigned w, const T* in, const T* bases, T* out, size_t n, 
     if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
     if (n && misaligned(bases)) return FL_ERR_ALIGN;
     if (const int waves = chosen_waves(Elem<T>::BITS, w, WAVE_UNDELTA_PACK))
-        return run_chain<T>(CHAIN_UNDELTA_PACK, waves, w, in, bases, out, n, s);
+        return run_chain<T>(OP_UNDELTA_PACK, waves, w, in, bases, out, n, s);
     return run_stream<T>(unpack_table_impl<T, BODY_UNDELTA>().fn[w], in, out, bases, 0, n, w != 0, true, true, s);
 }
 template <typename T>
@@ -155,6 +161,10 @@ int dev_undelta_pack_untranspose(unsigned w, const T* in, const T* bases, T* out
 {
     if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
     if (n && misaligned(bases)) return FL_ERR_ALIGN;
+    if (const int waves = chosen_waves(Elem<T>::BITS, w, WAVE_UNDELTA_PACK_UNTRANSPOSE)) {
+        const int rc = run_chain<T>(OP_UNDELTA_PACK_UNTRANSPOSE, waves, w, in, bases, out, n, s);
+        if (rc >= 0) return rc;
+    }
     return run_stream<T>(unpack_table_impl<T, BODY_UNDELTA_UNTRANSPOSE>().fn[w], in, out, bases, 0, n, w != 0, true, true, s);
 }
 template <typename T>
@@ -162,6 +172,10 @@ int dev_transpose_delta_pack(unsigned w, const T* in, const T* bases, T* out, si
 {
     if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
     if (n && misaligned(bases)) return FL_ERR_ALIGN;
+    if (const int waves = chosen_waves(Elem<T>::BITS, w, WAVE_TRANSPOSE_DELTA_PACK)) {
+        const int rc = run_chain<T>(OP_TRANSPOSE_DELTA_PACK, waves, w, in, bases, out, n, s);
+        if (rc >= 0) return rc;
+    }
     return run_stream<T>(pack_table_impl<T, PACK_TRANSPOSE_DELTA>().fn[w], in, out, bases, 0, n, true, w != 0, true, s);
 }
 template <typename T>
@@ -222,11 +236,15 @@ template <typename T> int dev_delta(bool inverse, const T* in, const T* bases, T
 {
     if (n && misaligned(bases)) return FL_ERR_ALIGN;
     if (const int waves = chosen_waves(Elem<T>::BITS, Elem<T>::BITS, inverse ? WAVE_UNDELTA : WAVE_DELTA))
-        return run_chain<T>(inverse ? CHAIN_UNDELTA : CHAIN_DELTA, waves, Elem<T>::BITS, in, bases, out, n, s);
+        return run_chain<T>(inverse ? OP_UNDELTA : OP_DELTA, waves, Elem<T>::BITS, in, bases, out, n, s);
     return run_stream<T>(delta_launcher<T>(inverse), in, out, bases, 0, n, true, true, true, s);
 }
 template <typename T> int dev_transpose(bool inverse, const T* in, T* out, size_t n, void* s)
 {
+    if (const int waves = chosen_waves(Elem<T>::BITS, Elem<T>::BITS, inverse ? WAVE_UNTRANSPOSE : WAVE_TRANSPOSE)) {
+        const int rc = run_chain<T>(inverse ? OP_UNTRANSPOSE : OP_TRANSPOSE, waves, Elem<T>::BITS, in, static_cast<const T*>(nullptr), out, n, s);
+        if (rc >= 0) return rc;
+    }
     return run_stream<T>(transpose_launcher<T>(inverse), in, out, nullptr, 0, n, true, true, false, s);
 }
 template <typename T>

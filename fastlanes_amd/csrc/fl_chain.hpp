@@ -1,29 +1,75 @@
-// fl_chain.hpp -- Delta's stateful bodies on the wave-per-block mapping (fl_widths.hpp):
-//   CHAIN_UNDELTA_PACK  Delta::undelta_pack::<W>  (delta.rs:47-63)   packed W rows + base  -> T rows
-//   CHAIN_UNDELTA       Delta::undelta            (delta.rs:36-45)   T rows + base         -> T rows
-//   CHAIN_DELTA         Delta::delta              (delta.rs:24-33)   T rows + base         -> T rows
-// One wavefront per block, every global access 1 KiB contiguous.  The per-FL-lane chain over the T logical rows
-// (row order matters: macros.rs:119, delta.rs:56-61) is cut into 8 segments of R = T/8 CONSECUTIVE rows: lane
-// (i = lane/8, c = lane%8) owns rows R*i .. R*i+R-1 of cell column c.  It takes their values from the wave's LDS
-// image of the input (funnel-shifted out of the packed rows, or read at row_cell(r)), runs the chain locally, and
-// the 8 segments are stitched with a 3-step exclusive scan of the segment totals across lane groups (undelta) or by
-// reading the previous segment's last row (delta).  The results go back into the LDS image at their row_cell
-// positions and leave in address order.  LDS is wave-local: no s_barrier.
+// fl_chain.hpp -- Delta's stateful bodies and the transposes on the wave-per-block mapping (fl_widths.hpp).
+//
+// One kernel template, three stages, one wavefront per block, every global access 1 KiB contiguous:
+//
+//   SOURCE                       BODY                              SINK
+//   SRC_PACKED   W packed rows   BODY_NONE                         SNK_ROWS      unpacked, transposed (FastLanes) layout
+//   SRC_ROWS     unpacked block  BODY_UNDELTA  running sum + base  SNK_ORIGINAL  unpacked, ORIGINAL order (fused untranspose)
+//   SRC_ORIGINAL original order  BODY_DELTA    difference to prev  SNK_PACKED    W packed rows (fused pack)
+//
+//   Delta::undelta_pack::<W>  (delta.rs:47-63)    = PACKED   -> UNDELTA -> ROWS
+//   Delta::undelta            (delta.rs:36-45)    = ROWS     -> UNDELTA -> ROWS
+//   Delta::delta              (delta.rs:24-33)    = ROWS     -> DELTA   -> ROWS
+//   Transpose::untranspose    (transpose.rs:17-22)= ROWS     -> NONE    -> ORIGINAL        (u32 / u64)
+//   Transpose::transpose      (transpose.rs:11-15)= ORIGINAL -> NONE    -> ROWS            (u32 / u64)
+//   ext. undelta_pack_untranspose (delta.rs:96-100 composed)  = PACKED   -> UNDELTA -> ORIGINAL   (u32 / u64)
+//   ext. transpose_delta_pack     (delta.rs:88-95 composed)   = ORIGINAL -> DELTA   -> PACKED     (u32 / u64)
+//
+// Between the stages a lane holds R = T/8 CONSECUTIVE logical rows of one cell column: lane (i = lane/8, c = lane%8)
+// owns rows R*i .. R*i+R-1 of column c (16/sizeof(T) FL lanes).  The per-FL-lane chain over the T rows (row order
+// matters: macros.rs:119, delta.rs:56-61) is then a local running value plus a 3-step exclusive scan of the 8 segment
+// totals across lane groups (undelta), or the previous group's last row (delta).
+//
+// The transposes need no shuffle network either: along an FL lane's row order the original positions
+// are consecutive, tau(index(r, l)) = lane_base(l) + r.  For the 32- and 64-bit types a 16-byte cell holds n = 4 / 2
+// elements and the block decomposes into n x n ELEMENT TILES -- n cells (rows r..r+n-1 of lane group g) in the
+// transposed layout are n cells (lanes n*g..n*g+n-1, rows r..r+n-1) in the original one -- so a lane's R rows are R/n
+// tiles and the transposition is a REGISTER RENAMING (out[e].word[j] = in[j].word[e]); the original-order image lives in
+// LDS with a padded line stride chosen so that the 8 lanes of a group hit 8 distinct 16-byte bank slots.  (u8 / u16,
+// whose cells hold more elements than fit a square tile per lane, keep the cell-column kernels.)
+// LDS is wave-local: no s_barrier.
 #pragma once
 #include "fl_widths.hpp"
 
 namespace fl {
 
-enum ChainMode { CHAIN_UNDELTA_PACK = 0, CHAIN_UNDELTA = 1, CHAIN_DELTA = 2 };
+enum ChainSrc { SRC_PACKED = 0, SRC_ROWS = 1, SRC_ORIGINAL = 2 };
+enum ChainBody { CHAIN_NONE = 0, CHAIN_UNDELTA = 1, CHAIN_DELTA = 2 };
+enum ChainSnk { SNK_ROWS = 0, SNK_ORIGINAL = 1, SNK_PACKED = 2 };
 
 struct ChainArgs {
-    const char* in;          // packed column (UNDELTA_PACK) or unpacked column
-    char* out;               // unpacked column
-    const char* bases;       // [n_blocks][128 bytes]
+    const char* in;          // packed column / unpacked column (either layout)
+    char* out;               // unpacked column (either layout) / packed column
+    const char* bases;       // [n_blocks][128 bytes]; unused by CHAIN_NONE
     uint64_t n_blocks;
     uint64_t tiles_per_xcd;
-    unsigned width;          // UNDELTA_PACK only
+    unsigned width;          // SRC_PACKED / SNK_PACKED only
 };
+
+// LDS image of a block in ORIGINAL order: byte a of the block lives at pad(a).  u32: +16 bytes per 128-byte line and +32 per
+// KiB; u64: +16 per KiB.  With these strides the cells the 8 lanes of a group touch for one tile position (lanes n*c+e,
+// c = 0..7, same rows) fall into 8 distinct 16-byte slots of the 128-byte bank window.
+template <typename T> struct OriginalImage {
+    static_assert(sizeof(T) >= 4, "element tiles: 32- and 64-bit types");
+    static constexpr unsigned BLOCK_BYTES = WaveBlock<T>::BLOCK_BYTES;
+    __host__ __device__ static constexpr unsigned pad(unsigned a)
+    {
+        return sizeof(T) == 4 ? a + 16u * (a >> 7) + 32u * (a >> 10) : a + 16u * (a >> 10);
+    }
+    static constexpr unsigned BYTES = (pad(BLOCK_BYTES - 16u) + 16u + 255u) & ~255u;
+    // byte offset (unpadded) of the original-order cell holding rows [n*q, n*q+n) of FL lane l  (transpose.rs:29-36 inverted)
+    __device__ __forceinline__ static unsigned cell_of(unsigned l, unsigned q)
+    {
+        return (lane_base(l) * (unsigned)sizeof(T)) + 16u * q;
+    }
+};
+
+// bytes of LDS one wavefront needs for a (source, sink) pair
+template <typename T, int SRC, int SNK> constexpr unsigned chain_wave_lds()
+{
+    if constexpr (SRC == SRC_ORIGINAL || SNK == SNK_ORIGINAL) return OriginalImage<T>::BYTES;
+    else return WaveBlock<T>::BLOCK_BYTES;
+}
 
 // value of lane (lane - 8*d) for every 32-bit word of the cell; lanes of the first d groups get zero
 template <typename T> __device__ __forceinline__ Cell<T> cell_from_group_below(const Cell<T>& v, unsigned lane, unsigned d)
@@ -38,12 +84,22 @@ template <typename T> __device__ __forceinline__ Cell<T> cell_from_group_below(c
     return __builtin_bit_cast(Cell<T>, r);
 }
 
-template <typename T, int MODE>
+// n x n element tile: in[j] = cell of row j (n lanes), out[e] = cell of lane e (n rows)  -- and back (the map is an involution)
+template <typename T> __device__ __forceinline__ void tile_transpose(const Cell<T>* in, Cell<T>* out)
+{
+    constexpr int N = Cell<T>::NW;      // 4 dwords (u32) / 2 qwords (u64) = elements per cell for these types
+    for (int e = 0; e < N; ++e)
+        for (int j = 0; j < N; ++j) out[e].x[j] = in[j].x[e];
+}
+
+template <typename T, int SRC, int BODY, int SNK>
 __global__ __launch_bounds__(WG) void k_chain(ChainArgs a)
 {
     using G = WaveBlock<T>;
     constexpr int TB = G::TB;
     constexpr int R = TB / 8;                                  // consecutive logical rows per lane
+    constexpr int N = 16 / (int)sizeof(T);                     // elements per cell = tile edge
+    constexpr unsigned WAVE_LDS = chain_wave_lds<T, SRC, SNK>();
     extern __shared__ __attribute__((aligned(16))) char lds_all[];
     const uint64_t n_tiles = (a.n_blocks + (WG / 64) - 1) / (WG / 64);
     const uint64_t tile = (uint64_t)(blockIdx.x & 7u) * a.tiles_per_xcd + (blockIdx.x >> 3);
@@ -52,31 +108,38 @@ __global__ __launch_bounds__(WG) void k_chain(ChainArgs a)
     const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
     const uint64_t blk = tile * (WG / 64) + wave;
     if (blk >= a.n_blocks) return;
-    char* lds = lds_all + wave * G::BLOCK_BYTES;
-    const unsigned i = lane >> 3, c16 = (lane & 7u) * 16u;
-    const unsigned w = MODE == CHAIN_UNDELTA_PACK ? a.width : (unsigned)TB;
+    char* lds = lds_all + wave * WAVE_LDS;
+    const unsigned i = lane >> 3, c = lane & 7u, c16 = c * 16u;
+    const unsigned w = (SRC == SRC_PACKED || SNK == SNK_PACKED) ? a.width : (unsigned)TB;
+    const unsigned r0 = R * i;
 
-    // ---- input block -> LDS image (1 KiB-contiguous loads) ---------------------------------------------------
-    const unsigned in_bytes = MODE == CHAIN_UNDELTA_PACK ? 128u * w : G::BLOCK_BYTES;
+    // ---- source block -> LDS image (1 KiB-contiguous loads) ----------------------------------------------------
+    const unsigned in_bytes = SRC == SRC_PACKED ? 128u * w : G::BLOCK_BYTES;
     const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(a.in) + blk * (uint64_t)in_bytes, 0, in_bytes, 0x00020000);
+    const unsigned w_in = SRC == SRC_PACKED ? w : (unsigned)TB;
     u32x4 img[G::GROUPS];
     static_for<G::GROUPS>([&](auto Gi) {
         constexpr int g = decltype(Gi)::value;
-        if (8u * g < w) img[g] = __builtin_amdgcn_raw_buffer_load_b128(in_rs, lane * 16u + g * 1024u, 0, MODE == CHAIN_UNDELTA_PACK ? 0 : 2);
+        if (8u * g < w_in) img[g] = __builtin_amdgcn_raw_buffer_load_b128(in_rs, lane * 16u + g * 1024u, 0, SRC == SRC_PACKED ? 0 : 2);
     });
     // base[lane] of this cell column (delta.rs:26,38,56): one 16-byte cell per column, behind the data loads
-    const Cell<T> base = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(a.bases + blk * 128u + c16 + opaque_zero()));
+    Cell<T> base = Cell<T>::zero();
+    if constexpr (BODY != CHAIN_NONE)
+        base = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(a.bases + blk * 128u + c16 + opaque_zero()));
     static_for<G::GROUPS>([&](auto Gi) {
         constexpr int g = decltype(Gi)::value;
-        if (8u * g < w) *reinterpret_cast<u32x4*>(lds + lane * 16u + g * 1024u) = img[g];
+        if (8u * g < w_in) {
+            unsigned at = lane * 16u + g * 1024u;
+            if constexpr (SRC == SRC_ORIGINAL) at = OriginalImage<T>::pad(at);
+            *reinterpret_cast<u32x4*>(lds + at) = img[g];
+        }
     });
     wave_lds_fence();
 
-    // ---- this lane's R consecutive rows ----------------------------------------------------------------------
+    // ---- this lane's R consecutive rows of cell column c --------------------------------------------------------
     Cell<T> x[R];
-    const unsigned r0 = R * i;
-    if constexpr (MODE == CHAIN_UNDELTA_PACK) {
+    if constexpr (SRC == SRC_PACKED) {
         if (w == 0) {                                          // macros.rs:118-125: every elem is 0
             static_for<R>([&](auto J) { x[decltype(J)::value] = Cell<T>::zero(); });
         } else {
@@ -91,25 +154,37 @@ __global__ __launch_bounds__(WG) void k_chain(ChainArgs a)
                 x[decltype(J)::value] = G::funnel(cur, nxt, sh, m);
             });
         }
-    } else {
+    } else if constexpr (SRC == SRC_ROWS) {
         static_for<R>([&](auto J) {
             x[decltype(J)::value] = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(lds + G::row_cell_rt(r0 + decltype(J)::value) * 16u + c16));
         });
+    } else {
+        // original order: tile t of this lane = rows r0 + N*t .. + N-1 of lanes N*c .. N*c+N-1 (transpose.rs:12-14)
+        static_for<R / N>([&](auto Tt) {
+            constexpr int t = decltype(Tt)::value;
+            Cell<T> o[N];
+            static_for<N>([&](auto E) {
+                const unsigned at = OriginalImage<T>::cell_of(N * c + decltype(E)::value, (r0 / N) + t);
+                o[decltype(E)::value] = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(lds + OriginalImage<T>::pad(at)));
+            });
+            tile_transpose<T>(o, &x[N * t]);
+        });
     }
-    if constexpr (MODE == CHAIN_DELTA) {
-        // out[idx] = in[idx] - prev; prev = in[idx]  (delta.rs:28-30): the row before the segment is the previous
-        // lane group's last row (still in the LDS image), or base for the first segment
-        Cell<T> prev = base;
-        if (i != 0) prev = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(lds + G::row_cell_rt(r0 - 1u) * 16u + c16));
-        wave_lds_fence();                                      // every lane has read its neighbour's row before anyone overwrites
+
+    // ---- the body, in row order ----------------------------------------------------------------------------------
+    if constexpr (BODY == CHAIN_DELTA) {
+        // out[idx] = in[idx] - prev; prev = in[idx]  (delta.rs:28-30): the row before the segment is the previous lane
+        // group's last row, or base for the first segment
+        Cell<T> prev = cell_from_group_below<T>(x[R - 1], lane, 1);
+        if (i == 0) prev = base;
         static_for<R>([&](auto J) {
             const Cell<T> cur = x[decltype(J)::value];
             x[decltype(J)::value] = cur.sub(prev);
             prev = cur;
         });
-    } else {
-        // next = elem + prev; out[idx] = next; prev = next  (delta.rs:40-42,58-60): local running sum, then the
-        // exclusive scan of the segment totals over the 8 lane groups (Hillis-Steele, 3 steps), base entering at segment 0
+    } else if constexpr (BODY == CHAIN_UNDELTA) {
+        // next = elem + prev; out[idx] = next; prev = next  (delta.rs:40-42,58-60): local running sum, then the exclusive
+        // scan of the segment totals over the 8 lane groups (Hillis-Steele, 3 steps), base entering at segment 0
         if (i == 0) x[0] = x[0].add(base);
         static_for<R - 1>([&](auto J) { x[decltype(J)::value + 1] = x[decltype(J)::value + 1].add(x[decltype(J)::value]); });
         Cell<T> incl = x[R - 1];
@@ -119,24 +194,44 @@ __global__ __launch_bounds__(WG) void k_chain(ChainArgs a)
         });
         const Cell<T> excl = cell_from_group_below<T>(incl, lane, 1);
         static_for<R>([&](auto J) { x[decltype(J)::value] = x[decltype(J)::value].add(excl); });
-        if constexpr (MODE == CHAIN_UNDELTA_PACK) wave_lds_fence();   // the packed image is dead only once every lane has unpacked
     }
+    // the source image is dead once every lane has taken its rows (lanes re-use other lanes' cells below, except ROWS -> ROWS)
+    if constexpr (!(SRC == SRC_ROWS && SNK == SNK_ROWS)) wave_lds_fence();
 
-    // ---- results -> LDS image at their address-order cells -> 1 KiB-contiguous stores ------------------------
-    static_for<R>([&](auto J) {
-        *reinterpret_cast<u32x4*>(lds + G::row_cell_rt(r0 + decltype(J)::value) * 16u + c16) = __builtin_bit_cast(u32x4, x[decltype(J)::value]);
-    });
+    // ---- sink -------------------------------------------------------------------------------------------------------
+    if constexpr (SNK == SNK_ORIGINAL) {
+        static_for<R / N>([&](auto Tt) {
+            constexpr int t = decltype(Tt)::value;
+            Cell<T> o[N];
+            tile_transpose<T>(&x[N * t], o);                   // transpose.rs:19-21
+            static_for<N>([&](auto E) {
+                const unsigned at = OriginalImage<T>::cell_of(N * c + decltype(E)::value, (r0 / N) + t);
+                *reinterpret_cast<u32x4*>(lds + OriginalImage<T>::pad(at)) = __builtin_bit_cast(u32x4, o[decltype(E)::value]);
+            });
+        });
+    } else {
+        static_for<R>([&](auto J) {
+            *reinterpret_cast<u32x4*>(lds + G::row_cell_rt(r0 + decltype(J)::value) * 16u + c16) = __builtin_bit_cast(u32x4, x[decltype(J)::value]);
+        });
+    }
     wave_lds_fence();
-    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(a.out + blk * G::BLOCK_BYTES, 0, G::BLOCK_BYTES, 0x00020000);
-    static_for<G::GROUPS>([&](auto K) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(lds + lane * 16u + decltype(K)::value * 1024u);
-        __builtin_amdgcn_raw_buffer_store_b128(v, out_rs, lane * 16u + decltype(K)::value * 1024u, 0, STORE_AUX);
-    });
+    if constexpr (SNK == SNK_PACKED) {
+        if (w != 0) pack_from_lds_image<T>(lds, w, a.out + blk * (uint64_t)(128u * w), lane);   // macros.rs:52-53: W == 0 writes nothing
+    } else {
+        const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(a.out + blk * G::BLOCK_BYTES, 0, G::BLOCK_BYTES, 0x00020000);
+        static_for<G::GROUPS>([&](auto K) {
+            unsigned at = lane * 16u + decltype(K)::value * 1024u;
+            const unsigned to = at;
+            if constexpr (SNK == SNK_ORIGINAL) at = OriginalImage<T>::pad(at);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(lds + at);
+            __builtin_amdgcn_raw_buffer_store_b128(v, out_rs, to, 0, STORE_AUX);
+        });
+    }
 }
 
 typedef hipError_t (*chain_launch_t)(const ChainArgs&, int waves, hipStream_t);
 
-template <typename T, int MODE>
+template <typename T, int SRC, int BODY, int SNK>
 hipError_t launch_chain(const ChainArgs& a0, int waves, hipStream_t s)
 {
     if (a0.n_blocks == 0) return hipSuccess;
@@ -144,10 +239,17 @@ hipError_t launch_chain(const ChainArgs& a0, int waves, hipStream_t s)
     const uint64_t n_tiles = (a.n_blocks + (WG / 64) - 1) / (WG / 64);
     a.tiles_per_xcd = (n_tiles + 7) / 8;
     if (a.tiles_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_chain<T, MODE>), dim3((unsigned)(a.tiles_per_xcd * 8)), dim3(WG), widths_lds_bytes<T>(waves), s, a);
+    const unsigned need = (WG / 64) * chain_wave_lds<T, SRC, SNK>();
+    if (waves < 3) waves = 3;
+    const unsigned pad = (CU_LDS_BYTES / (unsigned)waves) & ~1023u;
+    hipLaunchKernelGGL((k_chain<T, SRC, BODY, SNK>), dim3((unsigned)(a.tiles_per_xcd * 8)), dim3(WG), pad > need ? pad : need, s, a);
     return hipGetLastError();
 }
 
-template <typename T> chain_launch_t chain_launcher(int mode);
+// what the C ABI asks for
+enum ChainOp { OP_UNDELTA_PACK = 0, OP_UNDELTA = 1, OP_DELTA = 2, OP_UNTRANSPOSE = 3, OP_TRANSPOSE = 4,
+               OP_UNDELTA_PACK_UNTRANSPOSE = 5, OP_TRANSPOSE_DELTA_PACK = 6 };
+// nullptr where the wave-per-block form does not exist (the original-order forms of u8 / u16)
+template <typename T> chain_launch_t chain_launcher(int op);
 
 }  // namespace fl

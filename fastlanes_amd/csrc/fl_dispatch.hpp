@@ -12,7 +12,8 @@
 
 namespace fl {
 
-enum WaveOp { WAVE_UNPACK = 0, WAVE_PACK = 1, WAVE_UNDELTA_PACK = 2, WAVE_UNDELTA = 3, WAVE_DELTA = 4 };
+enum WaveOp { WAVE_UNPACK = 0, WAVE_PACK = 1, WAVE_UNDELTA_PACK = 2, WAVE_UNDELTA = 3, WAVE_DELTA = 4,
+              WAVE_UNTRANSPOSE = 5, WAVE_TRANSPOSE = 6, WAVE_UNDELTA_PACK_UNTRANSPOSE = 7, WAVE_TRANSPOSE_DELTA_PACK = 8 };
 
 // profiles/abuniform_r02b.txt and abuniform_r02c.txt are two boxes' full sweeps (GB/s on the same buffers, every
 // (T, W), cell-column vs wave-per-block at 3/4/5/6/8 waves per SIMD; r02c packs full-entropy values).  The
@@ -26,6 +27,16 @@ enum WaveOp { WAVE_UNPACK = 0, WAVE_PACK = 1, WAVE_UNDELTA_PACK = 2, WAVE_UNDELT
 // of u32 / u64 at 3 waves/SIMD (+1-4 %), u8 delta (+5 %), and undelta_pack of u64 at mid widths (+3 %).
 inline int chain_policy(unsigned type_bits, unsigned w, WaveOp op)
 {
+    if (op >= WAVE_UNTRANSPOSE) {
+        // original-order forms, 32- and 64-bit types only (profiles/abchain_r02c.txt, abchain_r02d.txt): transpose /
+        // untranspose +5...10 % at 3 waves/SIMD; fused decode to original order +4...13 % from mid widths up; fused
+        // encode only at the wide end
+        if (type_bits < 32) return 0;
+        if (op == WAVE_TRANSPOSE || op == WAVE_UNTRANSPOSE) return 3;
+        if (op == WAVE_UNDELTA_PACK_UNTRANSPOSE)
+            return type_bits == 32 ? (w < 10 ? 0 : w <= 16 ? 6 : 4) : (w < 12 ? 0 : w < 32 ? 4 : 3);
+        return type_bits == 32 ? (w >= 24 ? 4 : 0) : (w >= 32 ? 4 : 0);
+    }
     if (op == WAVE_UNDELTA_PACK) return (type_bits == 64 && w >= 12 && w <= 48) ? (w >= 32 ? 3 : 4) : 0;
     switch (type_bits) {
     case 64: return 3;

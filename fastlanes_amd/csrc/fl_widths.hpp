@@ -233,40 +233,18 @@ __global__ __launch_bounds__(WG) void k_unpack_widths(WidthsArgs a)
     for_each_block_of_wave<T>(a, [&](uint64_t blk, char* lds, unsigned lane) { unpack_block_wave<T>(a, blk, lds, lane); });
 }
 
-// unchecked_pack over per-block widths (bitpacking.rs:76-96); with a.refs also FoR::for_pack's body
-// `input[idx] - reference` (ffor.rs:32-34).  The unpacked block is parked in the wave's LDS image; lane (i, c)
-// then assembles packed cells (w = i + 8m, c): word w of an FL lane's stream holds bits [w*T, (w+1)*T), i.e. the
-// fields of rows floor(w*T/W) .. floor(((w+1)*T-1)/W) (macros.rs:72-92 regrouped by destination word instead of by
-// source row).
+// The W packed rows of one block assembled from the wave's LDS image of the UNPACKED block (transposed layout, cell of
+// logical row r at row_cell(r)): lane (i, c) builds packed cells (w = i + 8m, c) -- word w of an FL lane's stream holds bits
+// [w*T, (w+1)*T), i.e. the fields of rows floor(w*T/W) .. floor(((w+1)*T-1)/W) (macros.rs:72-92 regrouped by destination
+// word instead of by source row) -- and stores them 1 KiB-contiguously.  Requires 1 <= w <= T.
 template <typename T>
-__device__ __forceinline__ void pack_block_wave(const WidthsArgs& a, uint64_t blk, char* lds, unsigned lane)
+__device__ __forceinline__ void pack_from_lds_image(const char* lds, unsigned w, char* packed_block, unsigned lane)
 {
     using G = WaveBlock<T>;
     using word_t = typename G::word_t;
     constexpr int TB = G::TB;
-    unsigned w;
-    uint64_t off;
-    block_meta(a, blk, w, off);                               // wave-uniform
-    if (w > (unsigned)TB) {                                   // bitpacking.rs:93 unreachable!()
-        if (a.err_flag && lane == 0) *a.err_flag = 1u;
-        return;
-    }
-    if (w == 0) return;                                       // macros.rs:52-53: W == 0 writes nothing
     const unsigned c16 = (lane & 7u) * 16u, i = lane >> 3;
-    const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(
-        a.unpacked + blk * G::BLOCK_BYTES, 0, G::BLOCK_BYTES, 0x00020000);
-    u32x4 un[G::GROUPS];
-    static_for<G::GROUPS>([&](auto K) {
-        un[decltype(K)::value] = __builtin_amdgcn_raw_buffer_load_b128(in_rs, decltype(K)::value * 1024u + lane * 16u, 0, 2 /* nt */);
-    });
-    const Cell<T> ref = a.refs ? block_ref<T>(a, blk) : Cell<T>::zero();   // behind the data loads
-    static_for<G::GROUPS>([&](auto K) {
-        Cell<T> v = __builtin_bit_cast(Cell<T>, un[decltype(K)::value]);
-        if (a.refs) v = v.sub(ref);                                         // ffor.rs:32-34 (before the mask of macros.rs:73)
-        *reinterpret_cast<u32x4*>(lds + lane * 16u + decltype(K)::value * 1024u) = __builtin_bit_cast(u32x4, v);
-    });
-    wave_lds_fence();
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.packed) + off, 0, 128u * w, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(packed_block, 0, 128u * w, 0x00020000);
     for (unsigned m8 = 0; m8 < w; m8 += 8) {                  // wave-uniform trip count: ceil(w/8) groups of 8 packed rows
         const unsigned wd = m8 + i;                           // this lane's packed word-row
         Cell<T> acc = Cell<T>::zero();
@@ -292,6 +270,40 @@ __device__ __forceinline__ void pack_block_wave(const WidthsArgs& a, uint64_t bl
         // rows past the block's 128*w bytes fall outside the descriptor and are dropped
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rs, wd * 128u + c16, 0, STORE_AUX);
     }
+}
+
+// unchecked_pack over per-block widths (bitpacking.rs:76-96); with a.refs also FoR::for_pack's body
+// `input[idx] - reference` (ffor.rs:32-34).  The unpacked block is parked in the wave's LDS image; lane (i, c)
+// then assembles packed cells (w = i + 8m, c): word w of an FL lane's stream holds bits [w*T, (w+1)*T), i.e. the
+// fields of rows floor(w*T/W) .. floor(((w+1)*T-1)/W) (macros.rs:72-92 regrouped by destination word instead of by
+// source row).
+template <typename T>
+__device__ __forceinline__ void pack_block_wave(const WidthsArgs& a, uint64_t blk, char* lds, unsigned lane)
+{
+    using G = WaveBlock<T>;
+    constexpr int TB = G::TB;
+    unsigned w;
+    uint64_t off;
+    block_meta(a, blk, w, off);                               // wave-uniform
+    if (w > (unsigned)TB) {                                   // bitpacking.rs:93 unreachable!()
+        if (a.err_flag && lane == 0) *a.err_flag = 1u;
+        return;
+    }
+    if (w == 0) return;                                       // macros.rs:52-53: W == 0 writes nothing
+    const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(
+        a.unpacked + blk * G::BLOCK_BYTES, 0, G::BLOCK_BYTES, 0x00020000);
+    u32x4 un[G::GROUPS];
+    static_for<G::GROUPS>([&](auto K) {
+        un[decltype(K)::value] = __builtin_amdgcn_raw_buffer_load_b128(in_rs, decltype(K)::value * 1024u + lane * 16u, 0, 2 /* nt */);
+    });
+    const Cell<T> ref = a.refs ? block_ref<T>(a, blk) : Cell<T>::zero();   // behind the data loads
+    static_for<G::GROUPS>([&](auto K) {
+        Cell<T> v = __builtin_bit_cast(Cell<T>, un[decltype(K)::value]);
+        if (a.refs) v = v.sub(ref);                                         // ffor.rs:32-34 (before the mask of macros.rs:73)
+        *reinterpret_cast<u32x4*>(lds + lane * 16u + decltype(K)::value * 1024u) = __builtin_bit_cast(u32x4, v);
+    });
+    wave_lds_fence();
+    pack_from_lds_image<T>(lds, w, const_cast<char*>(a.packed) + off, lane);
     wave_lds_fence();                                         // the image is reused by the wavefront's next block
 }
 

@@ -513,8 +513,10 @@ def test_config5_u32_mixed_widths_10B_integers(fl, oracle):
 # extensions: fused decode to / encode from the ORIGINAL order.
 # Defined as compositions of reference functions, so the oracle composition is the spec.
 # ---------------------------------------------------------------------------
+@pytest.mark.parametrize("policy", [0, 1, 2])
 @pytest.mark.parametrize("ty", TYS)
-def test_fused_transpose_extensions_vs_oracle_composition(fl, oracle, ty):
+def test_fused_transpose_extensions_vs_oracle_composition(fl, oracle, kernel_policy, ty, policy):
+    kernel_policy(policy)
     import torch
     T = tbits(ty)
     n = 37

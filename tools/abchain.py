@@ -29,17 +29,25 @@ for ty, W in cases:
     out = torch.empty(n * 1024, dtype=tdt, device=dev)
     bases = rand_u8(n * 128, 3, dev).view(tdt)
     ops = {"undelta_pack": (lambda: fl.Delta.undelta_pack(W, pk, bases, output=out), n * (128 * W + 128 + 128 * T))}
+    if T >= 32:
+        pk_out = torch.empty_like(pk)
+        ops["undelta_pack_untr"] = (lambda: fl.Delta.undelta_pack_untranspose(W, pk, bases, output=out), n * (128 * W + 128 + 128 * T))
+        ops["transp_delta_pack"] = (lambda: fl.Delta.transpose_delta_pack(W, un, bases, output=pk_out), n * (128 * W + 128 + 128 * T))
+    if ty not in seen_plain and T >= 32:
+        ops["transpose"] = (lambda: fl.Transpose.transpose(un, output=out), n * 256 * T)
+        ops["untranspose"] = (lambda: fl.Transpose.untranspose(un, output=out), n * 256 * T)
     if ty not in seen_plain:
         seen_plain.add(ty)
         ops["undelta"] = (lambda: fl.Delta.undelta(un, bases, output=out), n * (256 * T + 128))
         ops["delta"] = (lambda: fl.Delta.delta(un, bases, output=out), n * (256 * T + 128))
     for name, (f, nbytes) in ops.items():
+        res_t = pk_out if name == "transp_delta_pack" else out
         lib.fl_set_kernel_policy(1)
         f()
-        ref = out.clone()
+        ref = res_t.clone()
         lib.fl_set_kernel_policy(2)
         f()
-        same = torch.equal(ref.view(torch.uint8), out.view(torch.uint8))
+        same = torch.equal(ref.view(torch.uint8), res_t.view(torch.uint8))
         del ref
         res = {}
         pols = [1] + [2 + 256 * w for w in WAVES]
@@ -53,6 +61,6 @@ for ty, W in cases:
                 torch.cuda.synchronize()
                 res.setdefault(p, []).append(a.elapsed_time(b))
         g = [nbytes / sorted(res[p])[len(res[p]) // 2] / 1e6 for p in pols]
-        print(f"{ty:3s} W={W:<2d} {name:13s}{'' if same else ' MISMATCH'} | cc {g[0]:6.0f}  wpb " + " ".join(f"{x:6.0f}" for x in g[1:]), flush=True)
+        print(f"{ty:3s} W={W:<2d} {name:17s}{'' if same else ' MISMATCH'} | cc {g[0]:6.0f}  wpb " + " ".join(f"{x:6.0f}" for x in g[1:]), flush=True)
     lib.fl_set_kernel_policy(0)
     del pk, un, out, bases
