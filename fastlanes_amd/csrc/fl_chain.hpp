@@ -50,11 +50,11 @@ struct ChainArgs {
 // KiB; u64: +16 per KiB.  With these strides the cells the 8 lanes of a group touch for one tile position (lanes n*c+e,
 // c = 0..7, same rows) fall into 8 distinct 16-byte slots of the 128-byte bank window.
 template <typename T> struct OriginalImage {
-    static_assert(sizeof(T) >= 4, "element tiles: 32- and 64-bit types");
     static constexpr unsigned BLOCK_BYTES = WaveBlock<T>::BLOCK_BYTES;
+    // u8 / u16 gather single elements (below) and keep the image linear
     __host__ __device__ static constexpr unsigned pad(unsigned a)
     {
-        return sizeof(T) == 4 ? a + 16u * (a >> 7) + 32u * (a >> 10) : a + 16u * (a >> 10);
+        return sizeof(T) == 4 ? a + 16u * (a >> 7) + 32u * (a >> 10) : sizeof(T) == 8 ? a + 16u * (a >> 10) : a;
     }
     static constexpr unsigned BYTES = (pad(BLOCK_BYTES - 16u) + 16u + 255u) & ~255u;
     // byte offset (unpadded) of the original-order cell holding rows [n*q, n*q+n) of FL lane l  (transpose.rs:29-36 inverted)
@@ -63,6 +63,46 @@ template <typename T> struct OriginalImage {
         return (lane_base(l) * (unsigned)sizeof(T)) + 16u * q;
     }
 };
+
+// ---- u8 / u16: a cell holds more elements (16 / 8) than a lane has rows (1 / 2), so the element tiles span several lanes.
+// The transposition is done by the LDS itself: 16 single-element reads per lane per block, each element fetched from where
+// the OTHER layout keeps it, packed into the cell.
+//   original position p of the block  <->  (FL lane l, row r):  p = lane_base(l) + r  (transpose.rs:29-36; runs of T rows)
+template <typename T> __device__ __forceinline__ unsigned rows_image_byte_of_position(unsigned p)
+{
+    constexpr unsigned TB = sizeof(T) * 8;
+    const unsigned a = p >> 6, rem = p & 63u;                 // a = l % 16
+    const unsigned r = rem & (TB - 1u);                       // row inside the run
+    const unsigned f = (rem - r) >> 3;                        // = FL_ORDER[l / 16]
+    const unsigned l = a + 16u * ((0x73516240u >> (4u * f)) & 7u);   // FL_ORDER is its own inverse (lib.rs:53-59)
+    return WaveBlock<T>::row_cell_rt(r) * 16u + l * (unsigned)sizeof(T);
+}
+template <typename T> __device__ __forceinline__ Cell<T> pack_elements(const uint32_t* e)
+{
+    Cell<T> c;
+    if constexpr (sizeof(T) == 2) {
+        for (int k = 0; k < 4; ++k) c.x[k] = e[2 * k] | (e[2 * k + 1] << 16);
+    } else {
+        for (int k = 0; k < 4; ++k) c.x[k] = e[4 * k] | (e[4 * k + 1] << 8) | (e[4 * k + 2] << 16) | (e[4 * k + 3] << 24);
+    }
+    return c;
+}
+// cell `o` (16-byte units) of the ORIGINAL order, gathered from the LDS image of the transposed rows
+template <typename T> __device__ __forceinline__ Cell<T> gather_original_cell(const char* lds_rows, unsigned o)
+{
+    constexpr int N = 16 / (int)sizeof(T);
+    uint32_t e[N];
+    for (int k = 0; k < N; ++k) e[k] = *reinterpret_cast<const T*>(lds_rows + rows_image_byte_of_position<T>(N * o + k));
+    return pack_elements<T>(e);
+}
+// cell (logical row r, lane group c) of the TRANSPOSED rows, gathered from the linear LDS image of the original order
+template <typename T> __device__ __forceinline__ Cell<T> gather_row_cell(const char* lds_original, unsigned r, unsigned c)
+{
+    constexpr int N = 16 / (int)sizeof(T);
+    uint32_t e[N];
+    for (int k = 0; k < N; ++k) e[k] = *reinterpret_cast<const T*>(lds_original + (lane_base(N * c + k) + r) * (unsigned)sizeof(T));
+    return pack_elements<T>(e);
+}
 
 // bytes of LDS one wavefront needs for a (source, sink) pair
 template <typename T, int SRC, int SNK> constexpr unsigned chain_wave_lds()
@@ -158,6 +198,8 @@ __global__ __launch_bounds__(WG) void k_chain(ChainArgs a)
         static_for<R>([&](auto J) {
             x[decltype(J)::value] = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(lds + G::row_cell_rt(r0 + decltype(J)::value) * 16u + c16));
         });
+    } else if constexpr (sizeof(T) < 4) {
+        static_for<R>([&](auto J) { x[decltype(J)::value] = gather_row_cell<T>(lds, r0 + decltype(J)::value, c); });   // transpose.rs:12-14
     } else {
         // original order: tile t of this lane = rows r0 + N*t .. + N-1 of lanes N*c .. N*c+N-1 (transpose.rs:12-14)
         static_for<R / N>([&](auto Tt) {
@@ -199,7 +241,18 @@ __global__ __launch_bounds__(WG) void k_chain(ChainArgs a)
     if constexpr (!(SRC == SRC_ROWS && SNK == SNK_ROWS)) wave_lds_fence();
 
     // ---- sink -------------------------------------------------------------------------------------------------------
-    if constexpr (SNK == SNK_ORIGINAL) {
+    if constexpr (SNK == SNK_ORIGINAL && sizeof(T) < 4) {
+        static_for<R>([&](auto J) {
+            *reinterpret_cast<u32x4*>(lds + G::row_cell_rt(r0 + decltype(J)::value) * 16u + c16) = __builtin_bit_cast(u32x4, x[decltype(J)::value]);
+        });
+        wave_lds_fence();
+        const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(a.out + blk * G::BLOCK_BYTES, 0, G::BLOCK_BYTES, 0x00020000);
+        static_for<G::GROUPS>([&](auto K) {                    // transpose.rs:19-21, one original-order cell per lane per KiB
+            const Cell<T> v = gather_original_cell<T>(lds, lane + 64u * decltype(K)::value);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rs, lane * 16u + decltype(K)::value * 1024u, 0, STORE_AUX);
+        });
+        return;
+    } else if constexpr (SNK == SNK_ORIGINAL) {
         static_for<R / N>([&](auto Tt) {
             constexpr int t = decltype(Tt)::value;
             Cell<T> o[N];

@@ -55,18 +55,12 @@ template <> chain_launch_t chain_launcher<T>(int op)
     case OP_UNDELTA_PACK: return &launch_chain<T, SRC_PACKED, CHAIN_UNDELTA, SNK_ROWS>;
     case OP_UNDELTA: return &launch_chain<T, SRC_ROWS, CHAIN_UNDELTA, SNK_ROWS>;
     case OP_DELTA: return &launch_chain<T, SRC_ROWS, CHAIN_DELTA, SNK_ROWS>;
-    default: break;
+    case OP_UNTRANSPOSE: return &launch_chain<T, SRC_ROWS, CHAIN_NONE, SNK_ORIGINAL>;
+    case OP_TRANSPOSE: return &launch_chain<T, SRC_ORIGINAL, CHAIN_NONE, SNK_ROWS>;
+    case OP_UNDELTA_PACK_UNTRANSPOSE: return &launch_chain<T, SRC_PACKED, CHAIN_UNDELTA, SNK_ORIGINAL>;
+    case OP_TRANSPOSE_DELTA_PACK: return &launch_chain<T, SRC_ORIGINAL, CHAIN_DELTA, SNK_PACKED>;
+    default: return nullptr;
     }
-    if constexpr (sizeof(T) >= 4) {
-        switch (op) {
-        case OP_UNTRANSPOSE: return &launch_chain<T, SRC_ROWS, CHAIN_NONE, SNK_ORIGINAL>;
-        case OP_TRANSPOSE: return &launch_chain<T, SRC_ORIGINAL, CHAIN_NONE, SNK_ROWS>;
-        case OP_UNDELTA_PACK_UNTRANSPOSE: return &launch_chain<T, SRC_PACKED, CHAIN_UNDELTA, SNK_ORIGINAL>;
-        case OP_TRANSPOSE_DELTA_PACK: return &launch_chain<T, SRC_ORIGINAL, CHAIN_DELTA, SNK_PACKED>;
-        default: break;
-        }
-    }
-    return nullptr;
 }
 #elif FL_FAMILY == 8
 static constexpr WidthTable<T> t_undelta_untr = make_unpack_table<T, BODY_UNDELTA_UNTRANSPOSE>(Ws{});

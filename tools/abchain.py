@@ -29,11 +29,11 @@ for ty, W in cases:
     out = torch.empty(n * 1024, dtype=tdt, device=dev)
     bases = rand_u8(n * 128, 3, dev).view(tdt)
     ops = {"undelta_pack": (lambda: fl.Delta.undelta_pack(W, pk, bases, output=out), n * (128 * W + 128 + 128 * T))}
-    if T >= 32:
+    if True:
         pk_out = torch.empty_like(pk)
         ops["undelta_pack_untr"] = (lambda: fl.Delta.undelta_pack_untranspose(W, pk, bases, output=out), n * (128 * W + 128 + 128 * T))
         ops["transp_delta_pack"] = (lambda: fl.Delta.transpose_delta_pack(W, un, bases, output=pk_out), n * (128 * W + 128 + 128 * T))
-    if ty not in seen_plain and T >= 32:
+    if ty not in seen_plain:
         ops["transpose"] = (lambda: fl.Transpose.transpose(un, output=out), n * 256 * T)
         ops["untranspose"] = (lambda: fl.Transpose.untranspose(un, output=out), n * 256 * T)
     if ty not in seen_plain:
