@@ -63,8 +63,8 @@ int run_stream(stream_launch_t fn, const T* in, T* out, const void* aux, size_t 
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
 
-// Delta's bodies and the transposes on the wave-per-block kernels (fl_chain.hpp).  Returns -1 when that form does not
-// exist for T (the original-order forms of u8 / u16): the caller then uses the cell-column kernel.
+// Delta's bodies and the transposes on the wave-per-block pipeline kernel (fl_chain.hpp).  Returns -1 when no such form
+// exists for the op: the caller then uses the cell-column kernel.
 template <typename T>
 int run_chain(int op, int waves, unsigned w, const T* in, const T* bases, T* out, size_t n_blocks, void* stream)
 {

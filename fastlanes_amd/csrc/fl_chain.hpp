@@ -10,10 +10,10 @@
 //   Delta::undelta_pack::<W>  (delta.rs:47-63)    = PACKED   -> UNDELTA -> ROWS
 //   Delta::undelta            (delta.rs:36-45)    = ROWS     -> UNDELTA -> ROWS
 //   Delta::delta              (delta.rs:24-33)    = ROWS     -> DELTA   -> ROWS
-//   Transpose::untranspose    (transpose.rs:17-22)= ROWS     -> NONE    -> ORIGINAL        (u32 / u64)
-//   Transpose::transpose      (transpose.rs:11-15)= ORIGINAL -> NONE    -> ROWS            (u32 / u64)
-//   ext. undelta_pack_untranspose (delta.rs:96-100 composed)  = PACKED   -> UNDELTA -> ORIGINAL   (u32 / u64)
-//   ext. transpose_delta_pack     (delta.rs:88-95 composed)   = ORIGINAL -> DELTA   -> PACKED     (u32 / u64)
+//   Transpose::untranspose    (transpose.rs:17-22)= ROWS     -> NONE    -> ORIGINAL
+//   Transpose::transpose      (transpose.rs:11-15)= ORIGINAL -> NONE    -> ROWS
+//   ext. undelta_pack_untranspose (delta.rs:96-100 composed)  = PACKED   -> UNDELTA -> ORIGINAL
+//   ext. transpose_delta_pack     (delta.rs:88-95 composed)   = ORIGINAL -> DELTA   -> PACKED
 //
 // Between the stages a lane holds R = T/8 CONSECUTIVE logical rows of one cell column: lane (i = lane/8, c = lane%8)
 // owns rows R*i .. R*i+R-1 of column c (16/sizeof(T) FL lanes).  The per-FL-lane chain over the T rows (row order
@@ -25,8 +25,9 @@
 // elements and the block decomposes into n x n ELEMENT TILES -- n cells (rows r..r+n-1 of lane group g) in the
 // transposed layout are n cells (lanes n*g..n*g+n-1, rows r..r+n-1) in the original one -- so a lane's R rows are R/n
 // tiles and the transposition is a REGISTER RENAMING (out[e].word[j] = in[j].word[e]); the original-order image lives in
-// LDS with a padded line stride chosen so that the 8 lanes of a group hit 8 distinct 16-byte bank slots.  (u8 / u16,
-// whose cells hold more elements than fit a square tile per lane, keep the cell-column kernels.)
+// LDS with a padded line stride chosen so that the 8 lanes of a group hit 8 distinct 16-byte bank slots.  For u8 / u16 a
+// cell holds more elements (16 / 8) than a lane has rows, so the tiles span lanes: there the LDS does the transposition,
+// 16 single-element reads per lane per block (gather_original_cell / gather_row_cell).
 // LDS is wave-local: no s_barrier.
 #pragma once
 #include "fl_widths.hpp"
@@ -302,7 +303,6 @@ hipError_t launch_chain(const ChainArgs& a0, int waves, hipStream_t s)
 // what the C ABI asks for
 enum ChainOp { OP_UNDELTA_PACK = 0, OP_UNDELTA = 1, OP_DELTA = 2, OP_UNTRANSPOSE = 3, OP_TRANSPOSE = 4,
                OP_UNDELTA_PACK_UNTRANSPOSE = 5, OP_TRANSPOSE_DELTA_PACK = 6 };
-// nullptr where the wave-per-block form does not exist (the original-order forms of u8 / u16)
 template <typename T> chain_launch_t chain_launcher(int op);
 
 }  // namespace fl
