@@ -762,9 +762,11 @@ def test_no_write_past_the_end_of_the_column(fl, ty):
         plan.close()
 
 
-def test_random_shapes_fuzz(fl, oracle):
-    """Seeded fuzz over (type, width, op, block count): tail handling of tiles / wavefronts."""
-    rng = np.random.default_rng(int(os.environ.get("FL_FUZZ_SEED", "2024")))
+@pytest.mark.parametrize("policy", [0, 1, 2])
+def test_random_shapes_fuzz(fl, oracle, kernel_policy, policy):
+    """Seeded fuzz over (type, width, op, block count): tail handling of tiles / wavefronts, under the automatic kernel
+    choice and with each kernel design forced (policy 2 also draws a random occupancy)."""
+    rng = np.random.default_rng(int(os.environ.get("FL_FUZZ_SEED", "2024")) + policy)
     ops = ["pack", "unpack", "for_pack", "unfor_pack", "undelta_pack", "delta", "undelta", "transpose", "untranspose"]
     for _ in range(int(os.environ.get("FL_FUZZ_ITERS", "60"))):
         ty = TYS[rng.integers(0, 4)]
@@ -773,6 +775,7 @@ def test_random_shapes_fuzz(fl, oracle):
         n = int(rng.choice([1, 2, 7, 8, 9, 31, 32, 33, 63, 64, 65, 255, 256, 257, 300, 511, 777]))
         op = ops[rng.integers(0, len(ops))]
         seed = int(rng.integers(0, 1 << 30))
+        kernel_policy(policy if policy != 2 else 2 + 256 * int(rng.choice([0, 3, 4, 5, 6, 8])))
         v = values(ty, n * 1024, seed)
         pk = values(ty, n * packed_len(ty, w), seed + 1)
         refs = values(ty, n, seed + 2)
