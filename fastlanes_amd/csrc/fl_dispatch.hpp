@@ -60,8 +60,8 @@ inline int wave_policy(unsigned type_bits, unsigned w, WaveOp op)
     }
     switch (type_bits) {
     case 64: return w <= 7 ? 0 : (w % 32 == 0) ? 3 : 4;
-    case 32: return w <= 4 ? 0 : w <= 7 ? 6 : 4;
-    case 16: return w <= 3 ? 0 : w <= 6 ? 8 : w <= 15 ? 6 : 4;
+    case 32: return w == 0 ? 0 : w <= 2 ? 6 : 4;      // narrow widths: chunks merged with LDS atomic ORs (profiles/abuniform_r02e.txt)
+    case 16: return w <= 3 ? 0 : w <= 15 ? 6 : 4;
     default: return w >= 7 ? 8 : 0;
     }
 }

@@ -237,12 +237,76 @@ __global__ __launch_bounds__(WG) void k_unpack_widths(WidthsArgs a)
 // logical row r at row_cell(r)): lane (i, c) builds packed cells (w = i + 8m, c) -- word w of an FL lane's stream holds bits
 // [w*T, (w+1)*T), i.e. the fields of rows floor(w*T/W) .. floor(((w+1)*T-1)/W) (macros.rs:72-92 regrouped by destination
 // word instead of by source row) -- and stores them 1 KiB-contiguously.  Requires 1 <= w <= T.
+//
+// Narrow widths (w < 8) would leave most lanes idle that way (w = 1: one packed row, 8 of 64 lanes, 32 rows each).  They
+// take the other route: lane (i, c) owns the R = T/8 CONSECUTIVE rows R*i .. R*i+R-1 of column c, whose fields are one
+// contiguous chunk of R*w <= T bits of every FL lane's stream, starting at bit R*i*w: the lane splices its chunk together,
+// and the chunks of the lanes that share a packed word are merged with LDS atomic ORs (ds_or_b32) into a zeroed image of the
+// packed block (re-using the first KiB of the unpacked image, which is dead once every lane holds its rows).
 template <typename T>
-__device__ __forceinline__ void pack_from_lds_image(const char* lds, unsigned w, char* packed_block, unsigned lane)
+__device__ __forceinline__ void pack_narrow_from_lds_image(char* lds, unsigned w, char* packed_block, unsigned lane)
 {
     using G = WaveBlock<T>;
     using word_t = typename G::word_t;
     constexpr int TB = G::TB;
+    constexpr int R = TB / 8;
+    constexpr int NW = Cell<T>::NW;
+    const unsigned c16 = (lane & 7u) * 16u, i = lane >> 3;
+    // chunk = field(row R*i) | field(row R*i+1) << w | ...   (macros.rs:73,79 for R consecutive rows)
+    const word_t mw = G::rep_mask(w);
+    word_t chunk[NW];
+    for (int x = 0; x < NW; ++x) chunk[x] = 0;
+    static_for<R>([&](auto J) {
+        const Cell<T> s = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(lds + G::row_cell_rt(R * i + decltype(J)::value) * 16u + c16));
+        for (int x = 0; x < NW; ++x) chunk[x] |= (s.x[x] & mw) << (decltype(J)::value * w);
+    });
+    wave_lds_fence();                                         // every lane holds its rows: the image may be overwritten
+    *reinterpret_cast<u32x4*>(lds + lane * 16u) = u32x4{0, 0, 0, 0};
+    wave_lds_fence();
+    // the chunk starts at stream bit R*i*w = word (i*w)/8, bit ((i*w)%8)*R, and may run into the next word (macros.rs:84-92)
+    const unsigned wl = (i * w) >> 3, sb = ((i * w) & 7u) * R;
+    const unsigned room = TB - sb;                            // bits of word wl at and above sb
+    const unsigned len = R * w;
+    uint32_t* lo_at = reinterpret_cast<uint32_t*>(lds + wl * 128u + c16);
+    const word_t mlo = G::rep_mask(len < room ? len : room);
+    for (int x = 0; x < NW; ++x) {
+        const word_t v = (chunk[x] & mlo) << sb;
+        if constexpr (sizeof(word_t) == 8) {
+            __hip_atomic_fetch_or(lo_at + 2 * x, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_or(lo_at + 2 * x + 1, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        } else {
+            __hip_atomic_fetch_or(lo_at + x, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+    }
+    if (len > room) {                                         // carry into word wl + 1 (sb > 0 here)
+        const word_t mhi = G::rep_mask(len - room);
+        uint32_t* hi_at = lo_at + 32;                         // next packed row: +128 bytes
+        for (int x = 0; x < NW; ++x) {
+            const word_t v = (chunk[x] >> room) & mhi;
+            if constexpr (sizeof(word_t) == 8) {
+                __hip_atomic_fetch_or(hi_at + 2 * x, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_or(hi_at + 2 * x + 1, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            } else {
+                __hip_atomic_fetch_or(hi_at + x, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        }
+    }
+    wave_lds_fence();
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(packed_block, 0, 128u * w, 0x00020000);
+    const u32x4 out = *reinterpret_cast<const u32x4*>(lds + lane * 16u);
+    __builtin_amdgcn_raw_buffer_store_b128(out, rs, lane * 16u, 0, STORE_AUX);   // cells past 128*w bytes are dropped by the descriptor
+}
+
+template <typename T>
+__device__ __forceinline__ void pack_from_lds_image(char* lds, unsigned w, char* packed_block, unsigned lane)
+{
+    using G = WaveBlock<T>;
+    using word_t = typename G::word_t;
+    constexpr int TB = G::TB;
+    if (w < 8u) {                                             // wave-uniform
+        pack_narrow_from_lds_image<T>(lds, w, packed_block, lane);
+        return;
+    }
     const unsigned c16 = (lane & 7u) * 16u, i = lane >> 3;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(packed_block, 0, 128u * w, 0x00020000);
     for (unsigned m8 = 0; m8 < w; m8 += 8) {                  // wave-uniform trip count: ceil(w/8) groups of 8 packed rows
