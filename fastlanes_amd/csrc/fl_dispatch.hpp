@@ -30,13 +30,15 @@ inline int chain_policy(unsigned type_bits, unsigned w, WaveOp op)
     if (op >= WAVE_UNTRANSPOSE) {
         // original-order forms (profiles/abchain_r02c.txt, abchain_r02d.txt, abchain_r02e.txt): transpose / untranspose
         // +5...10 % for every type (u64 / u32 at 3 waves/SIMD, u16 at 4, u8 at 8); fused decode to original order
-        // +4...13 % from mid widths up for u32 / u64; fused encode only at the wide end; the narrow types' fused forms
-        // stay on the cell-column kernels
+        // +4...13 % from mid widths up for u32 / u64; the narrow types' fused decode stays on the cell-column kernels
         if (op == WAVE_TRANSPOSE || op == WAVE_UNTRANSPOSE) return type_bits >= 32 ? 3 : type_bits == 16 ? 4 : 8;
-        if (type_bits < 32) return 0;
-        if (op == WAVE_UNDELTA_PACK_UNTRANSPOSE)
+        if (op == WAVE_UNDELTA_PACK_UNTRANSPOSE) {
+            if (type_bits < 32) return 0;
             return type_bits == 32 ? (w < 10 ? 0 : w <= 16 ? 6 : 4) : (w < 12 ? 0 : w < 32 ? 4 : 3);
-        return type_bits == 32 ? (w >= 24 ? 4 : 0) : (w >= 32 ? 4 : 0);
+        }
+        // fused encode (with the atomic-OR narrow pack: u32 W=3 +11 %, u64 W=60 +18 %, mid widths +2...4 %)
+        if (w == 0) return 0;
+        return type_bits == 64 ? 4 : type_bits == 32 ? (w <= 16 ? 6 : 4) : type_bits == 16 ? (w >= 12 ? 6 : 0) : 0;
     }
     if (op == WAVE_UNDELTA_PACK) return (type_bits == 64 && w >= 12 && w <= 48) ? (w >= 32 ? 3 : 4) : 0;
     switch (type_bits) {
