@@ -112,8 +112,6 @@ __device__ __forceinline__ unsigned opaque_zero()
     return z;
 }
 
-// widths[blk] and offsets[blk] of the wavefront's block: two independent vector loads in flight together, one
-// wait, then broadcast to SGPRs (wave-uniform) -- instead of a byte load, a wait, a dependent scalar load, a wait.
 __device__ __forceinline__ uint64_t wave_uniform_u64(uint64_t v)
 {
     // readfirstlane returns int: widen through uint32_t or a low word with bit 31 set sign-extends into the high one
@@ -122,6 +120,8 @@ __device__ __forceinline__ uint64_t wave_uniform_u64(uint64_t v)
     return ((uint64_t)hi << 32) | lo;
 }
 
+// widths[blk] and offsets[blk] of the wavefront's block: two independent vector loads in flight together, one
+// wait, then broadcast to SGPRs (wave-uniform) -- instead of a byte load, a wait, a dependent scalar load, a wait.
 __device__ __forceinline__ void block_meta(const WidthsArgs& a, uint64_t blk, unsigned& w, uint64_t& off)
 {
     w = a.uniform_width;
@@ -148,9 +148,9 @@ template <typename T> __device__ __forceinline__ Cell<T> block_ref(const WidthsA
 }
 
 // unchecked_unpack over per-block widths (bitpacking.rs:109-129); with a.refs also FoR::unfor_pack's body
-// `out[idx] = elem + reference` (ffor.rs:46-48).  One block per wavefront, 4 per workgroup; the wave's LDS image
-// is BLOCK_BYTES of the DYNAMIC shared memory -- the launcher pads the request to steer occupancy (fewer,
-// or more, concurrent DRAM streams) without compiling per-occupancy variants.
+// `out[idx] = elem + reference` (ffor.rs:46-48).  One block at a time per wavefront (a.bpw consecutive ones, 1 except
+// for u8 mixed-width columns); the wave's LDS image is BLOCK_BYTES of the DYNAMIC shared memory -- the launcher pads the
+// request to steer occupancy (fewer, or more, concurrent DRAM streams) without compiling per-occupancy variants.
 template <typename T>
 __device__ __forceinline__ void unpack_block_wave(const WidthsArgs& a, uint64_t blk, char* lds, unsigned lane)
 {
