@@ -57,8 +57,11 @@ declare_type!(u64, fl_u64_pack_host, fl_u64_unpack_host, fl_u64_unpack_single_ho
 // Mixed-width columns: the caller loop `for b { T::unchecked_unpack(widths[b], &packed[off[b]..], ..) }`
 // (bitpacking.rs:109-129) with widths[] (u8) and offsets[] (u64 byte offsets) resident in HBM.
 macro_rules! declare_widths {
-    ($T:ty, $unpack_widths:ident, $pack_widths:ident) => {
+    ($T:ty, $unpack_widths:ident, $pack_widths:ident, $unpack_single_widths:ident) => {
         extern "C" {
+            pub fn $unpack_single_widths(d_widths: *const u8, d_offsets: *const u64, d_packed: *const $T, n_blocks: usize,
+                                         d_indices: *const u64, n_indices: usize, d_out: *mut $T, d_err_flag: *mut u32,
+                                         stream: *mut c_void) -> i32;
             pub fn $unpack_widths(d_widths: *const u8, d_offsets: *const u64, d_packed: *const $T, d_out: *mut $T,
                                   n_blocks: usize, d_err_flag: *mut u32, stream: *mut c_void) -> i32;
             pub fn $pack_widths(d_widths: *const u8, d_offsets: *const u64, d_in: *const $T, d_packed: *mut $T,
@@ -66,10 +69,10 @@ macro_rules! declare_widths {
         }
     };
 }
-declare_widths!(u8, fl_u8_unpack_widths, fl_u8_pack_widths);
-declare_widths!(u16, fl_u16_unpack_widths, fl_u16_pack_widths);
-declare_widths!(u32, fl_u32_unpack_widths, fl_u32_pack_widths);
-declare_widths!(u64, fl_u64_unpack_widths, fl_u64_pack_widths);
+declare_widths!(u8, fl_u8_unpack_widths, fl_u8_pack_widths, fl_u8_unpack_single_widths);
+declare_widths!(u16, fl_u16_unpack_widths, fl_u16_pack_widths, fl_u16_unpack_single_widths);
+declare_widths!(u32, fl_u32_unpack_widths, fl_u32_pack_widths, fl_u32_unpack_single_widths);
+declare_widths!(u64, fl_u64_unpack_widths, fl_u64_pack_widths, fl_u64_unpack_single_widths);
 
 extern "C" {
     /// offsets[b] = sum_{i<b} 128 * widths[i] on the device (three small launches, no scratch memory)

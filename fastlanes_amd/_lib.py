@@ -42,6 +42,7 @@ def _signatures(ty):
         "pack_mixed": [_P, _P, _P, _P],
         "unpack_widths": [_P, _P, _P, _P, _Z, _P, _P],
         "pack_widths": [_P, _P, _P, _P, _Z, _P, _P],
+        "unpack_single_widths": [_P, _P, _P, _Z, _P, _Z, _P, _P, _P],
     }
     host = {
         "pack_host": [_U, _P, _P, _Z],

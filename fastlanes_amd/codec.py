@@ -501,6 +501,34 @@ def pack_widths(widths, offsets, input, output, check=True):
     return out.x
 
 
+def unpack_single_widths(widths, offsets, packed, index):
+    """`T::unchecked_unpack_single(widths[b], &packed[offsets[b]..], i)` (bitpacking.rs:58,181-200) batched over a mixed-width
+    column: `index` is a CUDA int64/uint64 tensor of column-global element indices (block*1024 + i); returns the values.
+    An index past the column raises like the reference's assert (bitpacking.rs:152), a width > T like its unreachable!()."""
+    import torch
+    src = _Arg(packed)
+    ty = src.ty
+    w = _Arg(widths, "u8")
+    o = _Arg(offsets, "u64")
+    _same_tier(src, w, o)
+    if not src.torch:
+        raise TypeError("unpack_single_widths is device tier: pass CUDA tensors")
+    if o.n != w.n:
+        raise ValueError("offsets must hold one entry per block")
+    idx = index if _is_torch(index) else torch.as_tensor(np.asarray(index, dtype=np.int64).reshape(-1), device=src.x.device)
+    idx = idx.contiguous()
+    assert idx.element_size() == 8
+    out = torch.empty(idx.numel(), dtype=src.x.dtype, device=src.x.device)
+    err = torch.zeros(1, dtype=torch.int32, device=src.x.device)
+    with torch.cuda.device(src.x.device):
+        _check(getattr(_lib.load(), f"fl_{ty}_unpack_single_widths")(w.ptr, o.ptr, src.ptr, w.n, idx.data_ptr(), idx.numel(),
+                                                                    out.data_ptr(), err.data_ptr(), _stream(src)),
+               f"fl_{ty}_unpack_single_widths")
+    if int(err.item()) != 0:
+        raise FastLanesError(2, f"fl_{ty}_unpack_single_widths")
+    return out
+
+
 class MixedWidthPlan:
     """A column whose blocks each have their own width (BASELINE.json config 5): the
     reference's caller loop `for b: T::unchecked_unpack(widths[b], ..)` (bitpacking.rs:109-129)

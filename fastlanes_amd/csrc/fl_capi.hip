@@ -254,7 +254,18 @@ int dev_unpack_single(unsigned w, const T* packed, size_t n_blocks, const uint64
     if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
     if (n_idx == 0) return FL_OK;
     if (!idx || !out || (w != 0 && !packed)) return FL_ERR_NULL;
-    SingleArgs a{packed, idx, out, err_flag, n_blocks, n_idx, w};
+    SingleArgs a{packed, idx, out, err_flag, n_blocks, n_idx, w, nullptr, nullptr};
+    hipError_t e = unpack_single_launch<T>(a, static_cast<hipStream_t>(s));
+    return e == hipSuccess ? FL_OK : hip_fail(e);
+}
+
+template <typename T>
+int dev_unpack_single_widths(const uint8_t* widths, const uint64_t* offsets, const T* packed, size_t n_blocks,
+                             const uint64_t* idx, size_t n_idx, T* out, uint32_t* err_flag, void* s)
+{
+    if (n_idx == 0) return FL_OK;
+    if (!widths || !offsets || !idx || !out || !packed) return FL_ERR_NULL;
+    SingleArgs a{packed, idx, out, err_flag, n_blocks, n_idx, 0, widths, offsets};
     hipError_t e = unpack_single_launch<T>(a, static_cast<hipStream_t>(s));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
@@ -565,6 +576,9 @@ size_t fl_packed_len(unsigned type_bits, unsigned width)
     { return run_widths<T>(false, w, o, pk, out, n, ef, s); }                                             \
     int fl_##S##_pack_widths(const uint8_t* w, const uint64_t* o, const T* in, T* pk, size_t n, uint32_t* ef, void* s) \
     { return run_widths<T>(true, w, o, pk, const_cast<T*>(in), n, ef, s); }                               \
+    int fl_##S##_unpack_single_widths(const uint8_t* w, const uint64_t* o, const T* pk, size_t n, const uint64_t* idx, \
+                                      size_t ni, T* out, uint32_t* ef, void* s)                           \
+    { return dev_unpack_single_widths<T>(w, o, pk, n, idx, ni, out, ef, s); }                             \
     int fl_##S##_pack_host(unsigned w, const T* in, T* out, size_t n)                                     \
     {                                                                                                     \
         if (w > sizeof(T) * 8) return FL_ERR_WIDTH;                                                       \

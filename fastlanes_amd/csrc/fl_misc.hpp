@@ -79,6 +79,9 @@ struct SingleArgs {
     uint64_t n_blocks;
     uint64_t n_indices;
     unsigned width;
+    // mixed-width columns: per-block widths[] / byte offsets[] in HBM (nullptr = every block has `width`, back to back)
+    const uint8_t* widths;
+    const uint64_t* offsets;
 };
 
 // bitpacking.rs:132-179 with the lookup tables of :207-232 computed in closed form.
@@ -91,9 +94,19 @@ __global__ __launch_bounds__(WG) void k_unpack_single(SingleArgs a)
     if (k >= a.n_indices) return;
     const uint64_t gi = a.indices[k];
     T* out = static_cast<T*>(a.out);
-    const unsigned W = a.width;
-    if (W == 0) { out[k] = 0; return; }                       // bitpacking.rs:136-139
     const uint64_t blk = gi >> 10;
+    if (a.widths && blk >= a.n_blocks) {                      // bitpacking.rs:152 (before the width is known)
+        out[k] = 0;
+        if (a.err_flag) *a.err_flag = 1u;
+        return;
+    }
+    const unsigned W = a.widths ? (unsigned)a.widths[blk] : a.width;
+    if (W > TB) {                                             // bitpacking.rs:197 unreachable!()
+        out[k] = 0;
+        if (a.err_flag) *a.err_flag = 1u;
+        return;
+    }
+    if (W == 0) { out[k] = 0; return; }                       // bitpacking.rs:136-139
     if (blk >= a.n_blocks) {                                  // bitpacking.rs:152
         out[k] = 0;
         if (a.err_flag) *a.err_flag = 1u;
@@ -104,7 +117,8 @@ __global__ __launch_bounds__(WG) void k_unpack_single(SingleArgs a)
     const unsigned s = index / 128;                           // bitpacking.rs:226
     const unsigned o = fl_order((index - s * 128 - lane) / 16);   // bitpacking.rs:227-228
     const unsigned row = o * 8 + s;                           // bitpacking.rs:229
-    const T* pk = static_cast<const T*>(a.packed) + blk * (uint64_t)(1024u * W / TB);
+    const T* pk = a.widths ? reinterpret_cast<const T*>(static_cast<const char*>(a.packed) + a.offsets[blk])
+                           : static_cast<const T*>(a.packed) + blk * (uint64_t)(1024u * W / TB);
     if (W == TB) { out[k] = pk[LANES * row + lane]; return; } // bitpacking.rs:159-162
     const T mask = (T)(((T)1 << W) - (T)1);
     const unsigned start_bit = row * W;

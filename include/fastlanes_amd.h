@@ -195,6 +195,12 @@ const uint8_t *fl_mixed_plan_widths(const fl_mixed_plan *plan);
                                T *out, size_t n_blocks, uint32_t *err_flag, void *stream);       \
     int fl_##S##_pack_widths(const uint8_t *widths, const uint64_t *offsets, const T *in,        \
                              T *packed, size_t n_blocks, uint32_t *err_flag, void *stream);      \
+    /* unchecked_unpack_single (bitpacking.rs:58,181-200) over such a column, batched: out[k] = element  \
+     * indices[k] (= block*1024 + index_in_block) of the column; an index past the column or a width  \
+     * > T writes 0 and sets *err_flag */                                                           \
+    int fl_##S##_unpack_single_widths(const uint8_t *widths, const uint64_t *offsets,            \
+                                      const T *packed, size_t n_blocks, const uint64_t *indices,  \
+                                      size_t n_indices, T *out, uint32_t *err_flag, void *stream); \
     /* the same over a mixed-width plan (see fl_mixed_plan) */                                     \
     int fl_##S##_unpack_mixed(const fl_mixed_plan *plan, const T *packed, T *out, void *stream); \
     int fl_##S##_pack_mixed(const fl_mixed_plan *plan, const T *in, T *packed, void *stream);    \

@@ -62,6 +62,7 @@ template <typename T> struct Abi;
         static constexpr auto pack_mixed = fl_##S##_pack_mixed;                                      \
         static constexpr auto unpack_widths = fl_##S##_unpack_widths;                                \
         static constexpr auto pack_widths = fl_##S##_pack_widths;                                    \
+        static constexpr auto unpack_single_widths = fl_##S##_unpack_single_widths;                  \
         static constexpr auto pack_host = fl_##S##_pack_host;                                        \
         static constexpr auto unpack_host = fl_##S##_unpack_host;                                    \
         static constexpr auto unpack_single_host = fl_##S##_unpack_single_host;                      \
@@ -252,6 +253,11 @@ template <typename T>
 inline void pack_widths_device(const std::uint8_t* d_widths, const std::uint64_t* d_offsets, const T* d_in, T* d_packed,
                                std::size_t n_blocks, std::uint32_t* d_err_flag = nullptr, void* stream = nullptr)
 { detail::check(detail::Abi<T>::pack_widths(d_widths, d_offsets, d_in, d_packed, n_blocks, d_err_flag, stream), "pack_widths"); }
+template <typename T>
+inline void unpack_single_widths_device(const std::uint8_t* d_widths, const std::uint64_t* d_offsets, const T* d_packed,
+                                        std::size_t n_blocks, const std::uint64_t* d_indices, std::size_t n_indices, T* d_out,
+                                        std::uint32_t* d_err_flag = nullptr, void* stream = nullptr)
+{ detail::check(detail::Abi<T>::unpack_single_widths(d_widths, d_offsets, d_packed, n_blocks, d_indices, n_indices, d_out, d_err_flag, stream), "unpack_single_widths"); }
 template <typename T>
 inline void widths_to_offsets_device(const std::uint8_t* d_widths, std::size_t n_blocks, std::uint64_t* d_offsets,
                                      std::uint64_t* d_total_bytes = nullptr, std::uint32_t* d_err_flag = nullptr, void* stream = nullptr)

@@ -414,6 +414,12 @@ def test_unpack_pack_widths_device_resident(fl, oracle, ty):
         k = packed_len(ty, int(w))
         assert np.array_equal(after[lo:lo + k], oracle.pack(ty, int(w), v[b * 1024:(b + 1) * 1024])), b
         assert np.array_equal(after[lo + k:lo + k + 256 // esz], before[lo + k:lo + k + 256 // esz]), "gap bytes were written"
+    # unpack_single over the same reversed / gapped column: every element of a few blocks, and random ones, vs unpack()
+    idx = np.concatenate([np.arange(3 * 1024), rng.integers(0, n * 1024, size=5000), [n * 1024 - 1]]).astype(np.int64)
+    got1 = to_np(fl.unpack_single_widths(dw, doff, to_dev(col), torch.from_numpy(idx).cuda()), ty)
+    assert np.array_equal(got1, want[idx]), (ty, "unpack_single_widths")
+    with pytest.raises(fl.FastLanesError):                                    # bitpacking.rs:152
+        fl.unpack_single_widths(dw, doff, to_dev(col), torch.tensor([n * 1024], dtype=torch.int64).cuda())
     # width > T: that block is skipped and the flag raised (bitpacking.rs:93,126 unreachable!())
     bad = widths.copy()
     bad[7] = T + 1
@@ -422,6 +428,8 @@ def test_unpack_pack_widths_device_resident(fl, oracle, ty):
         fl.unpack_widths(dbad, doff, to_dev(col))
     with pytest.raises(fl.FastLanesError):
         fl.widths_to_offsets(ty, dbad)
+    with pytest.raises(fl.FastLanesError):                                    # bitpacking.rs:197
+        fl.unpack_single_widths(dbad, doff, to_dev(col), torch.tensor([7 * 1024 + 5], dtype=torch.int64).cuda())
     out = torch.zeros(n * 1024, dtype=tdt, device="cuda:0")
     fl.unpack_widths(dbad, doff, to_dev(col), output=out, check=False)     # asynchronous form: no flag read-back
     g = to_np(out, ty)
