@@ -442,6 +442,41 @@ def test_unpack_pack_widths_device_resident(fl, oracle, ty):
     assert fl.unpack_widths(e8, o0, torch.empty(0, dtype=tdt, device="cuda:0")).numel() == 0
 
 
+def test_mixed_width_fuzz_shapes_and_occupancies(fl, oracle, kernel_policy):
+    """Seeded fuzz of the device-resident mixed-width kernels over (type, block count, widths incl. 0 and T, waves per SIMD,
+    blocks per wavefront): unpack_widths / pack_widths / unpack_single_widths against the oracle's per-block loop."""
+    import torch
+    rng = np.random.default_rng(int(os.environ.get("FL_FUZZ_SEED", "2025")))
+    for _ in range(int(os.environ.get("FL_FUZZ_ITERS", "48"))):
+        ty = TYS[rng.integers(0, 4)]
+        T = tbits(ty)
+        esz = T // 8
+        tdt = {"u8": torch.uint8, "u16": torch.uint16, "u32": torch.uint32, "u64": torch.uint64}[ty]
+        n = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 31, 32, 33, 63, 65, 127, 129, 300]))
+        waves = int(rng.choice([0, 3, 4, 6, 8]))
+        bpw = int(rng.choice([0, 1, 2, 3, 8]))
+        kernel_policy(2 + 256 * waves + 65536 * bpw)
+        widths = rng.integers(0, T + 1, size=n).astype(np.uint8)
+        off = np.concatenate([[0], np.cumsum(widths.astype(np.int64) * 128)])
+        seed = int(rng.integers(0, 1 << 30))
+        col = values(ty, int(off[-1]) // esz, seed)
+        v = values(ty, n * 1024, seed + 1)
+        dw = torch.from_numpy(widths).cuda()
+        doff, dtotal = fl.widths_to_offsets(ty, dw)
+        assert int(dtotal.item()) == off[-1]
+        want = np.concatenate([oracle.unpack(ty, int(w), col[off[b] // esz:off[b + 1] // esz]) for b, w in enumerate(widths)])
+        dcol = to_dev(col)
+        assert np.array_equal(to_np(fl.unpack_widths(dw, doff, dcol), ty), want), (ty, n, waves, bpw, seed, "unpack")
+        dpk = torch.zeros(int(off[-1]) // esz, dtype=tdt, device="cuda:0")
+        fl.pack_widths(dw, doff, to_dev(v), dpk)
+        wantp = np.concatenate([oracle.pack(ty, int(w), v[b * 1024:(b + 1) * 1024]) for b, w in enumerate(widths)]
+                               + [np.zeros(0, dtype=TYPES[ty][0])])
+        assert np.array_equal(to_np(dpk, ty), wantp), (ty, n, waves, bpw, seed, "pack")
+        idx = rng.integers(0, n * 1024, size=257).astype(np.int64)
+        got = to_np(fl.unpack_single_widths(dw, doff, dcol, torch.from_numpy(idx).cuda()), ty)
+        assert np.array_equal(got, want[idx]), (ty, n, seed, "unpack_single")
+
+
 def test_widths_to_offsets_large(fl):
     """The three-launch device scan across many 4096-block chunks, ragged tail, against numpy."""
     import torch
