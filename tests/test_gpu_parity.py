@@ -631,6 +631,15 @@ def test_functor_api_user_kernel_dict_decode(fl, oracle):
     assert np.array_equal(to_np(out, "u32"), want)
 
 
+def test_plain_c_caller_of_the_c_abi(fl):
+    """examples/column_decode.c: a C99 program (no C++, no Python) that encodes, decodes and point-reads a mixed-width column
+    through the C ABI exactly as a cgo / JNI / Rust-FFI binding would -- device tier, host tier and the device prefix sum."""
+    import subprocess
+    import __graft_entry__ as ge
+    r = subprocess.run([ge.build_examples()["column_decode"]], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", (r.returncode, r.stdout, r.stderr)
+
+
 def test_functor_api_user_kernel_on_iterate_rows(fl, oracle):
     """examples/iterate_running_max.hip: a stateful body spliced into fl::iterate_rows (the iterate! counterpart,
     macros.rs:11-32) -- a running maximum along every FastLanes lane in row order, the shape of Delta::undelta
