@@ -8,9 +8,20 @@ its own 10 M-block column on its own GPU (block-range sharding, no collective
 on the data path): weak scaling, value = N * 10.24 G integers / max-over-ranks time.
 
 `python bench.py --gpus N` with no torchrun environment SPAWNS the N ranks itself
-(one process per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, RCCL barrier and
-max-over-ranks time); under `python -m torch.distributed.run ... bench.py --gpus N`
-it is one of the N ranks.  Either way rank 0 prints ONE JSON line.
+(one process per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set); under
+`python -m torch.distributed.run ... bench.py --gpus N` it is one of the N ranks.
+Either way rank 0 prints ONE JSON line.
+
+Control plane (barrier, max-over-ranks time, gather of per-rank figures -- the data
+path has NO collective): a gloo group always exists; RCCL ("nccl") is tried on top of
+it -- first in a throw-away child process per rank (a hang or crash there costs a
+timeout, not the run), then in-process -- and used for the barrier / reductions only if
+EVERY rank got it working; otherwise the run continues on gloo.  The line says which
+(`control_backend`, `control_fallback_reason`).
+
+Every rank checks what it just timed -- the first and last block of ITS slice plus
+sampled blocks, both legs -- against the oracle outside the timed region
+(`per_rank[i].correct`); any mismatch makes every rank exit non-zero.
 
 After the headline leg the same processes time BASELINE.json configs[4] --
 u32, width[b] = 1 + b mod 32, the 10 B-integer column (9 765 625 blocks) sharded
@@ -64,8 +75,16 @@ def parse():
                     "then comes from profiles/pmc_traffic.json, or is null)")
     ap.add_argument("--no-config5", action="store_true", help="skip the strong-scaled mixed-width leg")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier / max-time "
-                    "reduction (nccl = RCCL; gloo only for plumbing tests)")
+    ap.add_argument("--backend", default="auto", choices=("auto", "nccl", "gloo"),
+                    help="control plane for the barrier / max-time reduction: auto = RCCL if every rank gets it working, "
+                         "else gloo; nccl = the same (the fallback still applies, the line reports it); gloo = never try RCCL")
+    ap.add_argument("--no-check", action="store_true", help="skip the per-rank oracle check of the timed output")
+    ap.add_argument("--probe-nccl", action="store_true", help="with --dry-run: still attempt the RCCL probe (exercises the "
+                    "fallback on a box without GPUs)")
+    ap.add_argument("--inject-mismatch", type=int, default=-1, help="with --dry-run: pretend this rank's oracle check failed "
+                    "(tests that one bad rank fails the whole launch)")
+    ap.add_argument("--nccl-probe-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--nccl-probe-timeout", type=float, default=120.0, help="seconds the throw-away RCCL probe may take")
     ap.add_argument("--single-device", action="store_true",
                     help="plumbing test: put every rank on cuda:0 (use with --backend gloo)")
     ap.add_argument("--dry-run", action="store_true",
@@ -247,7 +266,9 @@ class Workload:
         self.bytes = self.in_bytes + self.out_bytes      # algorithmic bytes per launch
 
     def check_against_oracle(self):
-        """Sampled blocks of what was just timed vs the oracle (rank 0, N=1, outside the timed region)."""
+        """The first and last block of this rank's slice plus sampled blocks of what was just timed vs the oracle
+        (every rank, outside the timed region; SURVEY.md 8(d) "first/last block of every GPU slice").
+        Returns (all equal, number of blocks compared)."""
         import numpy as np
         import torch
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -260,7 +281,8 @@ class Workload:
         def host(t):
             return t.view(torch.uint8).cpu().numpy().view(npdt)
         ok = True
-        for b in sorted({0, 1, 31, 32, n // 2, n - 2, n - 1}):
+        blocks = sorted(b for b in {0, 1, 31, 32, n // 3, n // 2, n - 2, n - 1} if 0 <= b < n)
+        for b in blocks:
             if op == "unpack_mixed":
                 w = int(self.widths[b].item())
                 lo = int(self.offsets[b].item()) // esz
@@ -277,20 +299,153 @@ class Workload:
                 else:
                     want = o.undelta_pack(ty, width, s, host(self.bases[b * (128 // esz):(b + 1) * (128 // esz)]))
             ok = ok and bool(np.array_equal(got, want))
-        return "bit-exact vs oracle on 7 sampled blocks" if ok else "MISMATCH vs oracle"
+        return ok, len(blocks)
 
 
-def timed_region(step, args, dist_ctx):
+def check_text(flags, n_checked):
+    if not flags:
+        return None
+    if all(flags):
+        return f"bit-exact vs oracle on {n_checked} blocks per rank (first, last and sampled blocks of every rank's slice)"
+    return "MISMATCH vs oracle on rank(s) " + ",".join(str(r) for r, f in enumerate(flags) if not f)
+
+
+# ---------------------------------------------------------------------------------------------
+# control plane: gloo always, RCCL on top of it when every rank gets it working
+# ---------------------------------------------------------------------------------------------
+def nccl_probe_child(args):
+    """Throw-away process: RCCL rendezvous + one all_reduce + one barrier on this rank's device.  Exit 0 = worked.
+    Run by Control.__init__ under a timeout, so an RCCL hang or crash never reaches the measuring process."""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    local = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=args.nccl_probe_timeout))
+    t = torch.ones(1, device=dev)
+    dist.all_reduce(t)
+    dist.barrier(device_ids=[local])
+    torch.cuda.synchronize()
+    ok = int(t.item()) == world
+    os._exit(0 if ok else 3)          # no destructors: a half-dead communicator must not hang the exit
+
+
+class Control:
+    """barrier / max / gather over the ranks.  The data path needs none of it, so RCCL is an
+    option, never a requirement: `backend` is what is actually in use."""
+
+    def __init__(self, args, world, rank, dev):
+        import datetime
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.world, self.rank, self.dev = world, rank, dev
+        self.backend, self.group, self.fallback_reason, self.inprocess_failed = "none", None, None, False
+        if world == 1:
+            return
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=30))
+        self.backend = "gloo"
+        if args.backend == "gloo" or (args.dry_run and not args.probe_nccl):
+            return
+        # 1. probe RCCL in a child process per rank (own rendezvous port), bounded by a timeout
+        err = None
+        port = torch.zeros(1, dtype=torch.int64)
+        if rank == 0:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port[0] = sk.getsockname()[1]
+        dist.broadcast(port, 0)
+        try:
+            env = dict(os.environ, MASTER_PORT=str(int(port.item())))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            cmd = [sys.executable, os.path.abspath(__file__), "--nccl-probe-child", "--gpus", str(world),
+                   "--nccl-probe-timeout", str(args.nccl_probe_timeout)] + (["--single-device"] if args.single_device else [])
+            r = subprocess.run(cmd, env=env, timeout=args.nccl_probe_timeout + 60, capture_output=True, text=True)
+            if r.returncode != 0:
+                tail = (r.stderr or "").strip().splitlines()[-1:] or ["no stderr"]
+                err = f"RCCL probe exited {r.returncode}: {tail[0][:200]}"
+        except subprocess.TimeoutExpired:
+            err = f"RCCL probe timed out after {args.nccl_probe_timeout + 60:.0f} s"
+        except Exception as e:       # the probe must never take the bench down
+            err = f"RCCL probe could not run: {e!r}"
+        if not self._all_ok(err is None):
+            self.fallback_reason = err or "the RCCL probe failed on another rank"
+            return
+        # 2. the probe worked everywhere: the same thing in-process, still guarded
+        try:
+            os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")     # a timeout raises instead of aborting the process
+            g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=args.nccl_probe_timeout))
+            t = torch.ones(1, device=dev)
+            dist.all_reduce(t, group=g)
+            torch.cuda.synchronize()
+            if int(t.item()) != world:
+                raise RuntimeError(f"all_reduce over RCCL returned {t.item()} for {world} ranks")
+        except Exception as e:
+            g, err, self.inprocess_failed = None, f"in-process RCCL init failed: {e!r}"[:300], True
+        if self._all_ok(g is not None):
+            self.group, self.backend = g, "nccl"
+        else:
+            self.fallback_reason = err or "in-process RCCL init failed on another rank"
+
+    def _all_ok(self, ok):
+        """logical AND over the ranks, on the gloo plane"""
+        t = self.torch.tensor([1.0 if ok else 0.0], dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return t.item() == 1.0
+
+    def barrier(self):
+        if self.world == 1:
+            return
+        if self.group is not None:
+            self.dist.barrier(group=self.group, device_ids=[self.dev.index])
+        else:
+            self.dist.barrier()
+
+    def _tensor(self, vals):
+        on_gpu = self.group is not None
+        return self.torch.tensor(vals, dtype=self.torch.float64, device=self.dev if on_gpu else "cpu")
+
+    def all_max(self, x):
+        if self.world == 1:
+            return x
+        t = self._tensor([x])
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
+    def gather(self, vals):
+        """[[vals of rank 0], [vals of rank 1], ...] on every rank."""
+        t = self._tensor(vals)
+        if self.world == 1:
+            return [t.tolist()]
+        out = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t, group=self.group)
+        return [o.tolist() for o in out]
+
+    def close(self):
+        if self.world == 1:
+            return
+        self.dist.barrier()                       # gloo: everybody is done
+        if self.inprocess_failed:
+            return                                # a failed RCCL attempt may have left threads behind: main() leaves by os._exit
+        try:
+            self.dist.destroy_process_group()
+        except Exception:
+            pass
+
+
+def timed_region(step, args, ctl):
     """W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides;
     returns (max-over-ranks wall seconds, this rank's per-launch HIP-event milliseconds)."""
     import torch
-    world, reduce_dev, dist = dist_ctx
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
-        dist.barrier()
+    ctl.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for a, b in evs:
@@ -298,27 +453,10 @@ def timed_region(step, args, dist_ctx):
         step()
         b.record()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    ctl.barrier()
     elapsed = time.perf_counter() - t0
     kern_ms = [a.elapsed_time(b) for a, b in evs]
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    return elapsed, kern_ms
-
-
-def gather_per_rank(vals, dist_ctx):
-    """[[vals of rank 0], [vals of rank 1], ...] on every rank."""
-    import torch
-    world, reduce_dev, dist = dist_ctx
-    t = torch.tensor(vals, dtype=torch.float64, device=reduce_dev)
-    if world == 1:
-        return [t.tolist()]
-    out = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(out, t)
-    return [o.tolist() for o in out]
+    return ctl.all_max(elapsed), kern_ms
 
 
 # ---------------------------------------------------------------------------------------------
@@ -413,22 +551,35 @@ def roofline(w, kern_ms, traffic=None, traffic_source=None):
     }
 
 
-def config5_leg(args, world, rank, dev, dist_ctx):
+def run_check(w, args, ctl):
+    """Per-rank oracle check; (flags of every rank, blocks compared per rank) or ([], 0) with --no-check."""
+    if args.no_check:
+        return [], 0
+    try:
+        ok, n_checked = w.check_against_oracle()
+    except Exception as e:          # an unloadable checker is a failed check, not a crash that strands the other ranks
+        print(f"rank {ctl.rank}: oracle check could not run: {e!r}", file=sys.stderr)
+        ok, n_checked = False, 0
+    flags = [bool(v[0]) for v in ctl.gather([1.0 if ok else 0.0])]
+    return flags, n_checked
+
+
+def config5_leg(args, world, rank, dev, ctl):
     """BASELINE.json configs[4], STRONG scaling: the 10 B-integer u32 column (9 765 625 blocks, width[b] = 1 + b mod 32)
     sharded by contiguous block range over the ranks (no collective on the data path)."""
     from fastlanes_amd.sharding import block_range
     first, n = block_range(CONFIG5_BLOCKS, world, rank)
     if args.dry_run:
-        per_rank = gather_per_rank([float(n), 0.0, 0.0], dist_ctx)
+        per_rank = ctl.gather([float(n), 0.0, 0.0])
         return {"dry_run": True, "per_rank": [{"rank": r, "first_block": block_range(CONFIG5_BLOCKS, world, r)[0],
                                                "blocks": int(v[0])} for r, v in enumerate(per_rank)]}
     w = Workload("u32_mixed_unpack", n, first, rank, dev)
-    elapsed, kern_ms = timed_region(w.step, args, dist_ctx)
+    elapsed, kern_ms = timed_region(w.step, args, ctl)
     avg_ms = sum(kern_ms) / len(kern_ms)
-    per_rank = gather_per_rank([float(n), avg_ms, float(w.bytes)], dist_ctx)
-    check = w.check_against_oracle() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    per_rank = ctl.gather([float(n), avg_ms, float(w.bytes)])
+    flags, n_checked = run_check(w, args, ctl)
     if rank != 0:
-        return None
+        return {"flags": flags}
     traffic = source = None
     if world == 1 and not args.no_pmc:
         del w.src, w.dst                     # the PMC child builds its own copy of the column
@@ -443,6 +594,8 @@ def config5_leg(args, world, rank, dev, dist_ctx):
     ranks = [{"rank": r, "first_block": block_range(CONFIG5_BLOCKS, world, r)[0], "blocks": int(v[0]),
               "kernel_ms_avg": round(v[1], 4), "GBps": round(v[2] / (v[1] / 1e3) / 1e9, 1),
               "frac": round(v[2] / (v[1] / 1e3) / 1e9 / HBM_PEAK_GBPS, 4)} for r, v in enumerate(per_rank)]
+    for r, f in enumerate(flags):
+        ranks[r]["correct"] = f
     return {
         "metric": "billion integers/sec decoded (u32 mixed widths 1-32, 10 B-integer column sharded over the GPUs)",
         "workload": "unpack u32 width[b] = 1 + b mod 32, 9 765 625 blocks in total (BASELINE.json configs[4]); widths[] / "
@@ -456,7 +609,8 @@ def config5_leg(args, world, rank, dev, dist_ctx):
         "aggregate_GBps": round(sum(v[2] for v in per_rank) * args.steps / elapsed / 1e9, 1),
         "per_rank": ranks,
         "roofline_rank0": roofline(w, kern_ms, traffic, source),
-        "correctness": check,
+        "correctness": check_text(flags, n_checked),
+        "flags": flags,
     }
 
 
@@ -464,11 +618,12 @@ def main():
     args = parse()
     if args.pmc_child:
         return pmc_child(args)
+    if args.nccl_probe_child:
+        return nccl_probe_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
 
     import torch
-    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -479,8 +634,6 @@ def main():
         local_rank = 0
     if args.dry_run:
         dev = torch.device("cpu")
-        if args.backend == "nccl":
-            args.backend = "gloo"
     else:
         if not torch.cuda.is_available():
             sys.exit("bench.py needs a GPU (there is no CPU path); --dry-run only exercises the launcher")
@@ -488,14 +641,10 @@ def main():
             sys.exit(f"rank {rank}: cuda:{local_rank} does not exist ({torch.cuda.device_count()} devices visible)")
         dev = torch.device("cuda", local_rank)
         torch.cuda.set_device(dev)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(args.backend)
-    reduce_dev = dev if (args.backend == "nccl" and not args.dry_run) else torch.device("cpu")
-    dist_ctx = (world, reduce_dev, dist)
+    ctl = Control(args, world, rank, dev)
+    control = {"control_backend": ctl.backend}
+    if ctl.fallback_reason:
+        control["control_fallback_reason"] = ctl.fallback_reason
 
     ty, width, op, _ = WORKLOADS[args.workload]
     strong_main = op == "unpack_mixed" and args.blocks == 10_000_000
@@ -507,35 +656,35 @@ def main():
     if args.dry_run:
         # plumbing only: the same barrier / max-reduce / gather calls, no codec work, no number
         t0 = time.perf_counter()
-        if world > 1:
-            dist.barrier()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        per_rank = gather_per_rank([float(rank), float(n)], dist_ctx)
-        c5 = None if (args.no_config5 or strong_main) else config5_leg(args, world, rank, dev, dist_ctx)
+        ctl.barrier()
+        ctl.all_max(time.perf_counter() - t0)
+        per_rank = ctl.gather([float(rank), float(n)])
+        flags = [bool(v[0]) for v in ctl.gather([0.0 if rank == args.inject_mismatch else 1.0])]   # the verdict plumbing
+        c5 = None if (args.no_config5 or strong_main) else config5_leg(args, world, rank, dev, ctl)
         if rank == 0:
-            print(json.dumps({"metric": "DRY RUN (no GPU work): launcher / rendezvous / sharding plumbing only",
-                              "value": None, "unit": "Gint/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                              "dry_run": True, "ranks": [int(v[0]) for v in per_rank],
-                              "blocks_per_rank": [int(v[1]) for v in per_rank], "config5_strong": c5}), flush=True)
-        if world > 1:
-            dist.destroy_process_group()
+            print(json.dumps(dict({"metric": "DRY RUN (no GPU work): launcher / rendezvous / sharding plumbing only",
+                                   "value": None, "unit": "Gint/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                                   "dry_run": True, "ranks": [int(v[0]) for v in per_rank],
+                                   "blocks_per_rank": [int(v[1]) for v in per_rank], "config5_strong": c5,
+                                   "per_rank": [{"rank": r, "correct": f} for r, f in enumerate(flags)],
+                                   "correctness": check_text(flags, 0)}, **control)), flush=True)
+        ctl.close()
+        if not all(flags):
+            sys.exit(1)
         return
 
     import fastlanes_amd as fl
     fl.load()  # fails loudly if the HIP extension is missing
 
     w = Workload(args.workload, n, first, rank, dev)
-    elapsed, kern_ms = timed_region(w.step, args, dist_ctx)
+    elapsed, kern_ms = timed_region(w.step, args, ctl)
     avg_ms = sum(kern_ms) / len(kern_ms)
-    per_rank = gather_per_rank([float(n), avg_ms, float(w.bytes)], dist_ctx)
+    per_rank = ctl.gather([float(n), avg_ms, float(w.bytes)])
+    flags, n_checked = run_check(w, args, ctl)       # every rank, its own slice, outside the timed region
 
-    # ---- rank 0, N=1: the cpu_baseline leg (the only place bench.py touches oracle/) also
-    # ---- checks sampled blocks of what was just timed against the oracle, outside the timed region
-    check = cpu = None
+    # ---- rank 0, N=1: the cpu_baseline leg (with the checks, the only place bench.py touches oracle/)
+    cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        check = w.check_against_oracle()
         cpu = cpu_baseline(args, ty, width, op)
 
     out = None
@@ -566,6 +715,10 @@ def main():
                         f"{n} blocks on rank 0" + (f" of {CONFIG5_BLOCKS} in total" if strong_main else " per GPU"))
         else:
             workload = f"{op} {ty} W={width}, {n} blocks per GPU"
+        ranks = [{"rank": r, "blocks": int(v[0]), "kernel_ms_avg": round(v[1], 4),
+                  "GBps": round(v[2] / (v[1] / 1e3) / 1e9, 1)} for r, v in enumerate(per_rank)]
+        for r, f in enumerate(flags):
+            ranks[r]["correct"] = f
         out = {
             # BASELINE.json "metric", verbatim, for the headline workload
             "metric": "billion integers/sec decoded (u32 width-7) + achieved HBM GB/s vs peak, 1-8 GPU"
@@ -584,30 +737,33 @@ def main():
             "data": "synthetic (uniform random packed bits, generated on device; inputs resident in HBM)",
             "config": {"workload": workload, "blocks_per_gpu": n, "sharding": "contiguous block range per GPU, no collective"},
             "roofline": roofline(w, kern_ms, traffic, traffic_source),
-            "per_rank": [{"rank": r, "blocks": int(v[0]), "kernel_ms_avg": round(v[1], 4),
-                          "GBps": round(v[2] / (v[1] / 1e3) / 1e9, 1)} for r, v in enumerate(per_rank)],
-            "correctness": check,
+            "per_rank": ranks,
+            "correctness": check_text(flags, n_checked),
         }
+        out.update(control)
         if cpu is not None:
             out["cpu_baseline"] = cpu
 
     # ---- second leg: BASELINE.json configs[4] strong-scaled over the same ranks ------------------
+    bad = not all(flags)
     if not args.no_config5 and not strong_main:
-        import torch
         del w
         torch.cuda.empty_cache()
-        c5 = config5_leg(args, world, rank, dev, dist_ctx)
+        c5 = config5_leg(args, world, rank, dev, ctl)
+        bad = bad or not all(c5.pop("flags"))
         if rank == 0:
             out["config5_strong"] = c5
 
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
-    if rank == 0:
-        bad = [c for c in (out.get("correctness"), (out.get("config5_strong") or {}).get("correctness")) if c and "MISMATCH" in c]
-        if bad:
-            sys.exit(1)
+    ctl.close()
+    rc = 1 if bad else 0            # every rank knows every rank's verdict: all of them fail together
+    if ctl.inprocess_failed:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(rc)
+    if rc:
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -66,3 +66,25 @@ def test_a_failing_rank_fails_the_launch():
                        capture_output=True, text=True, timeout=300, env=_clean_env())
     assert r.returncode != 0
     assert "needs a GPU" in r.stderr
+
+
+def test_rccl_failure_falls_back_to_gloo():
+    """The data path needs no collective, so RCCL must never be a single point of failure: with no GPU here the RCCL
+    probe (a throw-away child per rank) fails, every rank agrees over gloo, and the run completes on gloo saying so."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--probe-nccl", "--nccl-probe-timeout", "30",
+                        "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300, env=_clean_env())
+    assert r.returncode == 0, r.stderr
+    out = _one_json_line(r.stdout)
+    assert out["control_backend"] == "gloo"
+    assert "RCCL probe" in out["control_fallback_reason"]
+    assert [p["correct"] for p in out["per_rank"]] == [True, True]
+
+
+def test_one_mismatching_rank_fails_every_rank():
+    """per_rank[i].correct is gathered from every rank and any False makes the launch exit non-zero."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--dry-run", "--inject-mismatch", "1",
+                        "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300, env=_clean_env())
+    assert r.returncode != 0
+    out = _one_json_line(r.stdout)
+    assert [p["correct"] for p in out["per_rank"]] == [True, False]
+    assert "MISMATCH" in out["correctness"] and "1" in out["correctness"]

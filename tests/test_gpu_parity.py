@@ -1131,22 +1131,34 @@ def test_for_reference_stride_through_the_c_abi(fl, oracle):
         assert np.array_equal(to_np(back, "u32"), oracle.batch("unfor_pack", "u32", w, to_np(out, "u32"), aux=eff)), stride
 
 
-def test_bench_two_ranks_on_this_gpu(fl):
-    """The N > 1 path of bench.py with the real kernels: `bench.py --gpus 2` spawns two ranks (both on this GPU, gloo
-    rendezvous -- RCCL needs one device per rank), each decodes its own weak-scaled column and its half of the
-    strong-scaled 10 B-integer mixed-width column; rank 0 prints one line with both ranks' timings."""
+@pytest.mark.parametrize("backend", ["gloo", "auto"])
+def test_bench_two_ranks_on_this_gpu(fl, backend):
+    """The N > 1 path of bench.py with the real kernels: `bench.py --gpus 2` spawns two ranks (both on this GPU), each
+    decodes its own weak-scaled column and its half of the strong-scaled 10 B-integer mixed-width column and checks the
+    first / last / sampled blocks of ITS slice against the oracle; rank 0 prints one line with both ranks' timings and
+    verdicts.  backend=auto tries RCCL first: two ranks on one device is something RCCL refuses, so this is the
+    RCCL-failure path on real hardware -- the run must finish on gloo and say why."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
-                        "--steps", "3", "--warmup", "1", "--blocks", "500000"], capture_output=True, text=True, timeout=600, env=env)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", backend, "--single-device",
+                        "--nccl-probe-timeout", "60", "--steps", "3", "--warmup", "1", "--blocks", "500000"],
+                       capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert [p["rank"] for p in d["per_rank"]] == [0, 1] and all(p["blocks"] == 500000 and p["GBps"] > 0 for p in d["per_rank"])
+    assert [p["correct"] for p in d["per_rank"]] == [True, True] and "bit-exact" in d["correctness"]
     c5 = d["config5_strong"]
     assert c5["scaling"] == "strong" and c5["n_gpus"] == 2 and c5["value"] > 0
     assert [p["blocks"] for p in c5["per_rank"]] == [4882813, 4882812] and c5["per_rank"][1]["first_block"] == 4882813
+    assert [p["correct"] for p in c5["per_rank"]] == [True, True]
+    if backend == "gloo":
+        assert d["control_backend"] == "gloo" and "control_fallback_reason" not in d
+    else:
+        assert d["control_backend"] in ("gloo", "nccl")
+        if d["control_backend"] == "gloo":
+            assert d["control_fallback_reason"]
