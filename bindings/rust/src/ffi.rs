@@ -59,12 +59,12 @@ declare_type!(u64, fl_u64_pack_host, fl_u64_unpack_host, fl_u64_unpack_single_ho
 macro_rules! declare_widths {
     ($T:ty, $unpack_widths:ident, $pack_widths:ident, $unpack_single_widths:ident) => {
         extern "C" {
-            pub fn $unpack_single_widths(d_widths: *const u8, d_offsets: *const u64, d_packed: *const $T, n_blocks: usize,
+            pub fn $unpack_single_widths(d_widths: *const u8, d_offsets: *const u64, d_packed: *const $T, packed_bytes: usize, n_blocks: usize,
                                          d_indices: *const u64, n_indices: usize, d_out: *mut $T, d_err_flag: *mut u32,
                                          stream: *mut c_void) -> i32;
-            pub fn $unpack_widths(d_widths: *const u8, d_offsets: *const u64, d_packed: *const $T, d_out: *mut $T,
+            pub fn $unpack_widths(d_widths: *const u8, d_offsets: *const u64, d_packed: *const $T, packed_bytes: usize, d_out: *mut $T,
                                   n_blocks: usize, d_err_flag: *mut u32, stream: *mut c_void) -> i32;
-            pub fn $pack_widths(d_widths: *const u8, d_offsets: *const u64, d_in: *const $T, d_packed: *mut $T,
+            pub fn $pack_widths(d_widths: *const u8, d_offsets: *const u64, d_in: *const $T, d_packed: *mut $T, packed_bytes: usize,
                                 n_blocks: usize, d_err_flag: *mut u32, stream: *mut c_void) -> i32;
         }
     };

@@ -47,14 +47,14 @@ int main(void)
     CHECK_HIP(hipMemcpy(&total, d_total, sizeof total, hipMemcpyDeviceToHost));
     CHECK_HIP(hipMalloc((void **)&d_packed, total));
     /* encode: the unchecked_pack loop (bitpacking.rs:76-96); decode: the unchecked_unpack loop; both one call */
-    CHECK_FL(fl_u32_pack_widths(d_widths, d_offsets, d_values, d_packed, N, d_err, NULL));
-    CHECK_FL(fl_u32_unpack_widths(d_widths, d_offsets, d_packed, d_decoded, N, d_err, NULL));
+    CHECK_FL(fl_u32_pack_widths(d_widths, d_offsets, d_values, d_packed, total, N, d_err, NULL));
+    CHECK_FL(fl_u32_unpack_widths(d_widths, d_offsets, d_packed, total, d_decoded, N, d_err, NULL));
     /* point lookups: unchecked_unpack_single for a few global element indices */
     const uint64_t idx[4] = {0, 1023, 517 * 1024 + 77, (uint64_t)N * 1024 - 1};
     CHECK_HIP(hipMalloc((void **)&d_idx, sizeof idx));
     CHECK_HIP(hipMalloc((void **)&d_picked, 4 * sizeof(uint32_t)));
     CHECK_HIP(hipMemcpy(d_idx, idx, sizeof idx, hipMemcpyHostToDevice));
-    CHECK_FL(fl_u32_unpack_single_widths(d_widths, d_offsets, d_packed, N, d_idx, 4, d_picked, d_err, NULL));
+    CHECK_FL(fl_u32_unpack_single_widths(d_widths, d_offsets, d_packed, total, N, d_idx, 4, d_picked, d_err, NULL));
     /* the same trait call on host slices, one block (what a trait-for-trait binding does): block 517 */
     uint64_t off517 = 0;
     CHECK_HIP(hipMemcpy(&off517, d_offsets + 517, sizeof off517, hipMemcpyDeviceToHost));

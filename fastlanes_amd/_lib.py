@@ -40,9 +40,9 @@ def _signatures(ty):
         "unpack_compare": [_U, _P, ctypes.c_int, c, _Z, _P, _P],
         "unpack_mixed": [_P, _P, _P, _P],
         "pack_mixed": [_P, _P, _P, _P],
-        "unpack_widths": [_P, _P, _P, _P, _Z, _P, _P],
-        "pack_widths": [_P, _P, _P, _P, _Z, _P, _P],
-        "unpack_single_widths": [_P, _P, _P, _Z, _P, _Z, _P, _P, _P],
+        "unpack_widths": [_P, _P, _P, _Z, _P, _Z, _P, _P],
+        "pack_widths": [_P, _P, _P, _P, _Z, _Z, _P, _P],
+        "unpack_single_widths": [_P, _P, _P, _Z, _Z, _P, _Z, _P, _P, _P],
     }
     host = {
         "pack_host": [_U, _P, _P, _Z],
@@ -65,7 +65,7 @@ def exported_symbols():
     names = ["fl_version", "fl_status_string", "fl_last_hip_error", "fl_packed_len",
              "fl_mixed_plan_create", "fl_mixed_plan_destroy", "fl_mixed_plan_n_blocks",
              "fl_mixed_plan_packed_bytes", "fl_mixed_plan_offsets", "fl_mixed_plan_widths",
-             "fl_widths_to_offsets", "fl_host_release", "fl_set_kernel_policy", "fl_get_kernel_policy"]
+             "fl_widths_to_offsets", "fl_fill_random", "fl_host_release", "fl_internal_set_kernel_policy", "fl_internal_get_kernel_policy"]
     for ty in TYPES:
         names += [f"fl_{ty}_{m}" for m in _signatures(ty)]
     return names
@@ -102,12 +102,14 @@ def load():
     lib.fl_mixed_plan_offsets.argtypes = [_P]
     lib.fl_mixed_plan_widths.restype = _P
     lib.fl_mixed_plan_widths.argtypes = [_P]
-    lib.fl_set_kernel_policy.restype = None
-    lib.fl_set_kernel_policy.argtypes = [ctypes.c_int]
-    lib.fl_get_kernel_policy.restype = ctypes.c_int
-    lib.fl_get_kernel_policy.argtypes = []
+    lib.fl_internal_set_kernel_policy.restype = None
+    lib.fl_internal_set_kernel_policy.argtypes = [ctypes.c_int]
+    lib.fl_internal_get_kernel_policy.restype = ctypes.c_int
+    lib.fl_internal_get_kernel_policy.argtypes = []
     lib.fl_host_release.restype = None
     lib.fl_host_release.argtypes = []
+    lib.fl_fill_random.restype = ctypes.c_int
+    lib.fl_fill_random.argtypes = [_P, _Z, _Q, _P]
     lib.fl_widths_to_offsets.restype = ctypes.c_int
     lib.fl_widths_to_offsets.argtypes = [_U, _P, _Z, _P, _P, _P, _P]
     for ty in TYPES:

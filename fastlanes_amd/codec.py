@@ -62,6 +62,35 @@ def _check(rc, where):
         raise FastLanesError(rc, where)
 
 
+# FL_DEVERR_* bits of a device error flag -> the fl_status a synchronous call would have returned
+_DEVERR = ((1, 1), (2, 2), (8, 6), (4, 4))     # width, index, bounds, align (most specific first)
+
+
+def _check_flag(err, where):
+    bits = int(err.item())
+    for bit, status in _DEVERR:
+        if bits & bit:
+            raise FastLanesError(status, where)
+    if bits:
+        raise FastLanesError(5, where)
+
+
+def _indices(index, like):
+    """Column-global element indices for the device tier: a CUDA int64/uint64 tensor on `like`'s device (anything
+    else is converted from the host).  A float tensor, or one of another device, would be reinterpreted / fault."""
+    import torch
+    if _is_torch(index):
+        if index.dtype not in (torch.int64, torch.uint64):
+            raise TypeError(f"indices must be an int64/uint64 tensor, got {index.dtype}")
+        idx = _Arg(index.contiguous(), "u64")
+        _same_tier(like, idx)
+        return idx.x
+    a = np.asarray(index)
+    if a.dtype.kind not in "ui":
+        raise TypeError(f"indices must be integers, got dtype {a.dtype}")
+    return torch.as_tensor(a.astype(np.int64).reshape(-1), device=like.x.device)
+
+
 class _Arg:
     """Uniform view of a numpy array or a torch CUDA tensor."""
 
@@ -220,17 +249,14 @@ class BitPacking:
             _check(rc, f"fl_{ty}_unpack_single")
             return val.value
         import torch
-        idx = index if _is_torch(index) else torch.as_tensor(np.asarray(index, dtype=np.int64).reshape(-1), device=src.x.device)
-        idx = idx.contiguous()
-        assert idx.element_size() == 8
+        idx = _indices(index, src)
         out = torch.empty(idx.numel(), dtype=src.x.dtype, device=src.x.device)
         err = torch.zeros(1, dtype=torch.int32, device=src.x.device)
         with torch.cuda.device(src.x.device):
             rc = getattr(lib, f"fl_{ty}_unpack_single")(width, src.ptr, nb, idx.data_ptr(), idx.numel(),
                                                         out.data_ptr(), err.data_ptr(), _stream(src))
         _check(rc, f"fl_{ty}_unpack_single")
-        if int(err.item()) != 0:
-            raise FastLanesError(2, f"fl_{ty}_unpack_single")  # bitpacking.rs:152
+        _check_flag(err, f"fl_{ty}_unpack_single")             # bitpacking.rs:152
         return out
 
     unchecked_unpack_single = unpack_single
@@ -447,8 +473,7 @@ def widths_to_offsets(ty, widths):
     with torch.cuda.device(dev):
         _check(_lib.load().fl_widths_to_offsets(_lib.BITS[ty], w.ptr, w.n, offsets.data_ptr(), total.data_ptr(),
                                                 err.data_ptr(), _stream(w)), "fl_widths_to_offsets")
-    if int(err.item()) != 0:
-        raise FastLanesError(1, "fl_widths_to_offsets")         # bitpacking.rs:93 unreachable!()
+    _check_flag(err, "fl_widths_to_offsets")                    # bitpacking.rs:93 unreachable!()
     return offsets, total
 
 
@@ -466,22 +491,24 @@ def _widths_call(method, ty, widths, offsets, packed, unpacked, check):
         raise ValueError(f"{method}: the unpacked column must hold 1024 elements per block")
     dev = packed.x.device
     err = torch.zeros(1, dtype=torch.int32, device=dev) if check else None
-    # C ABI argument order is (widths, offsets, in, out, ..): packed -> unpacked for unpack, the reverse for pack
-    first, second = (packed, unpacked) if method == "unpack_widths" else (unpacked, packed)
+    pbytes = packed.n * (_lib.BITS[ty] // 8)     # the kernel skips (and flags) any block that does not lie inside these bytes
+    # C ABI argument order is (widths, offsets, in, out, ..): packed, packed_bytes -> unpacked for unpack, the reverse for pack
+    args = (packed.ptr, pbytes, unpacked.ptr) if method == "unpack_widths" else (unpacked.ptr, packed.ptr, pbytes)
     with torch.cuda.device(dev):
-        _check(getattr(_lib.load(), f"fl_{ty}_{method}")(w.ptr, o.ptr, first.ptr, second.ptr, n,
+        _check(getattr(_lib.load(), f"fl_{ty}_{method}")(w.ptr, o.ptr, *args, n,
                                                          err.data_ptr() if check else None, _stream(packed)),
                f"fl_{ty}_{method}")
-    if check and int(err.item()) != 0:
-        raise FastLanesError(1, f"fl_{ty}_{method}")            # bitpacking.rs:93,126 unreachable!()
+    if check:
+        _check_flag(err, f"fl_{ty}_{method}")                   # bitpacking.rs:93,126 unreachable!(); :78-80,111-113
 
 
 def unpack_widths(widths, offsets, packed, output=None, check=True):
     """The reference's caller loop `for b: T::unchecked_unpack(widths[b], &packed[offsets[b]..], ..)`
     (bitpacking.rs:109-129) as ONE launch with everything device-resident: `widths` (CUDA uint8, one per
     block), `offsets` (CUDA int64/uint64 byte offsets into `packed`), `packed` (CUDA tensor of the element
-    type).  `check=True` reads the device error flag back (one sync) and raises on a width > T;
-    `check=False` stays asynchronous."""
+    type).  `check=True` reads the device error flag back (one sync) and raises on a width > T, an
+    offset that is not a multiple of 16, or a block that does not lie inside `packed` (the kernel skips such blocks
+    either way); `check=False` stays asynchronous."""
     src = _Arg(packed)
     ty = src.ty
     n = _Arg(widths, "u8").n
@@ -515,17 +542,15 @@ def unpack_single_widths(widths, offsets, packed, index):
         raise TypeError("unpack_single_widths is device tier: pass CUDA tensors")
     if o.n != w.n:
         raise ValueError("offsets must hold one entry per block")
-    idx = index if _is_torch(index) else torch.as_tensor(np.asarray(index, dtype=np.int64).reshape(-1), device=src.x.device)
-    idx = idx.contiguous()
-    assert idx.element_size() == 8
+    idx = _indices(index, src)
     out = torch.empty(idx.numel(), dtype=src.x.dtype, device=src.x.device)
     err = torch.zeros(1, dtype=torch.int32, device=src.x.device)
     with torch.cuda.device(src.x.device):
-        _check(getattr(_lib.load(), f"fl_{ty}_unpack_single_widths")(w.ptr, o.ptr, src.ptr, w.n, idx.data_ptr(), idx.numel(),
-                                                                    out.data_ptr(), err.data_ptr(), _stream(src)),
+        _check(getattr(_lib.load(), f"fl_{ty}_unpack_single_widths")(w.ptr, o.ptr, src.ptr, src.n * (_lib.BITS[ty] // 8), w.n,
+                                                                    idx.data_ptr(), idx.numel(), out.data_ptr(), err.data_ptr(),
+                                                                    _stream(src)),
                f"fl_{ty}_unpack_single_widths")
-    if int(err.item()) != 0:
-        raise FastLanesError(2, f"fl_{ty}_unpack_single_widths")
+    _check_flag(err, f"fl_{ty}_unpack_single_widths")
     return out
 
 
@@ -541,6 +566,10 @@ class MixedWidthPlan:
         self.ty = ty
         w = _check_widths_host(ty, widths)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("a MixedWidthPlan lives on a GPU")
+        if self.device.index is None:        # torch.device('cuda') != torch.device('cuda:0'): pin the index now
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self._plan = ctypes.c_void_p()
         lib = _lib.load()
         with torch.cuda.device(self.device):

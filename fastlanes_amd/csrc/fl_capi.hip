@@ -3,6 +3,7 @@
 // (the reference's `match width`, bitpacking.rs:82-95) and launches it.  No CPU
 // compute path exists in this library: every entry point ends in a HIP launch.
 #include "../../include/fastlanes_amd.h"
+#include "../../include/fastlanes_amd_internal.h"
 #include "fl_kernels.hpp"
 #include "fl_misc.hpp"
 #include "fl_widths.hpp"
@@ -21,7 +22,7 @@ using namespace fl;
 
 thread_local int g_last_hip_error = 0;
 
-// fl_set_kernel_policy: 0 = measured choice (fl_dispatch.hpp), 1 = cell-column kernels only, 2 = wave-per-block
+// fl_internal_set_kernel_policy: 0 = measured choice (fl_dispatch.hpp), 1 = cell-column kernels only, 2 = wave-per-block
 // kernels wherever they exist.  Results are bit-identical; only speed differs.
 std::atomic<int> g_kernel_policy{0};
 
@@ -107,6 +108,7 @@ int run_wave_uniform(bool pack, int waves, unsigned w, const T* packed, T* unpac
     a.tiles_per_xcd = 0;
     a.uniform_width = w;
     a.bpw = 1;
+    a.packed_bytes = 0;      // not read: uniform-width calls are validated here, on the host side
     hipError_t e = widths_launcher<T>(pack)(a, waves, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
@@ -254,18 +256,18 @@ int dev_unpack_single(unsigned w, const T* packed, size_t n_blocks, const uint64
     if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
     if (n_idx == 0) return FL_OK;
     if (!idx || !out || (w != 0 && !packed)) return FL_ERR_NULL;
-    SingleArgs a{packed, idx, out, err_flag, n_blocks, n_idx, w, nullptr, nullptr};
+    SingleArgs a{packed, idx, out, err_flag, n_blocks, n_idx, w, nullptr, nullptr, 0};
     hipError_t e = unpack_single_launch<T>(a, static_cast<hipStream_t>(s));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
 
 template <typename T>
-int dev_unpack_single_widths(const uint8_t* widths, const uint64_t* offsets, const T* packed, size_t n_blocks,
+int dev_unpack_single_widths(const uint8_t* widths, const uint64_t* offsets, const T* packed, size_t packed_bytes, size_t n_blocks,
                              const uint64_t* idx, size_t n_idx, T* out, uint32_t* err_flag, void* s)
 {
     if (n_idx == 0) return FL_OK;
     if (!widths || !offsets || !idx || !out || !packed) return FL_ERR_NULL;
-    SingleArgs a{packed, idx, out, err_flag, n_blocks, n_idx, 0, widths, offsets};
+    SingleArgs a{packed, idx, out, err_flag, n_blocks, n_idx, 0, widths, offsets, packed_bytes};
     hipError_t e = unpack_single_launch<T>(a, static_cast<hipStream_t>(s));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
@@ -290,15 +292,24 @@ struct HostCtx {
     char* pin = nullptr;
     size_t pin_cap = 0;
 
+    // Best effort: runs from fl_host_release() and from the thread_local destructor, i.e. possibly while the process is
+    // tearing down.  If the runtime no longer answers (hipGetDevice fails) or the context's device cannot be made current,
+    // nothing is freed -- leaking at exit is harmless, calling into a torn-down runtime is not.  Long-lived worker
+    // threads should call fl_host_release() themselves before they exit.
     void release()
     {
         if (device < 0) return;
         int cur = -1;
-        const bool switched = hipGetDevice(&cur) == hipSuccess && cur != device && hipSetDevice(device) == hipSuccess;
-        if (stream) (void)hipStreamDestroy(stream);
-        if (dev) (void)hipFree(dev);
-        if (pin) (void)hipHostFree(pin);
-        if (switched) (void)hipSetDevice(cur);
+        bool usable = hipGetDevice(&cur) == hipSuccess;
+        bool switched = false;
+        if (usable && cur != device) usable = switched = hipSetDevice(device) == hipSuccess;
+        if (usable) {
+            if (stream) (void)hipStreamSynchronize(stream);
+            if (stream) (void)hipStreamDestroy(stream);
+            if (dev) (void)hipFree(dev);
+            if (pin) (void)hipHostFree(pin);
+            if (switched) (void)hipSetDevice(cur);
+        }
         stream = nullptr; dev = nullptr; pin = nullptr;
         dev_cap = pin_cap = 0;
         device = -1;
@@ -320,7 +331,11 @@ struct HostCtx {
     hipError_t need_pinned(size_t bytes)
     {
         if (bytes <= pin_cap) return hipSuccess;
-        if (pin) { (void)hipStreamSynchronize(stream); (void)hipHostFree(pin); pin = nullptr; pin_cap = 0; }
+        if (pin) {
+            hipError_t es = hipStreamSynchronize(stream);          // a kernel may still be using the old buffer
+            if (es != hipSuccess) return es;
+            (void)hipHostFree(pin); pin = nullptr; pin_cap = 0;
+        }
         const size_t cap = grown(bytes, pin_cap < 65536 ? 65536 : pin_cap);
         hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&pin), cap, hipHostMallocDefault);
         if (e == hipSuccess) pin_cap = cap; else pin = nullptr;
@@ -329,7 +344,11 @@ struct HostCtx {
     hipError_t need_device(size_t bytes)
     {
         if (bytes <= dev_cap) return hipSuccess;
-        if (dev) { (void)hipStreamSynchronize(stream); (void)hipFree(dev); dev = nullptr; dev_cap = 0; }
+        if (dev) {
+            hipError_t es = hipStreamSynchronize(stream);
+            if (es != hipSuccess) return es;
+            (void)hipFree(dev); dev = nullptr; dev_cap = 0;
+        }
         const size_t cap = grown(bytes, dev_cap);
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&dev), cap);
         if (e == hipSuccess) dev_cap = cap; else dev = nullptr;
@@ -419,7 +438,7 @@ struct fl_mixed_plan {
 namespace {
 
 template <typename T>
-int run_widths(bool pack, const uint8_t* widths, const uint64_t* offsets, const void* packed, void* unpacked,
+int run_widths(bool pack, const uint8_t* widths, const uint64_t* offsets, const void* packed, size_t packed_bytes, void* unpacked,
                size_t n_blocks, uint32_t* err_flag, void* stream)
 {
     if (n_blocks == 0) return FL_OK;
@@ -436,6 +455,7 @@ int run_widths(bool pack, const uint8_t* widths, const uint64_t* offsets, const 
     a.n_blocks = n_blocks;
     a.tiles_per_xcd = 0;
     a.uniform_width = 0;
+    a.packed_bytes = packed_bytes;
     a.bpw = mixed_blocks_per_wave(Elem<T>::BITS);
     int waves = mixed_waves(Elem<T>::BITS, pack);
     const int pol = g_kernel_policy.load(std::memory_order_relaxed);       // A/B tools: 2 + 256*waves + 65536*blocks-per-wavefront
@@ -454,7 +474,7 @@ int run_mixed(bool pack, const fl_mixed_plan* p, const void* packed, void* unpac
     if (!unpacked || (p->packed_bytes && !packed)) return FL_ERR_NULL;
     // widths were validated at plan creation; an all-zero-width column has no packed bytes at all
     static const char dummy[16] __attribute__((aligned(16))) = {0};
-    return run_widths<T>(pack, p->d_widths, p->d_offsets, p->packed_bytes ? packed : dummy, unpacked, p->n_blocks, nullptr, stream);
+    return run_widths<T>(pack, p->d_widths, p->d_offsets, p->packed_bytes ? packed : dummy, p->packed_bytes, unpacked, p->n_blocks, nullptr, stream);
 }
 
 }  // namespace
@@ -504,6 +524,15 @@ int fl_mixed_plan_create(unsigned type_bits, const uint8_t* widths, size_t n_blo
     return FL_OK;
 }
 
+int fl_fill_random(void* dst, size_t n_bytes, uint64_t seed, void* stream)
+{
+    if (n_bytes == 0) return FL_OK;
+    if (!dst) return FL_ERR_NULL;
+    if ((reinterpret_cast<uintptr_t>(dst) & 7u) || (n_bytes & 7u)) return FL_ERR_ALIGN;
+    hipError_t e = launch_fill_random(static_cast<uint64_t*>(dst), n_bytes / 8, seed, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? FL_OK : hip_fail(e);
+}
+
 void fl_mixed_plan_destroy(fl_mixed_plan* p)
 {
     if (!p) return;
@@ -517,10 +546,16 @@ const uint64_t* fl_mixed_plan_offsets(const fl_mixed_plan* p) { return p ? p->d_
 const uint8_t* fl_mixed_plan_widths(const fl_mixed_plan* p) { return p ? p->d_widths : nullptr; }
 
 void fl_host_release(void) { g_host.release(); }
-void fl_set_kernel_policy(int policy) { g_kernel_policy.store(policy < 0 || (policy & 0xff) > 2 ? 0 : policy, std::memory_order_relaxed); }
-int fl_get_kernel_policy(void) { return g_kernel_policy.load(std::memory_order_relaxed); }
+void fl_internal_set_kernel_policy(int policy)
+{
+    const int mode = policy & 0xff, waves = (policy >> 8) & 0xff, bpw = (policy >> 16) & 0xff;
+    const bool ok = policy >= 0 && (policy >> 24) == 0 && mode <= 2 && (waves == 0 || (waves >= 3 && waves <= 8)) && bpw <= 16
+                    && (mode == 2 || (waves == 0 && bpw == 0));
+    g_kernel_policy.store(ok ? policy : 0, std::memory_order_relaxed);
+}
+int fl_internal_get_kernel_policy(void) { return g_kernel_policy.load(std::memory_order_relaxed); }
 
-const char* fl_version(void) { return "fastlanes_amd 0.2.0 (gfx950; wire format of spiraldb/fastlanes 0.1.8)"; }
+const char* fl_version(void) { return "fastlanes_amd 0.3.0 (gfx950; wire format of spiraldb/fastlanes 0.1.8)"; }
 
 const char* fl_status_string(int status)
 {
@@ -529,8 +564,9 @@ const char* fl_status_string(int status)
     case FL_ERR_WIDTH: return "width > T";
     case FL_ERR_INDEX: return "index out of range";
     case FL_ERR_NULL: return "null pointer";
-    case FL_ERR_ALIGN: return "device pointer not 16-byte aligned";
+    case FL_ERR_ALIGN: return "device pointer (or offset / size) not aligned as required";
     case FL_ERR_HIP: return "HIP runtime error";
+    case FL_ERR_BOUNDS: return "block outside the packed column";
     default: return "unknown status";
     }
 }
@@ -572,13 +608,13 @@ size_t fl_packed_len(unsigned type_bits, unsigned width)
     int fl_##S##_untranspose(const T* in, T* out, size_t n, void* s) { return dev_transpose<T>(true, in, out, n, s); } \
     int fl_##S##_unpack_mixed(const fl_mixed_plan* p, const T* pk, T* out, void* s) { return run_mixed<T>(false, p, pk, out, s); } \
     int fl_##S##_pack_mixed(const fl_mixed_plan* p, const T* in, T* pk, void* s) { return run_mixed<T>(true, p, pk, const_cast<T*>(in), s); } \
-    int fl_##S##_unpack_widths(const uint8_t* w, const uint64_t* o, const T* pk, T* out, size_t n, uint32_t* ef, void* s) \
-    { return run_widths<T>(false, w, o, pk, out, n, ef, s); }                                             \
-    int fl_##S##_pack_widths(const uint8_t* w, const uint64_t* o, const T* in, T* pk, size_t n, uint32_t* ef, void* s) \
-    { return run_widths<T>(true, w, o, pk, const_cast<T*>(in), n, ef, s); }                               \
-    int fl_##S##_unpack_single_widths(const uint8_t* w, const uint64_t* o, const T* pk, size_t n, const uint64_t* idx, \
+    int fl_##S##_unpack_widths(const uint8_t* w, const uint64_t* o, const T* pk, size_t pb, T* out, size_t n, uint32_t* ef, void* s) \
+    { return run_widths<T>(false, w, o, pk, pb, out, n, ef, s); }                                         \
+    int fl_##S##_pack_widths(const uint8_t* w, const uint64_t* o, const T* in, T* pk, size_t pb, size_t n, uint32_t* ef, void* s) \
+    { return run_widths<T>(true, w, o, pk, pb, const_cast<T*>(in), n, ef, s); }                           \
+    int fl_##S##_unpack_single_widths(const uint8_t* w, const uint64_t* o, const T* pk, size_t pb, size_t n, const uint64_t* idx, \
                                       size_t ni, T* out, uint32_t* ef, void* s)                           \
-    { return dev_unpack_single_widths<T>(w, o, pk, n, idx, ni, out, ef, s); }                             \
+    { return dev_unpack_single_widths<T>(w, o, pk, pb, n, idx, ni, out, ef, s); }                         \
     int fl_##S##_pack_host(unsigned w, const T* in, T* out, size_t n)                                     \
     {                                                                                                     \
         if (w > sizeof(T) * 8) return FL_ERR_WIDTH;                                                       \

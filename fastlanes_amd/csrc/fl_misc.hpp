@@ -82,7 +82,14 @@ struct SingleArgs {
     // mixed-width columns: per-block widths[] / byte offsets[] in HBM (nullptr = every block has `width`, back to back)
     const uint8_t* widths;
     const uint64_t* offsets;
+    uint64_t packed_bytes;    // size of the packed column (only read when widths != nullptr)
 };
+
+// FL_DEVERR_* of include/fastlanes_amd.h (same values as fl_widths.hpp's DEVERR_*)
+__device__ __forceinline__ void single_error(const SingleArgs& a, uint32_t bits)
+{
+    if (a.err_flag) __hip_atomic_fetch_or(a.err_flag, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // bitpacking.rs:132-179 with the lookup tables of :207-232 computed in closed form.
 template <typename T>
@@ -97,20 +104,29 @@ __global__ __launch_bounds__(WG) void k_unpack_single(SingleArgs a)
     const uint64_t blk = gi >> 10;
     if (a.widths && blk >= a.n_blocks) {                      // bitpacking.rs:152 (before the width is known)
         out[k] = 0;
-        if (a.err_flag) *a.err_flag = 1u;
+        single_error(a, 2u /* FL_DEVERR_INDEX */);
         return;
     }
     const unsigned W = a.widths ? (unsigned)a.widths[blk] : a.width;
     if (W > TB) {                                             // bitpacking.rs:197 unreachable!()
         out[k] = 0;
-        if (a.err_flag) *a.err_flag = 1u;
+        single_error(a, 1u /* FL_DEVERR_WIDTH */);
         return;
     }
     if (W == 0) { out[k] = 0; return; }                       // bitpacking.rs:136-139
     if (blk >= a.n_blocks) {                                  // bitpacking.rs:152
         out[k] = 0;
-        if (a.err_flag) *a.err_flag = 1u;
+        single_error(a, 2u /* FL_DEVERR_INDEX */);
         return;
+    }
+    if (a.widths) {                                           // bitpacking.rs:185-186 debug_assert on the packed length
+        const uint64_t off = a.offsets[blk];
+        const uint32_t e = ((off & (sizeof(T) - 1)) ? 4u : 0u) | ((off > a.packed_bytes || 128ull * W > a.packed_bytes - off) ? 8u : 0u);
+        if (e) {
+            out[k] = 0;
+            single_error(a, e);
+            return;
+        }
     }
     const unsigned index = (unsigned)gi & 1023u;
     const unsigned lane = index % LANES;                      // bitpacking.rs:210

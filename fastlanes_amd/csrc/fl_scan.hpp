@@ -66,7 +66,7 @@ __global__ __launch_bounds__(WG) void k_scan_local(ScanArgs a)
         bad |= w[e] > a.type_bits;
         sum += 128ull * w[e];
     }
-    if (bad && a.err_flag) *a.err_flag = 1u;
+    if (bad && a.err_flag) __hip_atomic_fetch_or(a.err_flag, 1u /* FL_DEVERR_WIDTH */, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint64_t total;
     uint64_t run = wg_excl_scan(sum, &total);
     for (int e = 0; e < SCAN_PER_THREAD; ++e) {
@@ -109,6 +109,32 @@ inline hipError_t launch_widths_to_offsets(const ScanArgs& a, hipStream_t s)
     hipLaunchKernelGGL(k_scan_local, dim3(n_chunks), dim3(WG), 0, s, a);
     hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(WG), 0, s, a);
     hipLaunchKernelGGL(k_scan_add, dim3(n_chunks), dim3(WG), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// fl_fill_random: counter-based test / benchmark data generated in HBM (SURVEY.md 8(d) "value distribution / seeds":
+// splitmix64 of the global index, so a host can regenerate any part of the stream without a PCIe transfer).
+// 64-bit word i = splitmix64 output number i+1 of the generator seeded with seed * GOLDEN -- the stream
+// tests/datagen.py and the oracle's parallel fill produce.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_fill_splitmix64(uint64_t* dst, uint64_t n_words, uint64_t seed)
+{
+    const uint64_t GOLDEN = 0x9E3779B97F4A7C15ull;
+    const uint64_t stride = (uint64_t)gridDim.x * WG;
+    for (uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x; i < n_words; i += stride) {
+        uint64_t z = seed * GOLDEN + (i + 1) * GOLDEN;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        __builtin_nontemporal_store(z ^ (z >> 31), dst + i);
+    }
+}
+
+inline hipError_t launch_fill_random(uint64_t* dst, uint64_t n_words, uint64_t seed, hipStream_t s)
+{
+    if (n_words == 0) return hipSuccess;
+    const uint64_t want = (n_words + WG - 1) / WG;
+    hipLaunchKernelGGL(k_fill_splitmix64, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(WG), 0, s, dst, n_words, seed);
     return hipGetLastError();
 }
 

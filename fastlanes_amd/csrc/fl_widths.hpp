@@ -31,13 +31,14 @@ struct WidthsArgs {
     char* unpacked;            // unpacked column base
     const uint8_t* widths;     // [n_blocks]; nullptr = every block has `uniform_width`
     const uint64_t* offsets;   // [n_blocks] byte offsets into `packed`; nullptr = b * 128 * uniform_width
-    uint32_t* err_flag;        // set to 1 if some widths[b] > T (that block is skipped); may be nullptr
+    uint32_t* err_flag;        // FL_DEVERR_* bits ORed in for every block that had to be skipped; may be nullptr
     const void* refs;          // FoR: references[b * ref_stride] (ffor.rs:24-50); nullptr = plain BitPacking
     uint64_t ref_stride;
     uint64_t n_blocks;
     uint64_t tiles_per_xcd;
     unsigned uniform_width;
     unsigned bpw;              // consecutive blocks per wavefront (>= 1); a workgroup takes 4*bpw blocks
+    uint64_t packed_bytes;     // size of the packed column: a block must lie inside [0, packed_bytes) (only read when widths != nullptr)
 };
 
 template <typename T> struct WaveBlock {
@@ -120,6 +121,27 @@ __device__ __forceinline__ uint64_t wave_uniform_u64(uint64_t v)
     return ((uint64_t)hi << 32) | lo;
 }
 
+// Device-side error bits (include/fastlanes_amd.h: FL_DEVERR_*).  A block that violates a precondition is SKIPPED and its
+// bit is ORed into *err_flag -- the device-side form of the reference's unreachable!() / debug_assert (bitpacking.rs:78-80,93,126).
+constexpr uint32_t DEVERR_WIDTH = 1u, DEVERR_INDEX = 2u, DEVERR_ALIGN = 4u, DEVERR_BOUNDS = 8u;
+
+// 0 if block `blk` of a mixed-width column may be processed, else its error bits (wave-uniform; uniform-width calls pass
+// widths == nullptr and are validated on the host side of the ABI)
+__device__ __forceinline__ uint32_t block_precondition(const WidthsArgs& a, unsigned w, uint64_t off, unsigned type_bits)
+{
+    if (w > type_bits) return DEVERR_WIDTH;                                    // bitpacking.rs:93,126 unreachable!()
+    if (!a.widths) return 0u;
+    uint32_t e = 0u;
+    if (off & 15u) e |= DEVERR_ALIGN;                                           // 16-byte cells: the header's precondition
+    if (off > a.packed_bytes || 128ull * w > a.packed_bytes - off) e |= DEVERR_BOUNDS;   // bitpacking.rs:78-80,111-113
+    return e;
+}
+
+__device__ __forceinline__ void raise_device_error(uint32_t* err_flag, uint32_t bits, unsigned lane)
+{
+    if (err_flag && lane == 0) __hip_atomic_fetch_or(err_flag, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // widths[blk] and offsets[blk] of the wavefront's block: two independent vector loads in flight together, one
 // wait, then broadcast to SGPRs (wave-uniform) -- instead of a byte load, a wait, a dependent scalar load, a wait.
 __device__ __forceinline__ void block_meta(const WidthsArgs& a, uint64_t blk, unsigned& w, uint64_t& off)
@@ -159,8 +181,8 @@ __device__ __forceinline__ void unpack_block_wave(const WidthsArgs& a, uint64_t 
     unsigned w;
     uint64_t off;
     block_meta(a, blk, w, off);                               // wave-uniform
-    if (w > (unsigned)TB) {                                   // bitpacking.rs:126 unreachable!()
-        if (a.err_flag && lane == 0) *a.err_flag = 1u;
+    if (const uint32_t e = block_precondition(a, w, off, TB)) {   // bitpacking.rs:126 unreachable!(), :111-113
+        raise_device_error(a.err_flag, e, lane);
         return;
     }
     const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -349,8 +371,8 @@ __device__ __forceinline__ void pack_block_wave(const WidthsArgs& a, uint64_t bl
     unsigned w;
     uint64_t off;
     block_meta(a, blk, w, off);                               // wave-uniform
-    if (w > (unsigned)TB) {                                   // bitpacking.rs:93 unreachable!()
-        if (a.err_flag && lane == 0) *a.err_flag = 1u;
+    if (const uint32_t e = block_precondition(a, w, off, TB)) {   // bitpacking.rs:93 unreachable!(), :78-80
+        raise_device_error(a.err_flag, e, lane);
         return;
     }
     if (w == 0) return;                                       // macros.rs:52-53: W == 0 writes nothing

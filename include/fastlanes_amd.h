@@ -64,9 +64,21 @@ typedef enum fl_status {
     FL_ERR_WIDTH = 1,   /* width > T              (bitpacking.rs:93 unreachable!) */
     FL_ERR_INDEX = 2,   /* index >= 1024*n_blocks (bitpacking.rs:152 assert!)      */
     FL_ERR_NULL = 3,    /* required pointer is NULL                                */
-    FL_ERR_ALIGN = 4,   /* device pointer not 16-byte aligned                      */
-    FL_ERR_HIP = 5      /* HIP runtime error; see fl_last_hip_error()              */
+    FL_ERR_ALIGN = 4,   /* device pointer not 16-byte aligned (fl_fill_random: 8)  */
+    FL_ERR_HIP = 5,     /* HIP runtime error; see fl_last_hip_error()              */
+    FL_ERR_BOUNDS = 6   /* a block's bytes lie outside the packed column           */
 } fl_status;
+
+/* Device-side error bits.  The device tier never synchronises, so what the reference reports by panicking in the middle
+ * of a caller loop (bitpacking.rs:93,126,152,197 and the debug_asserts on lengths :78-80,111-113,185-186) is reported
+ * through *err_flag (a device uint32 the caller zeroes; may be NULL): the offending block / index is SKIPPED (a lookup
+ * writes 0) and its bit is ORed in. */
+enum {
+    FL_DEVERR_WIDTH = 1,   /* widths[b] > T                                              -> FL_ERR_WIDTH  */
+    FL_DEVERR_INDEX = 2,   /* lookup index >= 1024*n_blocks                              -> FL_ERR_INDEX  */
+    FL_DEVERR_ALIGN = 4,   /* offsets[b] not a multiple of 16 (lookups: of sizeof(T))    -> FL_ERR_ALIGN  */
+    FL_DEVERR_BOUNDS = 8   /* offsets[b] + 128*widths[b] > packed_bytes                  -> FL_ERR_BOUNDS */
+};
 
 /* predicates of fl_<ty>_unpack_compare (unsigned comparison with a constant) */
 typedef enum fl_cmp { FL_CMP_EQ = 0, FL_CMP_NE = 1, FL_CMP_LT = 2, FL_CMP_LE = 3, FL_CMP_GT = 4, FL_CMP_GE = 5 } fl_cmp;
@@ -81,17 +93,17 @@ size_t fl_packed_len(unsigned type_bits, unsigned width);
 /* The host tier keeps one cached context per calling thread (a private stream, a pinned staging
  * buffer, a device scratch buffer; see "HOST tier" above) so that its calls allocate nothing after
  * the first one, like the allocation-free reference (lib.rs:3).  It is freed at thread exit; this
- * frees the calling thread's context early. */
+ * frees the calling thread's context early (long-lived worker threads should call it before they exit: at process
+ * teardown the destructor frees nothing if the HIP runtime no longer answers). */
 void fl_host_release(void);
-/* Two kernel designs serve uniform-width pack / unpack / for_pack / unfor_pack and produce identical
- * bytes: per-(T,W) "cell-column" kernels and runtime-width "wave-per-block" kernels (the ones the
- * mixed-width entry points use).  By default each (T, W, direction) runs the one measured faster
- * (fastlanes_amd/csrc/fl_dispatch.hpp).  For A/B measurements and for testing both designs on every
- * (T, W): policy 0 = automatic, 1 = cell-column only, 2 = wave-per-block wherever it exists
- * (pack, unpack, for_pack, unfor_pack, undelta_pack, delta, undelta); 2 + 256*n additionally runs those
- * kernels at n wavefronts per SIMD, + 65536*m the mixed-width kernels at m blocks per wavefront (A/B tools).  Process-wide; affects speed only. */
-void fl_set_kernel_policy(int policy);
-int fl_get_kernel_policy(void);
+/* (The kernel-selection override used by the parity tests and the A/B tools is NOT part of this interface:
+ * include/fastlanes_amd_internal.h.) */
+
+/* Test / benchmark data generated in HBM (not a reference function; SURVEY.md 8(d) asks for a counter-based generator
+ * so that a host can regenerate any part of a device-resident column without a PCIe transfer): 64-bit word i of dst =
+ * output number i+1 of splitmix64 seeded with seed * 0x9E3779B97F4A7C15.  dst 8-byte aligned, n_bytes a multiple of 8
+ * (FL_ERR_ALIGN otherwise).  Asynchronous on `stream`. */
+int fl_fill_random(void *dst, size_t n_bytes, uint64_t seed, void *stream);
 
 /*
  * Mixed-width columns (BASELINE.json config 5): block b has its own width widths[b].
@@ -104,13 +116,16 @@ int fl_get_kernel_policy(void);
  *                                (multiples of 16; back-to-back blocks give multiples of 128)
  * read by the kernel itself (fl_<ty>_unpack_widths / fl_<ty>_pack_widths below): one wavefront per
  * block, blocks in column order, ONE launch, no host pass over the column, no allocation, any
- * block count.  A block whose width exceeds T is skipped and *err_flag (a device uint32, may be
- * NULL) is set to 1 -- the device-side form of bitpacking.rs:93/126 unreachable!().
+ * block count.  `packed_bytes` is the size of the packed column.  The kernel checks every block's
+ * preconditions itself: a block whose width exceeds T, whose offset is not a multiple of 16, or whose
+ * 128*widths[b] bytes do not lie inside [0, packed_bytes) is SKIPPED (nothing is read or written for
+ * it) and its FL_DEVERR_* bit is ORed into *err_flag -- the device-side form of bitpacking.rs:93/126
+ * unreachable!() and of the length debug_asserts (:78-80, :111-113).
  *
  * fl_widths_to_offsets builds the back-to-back offsets on the device: offsets[b] = sum_{i<b}
  * 128*widths[i] (exclusive prefix sum, three small launches on `stream`, no scratch memory),
- * *total_bytes (device uint64, may be NULL) = the packed column's size, *err_flag set to 1 if
- * some width exceeds type_bits.
+ * *total_bytes (device uint64, may be NULL) = the packed column's size, FL_DEVERR_WIDTH ORed into
+ * *err_flag if some width exceeds type_bits.
  */
 int fl_widths_to_offsets(unsigned type_bits, const uint8_t *widths, size_t n_blocks,
                          uint64_t *offsets, uint64_t *total_bytes, uint32_t *err_flag,
@@ -142,8 +157,8 @@ const uint8_t *fl_mixed_plan_widths(const fl_mixed_plan *plan);
     /* BitPacking::unchecked_unpack_single (bitpacking.rs:58,181-200) -> unpack_single::<W>    \
      * (:132-179), batched: out[k] = value at element indices[k] of the column, where          \
      * indices[k] = block*1024 + index_in_block.  Out-of-range indices make the call return    \
-     * FL_ERR_INDEX on the host tier; on the device tier they write 0 and set *err_flag        \
-     * (a device uint32, may be NULL) to 1. */                                                 \
+     * FL_ERR_INDEX on the host tier; on the device tier they write 0 and OR FL_DEVERR_INDEX   \
+     * into *err_flag (a device uint32, may be NULL). */                                       \
     int fl_##S##_unpack_single(unsigned width, const T *packed, size_t n_blocks,                \
                                const uint64_t *indices, size_t n_indices, T *out,               \
                                uint32_t *err_flag, void *stream);                               \
@@ -192,15 +207,18 @@ const uint8_t *fl_mixed_plan_widths(const fl_mixed_plan *plan);
     /* unchecked_unpack / unchecked_pack (bitpacking.rs:109-129, :76-96) looped over blocks with    \
      * per-block device widths[] / offsets[] (see "Mixed-width columns" above) */                  \
     int fl_##S##_unpack_widths(const uint8_t *widths, const uint64_t *offsets, const T *packed,  \
-                               T *out, size_t n_blocks, uint32_t *err_flag, void *stream);       \
+                               size_t packed_bytes, T *out, size_t n_blocks, uint32_t *err_flag,  \
+                               void *stream);                                                    \
     int fl_##S##_pack_widths(const uint8_t *widths, const uint64_t *offsets, const T *in,        \
-                             T *packed, size_t n_blocks, uint32_t *err_flag, void *stream);      \
+                             T *packed, size_t packed_bytes, size_t n_blocks, uint32_t *err_flag, \
+                             void *stream);                                                      \
     /* unchecked_unpack_single (bitpacking.rs:58,181-200) over such a column, batched: out[k] = element  \
-     * indices[k] (= block*1024 + index_in_block) of the column; an index past the column or a width  \
-     * > T writes 0 and sets *err_flag */                                                           \
+     * indices[k] (= block*1024 + index_in_block) of the column; an index past the column, a width  \
+     * > T or a block outside the packed column writes 0 and ORs its FL_DEVERR_* bit into *err_flag */ \
     int fl_##S##_unpack_single_widths(const uint8_t *widths, const uint64_t *offsets,            \
-                                      const T *packed, size_t n_blocks, const uint64_t *indices,  \
-                                      size_t n_indices, T *out, uint32_t *err_flag, void *stream); \
+                                      const T *packed, size_t packed_bytes, size_t n_blocks,      \
+                                      const uint64_t *indices, size_t n_indices, T *out,          \
+                                      uint32_t *err_flag, void *stream);                          \
     /* the same over a mixed-width plan (see fl_mixed_plan) */                                     \
     int fl_##S##_unpack_mixed(const fl_mixed_plan *plan, const T *packed, T *out, void *stream); \
     int fl_##S##_pack_mixed(const fl_mixed_plan *plan, const T *in, T *packed, void *stream);    \

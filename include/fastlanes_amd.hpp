@@ -244,20 +244,21 @@ private:
 };
 
 // The same loop with the per-block widths / byte offsets already resident in HBM:
-// nothing is built on the host.  A width > T skips that block and sets *d_err_flag (device uint32, may be null).
+// nothing is built on the host.  A block with a width > T, a misaligned offset or bytes outside [0, packed_bytes) is skipped and its
+// FL_DEVERR_* bit is ORed into *d_err_flag (device uint32, may be null).
 template <typename T>
-inline void unpack_widths_device(const std::uint8_t* d_widths, const std::uint64_t* d_offsets, const T* d_packed, T* d_out,
+inline void unpack_widths_device(const std::uint8_t* d_widths, const std::uint64_t* d_offsets, const T* d_packed, std::size_t packed_bytes, T* d_out,
                                  std::size_t n_blocks, std::uint32_t* d_err_flag = nullptr, void* stream = nullptr)
-{ detail::check(detail::Abi<T>::unpack_widths(d_widths, d_offsets, d_packed, d_out, n_blocks, d_err_flag, stream), "unpack_widths"); }
+{ detail::check(detail::Abi<T>::unpack_widths(d_widths, d_offsets, d_packed, packed_bytes, d_out, n_blocks, d_err_flag, stream), "unpack_widths"); }
 template <typename T>
-inline void pack_widths_device(const std::uint8_t* d_widths, const std::uint64_t* d_offsets, const T* d_in, T* d_packed,
+inline void pack_widths_device(const std::uint8_t* d_widths, const std::uint64_t* d_offsets, const T* d_in, T* d_packed, std::size_t packed_bytes,
                                std::size_t n_blocks, std::uint32_t* d_err_flag = nullptr, void* stream = nullptr)
-{ detail::check(detail::Abi<T>::pack_widths(d_widths, d_offsets, d_in, d_packed, n_blocks, d_err_flag, stream), "pack_widths"); }
+{ detail::check(detail::Abi<T>::pack_widths(d_widths, d_offsets, d_in, d_packed, packed_bytes, n_blocks, d_err_flag, stream), "pack_widths"); }
 template <typename T>
-inline void unpack_single_widths_device(const std::uint8_t* d_widths, const std::uint64_t* d_offsets, const T* d_packed,
+inline void unpack_single_widths_device(const std::uint8_t* d_widths, const std::uint64_t* d_offsets, const T* d_packed, std::size_t packed_bytes,
                                         std::size_t n_blocks, const std::uint64_t* d_indices, std::size_t n_indices, T* d_out,
                                         std::uint32_t* d_err_flag = nullptr, void* stream = nullptr)
-{ detail::check(detail::Abi<T>::unpack_single_widths(d_widths, d_offsets, d_packed, n_blocks, d_indices, n_indices, d_out, d_err_flag, stream), "unpack_single_widths"); }
+{ detail::check(detail::Abi<T>::unpack_single_widths(d_widths, d_offsets, d_packed, packed_bytes, n_blocks, d_indices, n_indices, d_out, d_err_flag, stream), "unpack_single_widths"); }
 template <typename T>
 inline void widths_to_offsets_device(const std::uint8_t* d_widths, std::size_t n_blocks, std::uint64_t* d_offsets,
                                      std::uint64_t* d_total_bytes = nullptr, std::uint32_t* d_err_flag = nullptr, void* stream = nullptr)

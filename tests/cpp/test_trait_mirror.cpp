@@ -216,8 +216,8 @@ static void test_device_tier()
     DevVec<uint32_t> derr(1), dm2(plan.packed_bytes() / 4), dmu2(N * 1024);
     (void)hipMemset(derr.p, 0, 4);
     widths_to_offsets_device<uint32_t>(dw.p, N, doff.p, dtot.p, derr.p);
-    pack_widths_device<uint32_t>(dw.p, doff.p, dv.p, dm2.p, N, derr.p);
-    unpack_widths_device<uint32_t>(dw.p, doff.p, dm2.p, dmu2.p, N, derr.p);
+    pack_widths_device<uint32_t>(dw.p, doff.p, dv.p, dm2.p, plan.packed_bytes(), N, derr.p);
+    unpack_widths_device<uint32_t>(dw.p, doff.p, dm2.p, plan.packed_bytes(), dmu2.p, N, derr.p);
     EXPECT(dtot.down()[0] == plan.packed_bytes());
     EXPECT(dm2.down() == dm.down());
     EXPECT(dmu2.down() == v);

@@ -24,14 +24,16 @@ def _header_symbols():
     body = text.split("#define FL_DECLARE_TYPE(T, S)")[1].split("FL_DECLARE_TYPE(uint8_t, u8)")[0]
     per_type = re.findall(r"fl_##S##_(\w+)\(", body)
     syms = [f"fl_{ty}_{m}" for ty in ("u8", "u16", "u32", "u64") for m in per_type]
-    syms += re.findall(r"\b(fl_(?:version|status_string|last_hip_error|packed_len|widths_to_offsets|host_release|[sg]et_kernel_policy|mixed_plan_\w+))\(", text)
+    # every other function either header names (a name followed by "(", in a declaration or in a comment about one)
+    for h in ("fastlanes_amd.h", "fastlanes_amd_internal.h"):
+        syms += re.findall(r"\b(fl_[a-z][a-z0-9_]*)\(", open(os.path.join(ROOT, "include", h)).read())
     return sorted(set(syms))
 
 
 def test_every_declared_symbol_is_exported(lib):
     import fastlanes_amd
     syms = _header_symbols()
-    assert len(syms) == 4 * 30 + 14
+    assert len(syms) == 4 * 30 + 15
     assert sorted(fastlanes_amd.exported_symbols()) == syms
     for s in syms:
         assert hasattr(lib, s), s
@@ -61,6 +63,30 @@ def test_width_validation_needs_no_gpu(lib):
         assert getattr(lib, f"fl_{ty}_unpack")(3, p, p, 0, None) == 0            # empty column
         v = (ctypes.c_uint64 * 1)()
         assert getattr(lib, f"fl_{ty}_unpack_single_host")(3, p, 1, 1024, v) == 2  # bitpacking.rs:152
+
+
+def test_internal_kernel_policy_is_validated(lib):
+    """include/fastlanes_amd_internal.h: mode 0..2, waves 0 or 3..8 and blocks-per-wave 0..16 (mode 2 only); anything
+    else resets to 0 -- a stray value must not select a kernel shape that was never tested."""
+    try:
+        for ok in (0, 1, 2, 2 + 256 * 3, 2 + 256 * 8, 2 + 65536 * 16, 2 + 256 * 6 + 65536 * 8):
+            lib.fl_internal_set_kernel_policy(ok)
+            assert lib.fl_internal_get_kernel_policy() == ok
+        for bad in (-1, 3, 255, 2 + 256 * 2, 2 + 256 * 9, 2 + 65536 * 17, 1 + 256 * 4, 65536 * 2, 1 << 24, 2 + (1 << 30)):
+            lib.fl_internal_set_kernel_policy(bad)
+            assert lib.fl_internal_get_kernel_policy() == 0, bad
+    finally:
+        lib.fl_internal_set_kernel_policy(0)
+
+
+def test_fill_random_validation_needs_no_gpu(lib):
+    buf = np.zeros(16, dtype=np.uint64)
+    p = buf.ctypes.data
+    assert lib.fl_fill_random(None, 0, 1, None) == 0            # empty
+    assert lib.fl_fill_random(None, 64, 1, None) == 3           # FL_ERR_NULL
+    assert lib.fl_fill_random(p + 4, 64, 1, None) == 4          # FL_ERR_ALIGN: 8-byte words
+    assert lib.fl_fill_random(p, 60, 1, None) == 4
+    assert lib.fl_status_string(6) == b"block outside the packed column"
 
 
 def test_python_mirror_raises_like_the_reference():

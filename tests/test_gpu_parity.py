@@ -47,14 +47,14 @@ def to_np(t, ty):
 # ---------------------------------------------------------------------------
 @pytest.fixture
 def kernel_policy(fl):
-    """fl_set_kernel_policy for one test, restored afterwards (0 automatic, 1 cell-column kernels, 2 wave-per-block)."""
+    """fl_internal_set_kernel_policy for one test, restored afterwards (0 automatic, 1 cell-column kernels, 2 wave-per-block)."""
     lib = fl.load()
 
     def set_policy(p):
-        lib.fl_set_kernel_policy(p)
-        assert lib.fl_get_kernel_policy() == p
+        lib.fl_internal_set_kernel_policy(p)
+        assert lib.fl_internal_get_kernel_policy() == p
     yield set_policy
-    lib.fl_set_kernel_policy(0)
+    lib.fl_internal_set_kernel_policy(0)
 
 
 @pytest.mark.parametrize("policy", [0, 1, 2])
@@ -361,6 +361,15 @@ def test_mixed_width_plan_vs_oracle(fl, oracle, ty):
         plan.close()
     with pytest.raises(fl.FastLanesError):                               # bitpacking.rs:93
         fl.MixedWidthPlan(ty, np.array([T + 1], dtype=np.uint8))
+    # an index-less device name means the current device (torch.device('cuda') != torch.device('cuda:0'))
+    for name in ("cuda", "cuda:0", torch.device("cuda")):
+        plan = fl.MixedWidthPlan(ty, np.full(4, 3, dtype=np.uint8), device=name)
+        pk = to_dev(values(ty, 4 * packed_len(ty, 3), 12))
+        assert plan.unpack(pk).device == torch.device("cuda", 0)
+        assert torch.equal(plan.pack(plan.unpack(pk)).view(torch.uint8), pk.view(torch.uint8))
+        plan.close()
+    with pytest.raises(ValueError):
+        fl.MixedWidthPlan(ty, np.full(4, 3, dtype=np.uint8), device="cpu")
 
 
 @pytest.mark.parametrize("ty", TYS)
@@ -435,6 +444,47 @@ def test_unpack_pack_widths_device_resident(fl, oracle, ty):
     g = to_np(out, ty)
     assert np.array_equal(g[:7 * 1024], want[:7 * 1024]) and np.array_equal(g[8 * 1024:], want[8 * 1024:])
     assert not g[7 * 1024:8 * 1024].any()
+    # the kernels check every block's preconditions themselves (include/fastlanes_amd.h FL_DEVERR_*): a misaligned offset
+    # (not a multiple of 16) or a block that does not lie inside the packed column is SKIPPED and flagged -- nothing is
+    # read or written for it, every other block is processed (bitpacking.rs:78-80,111-113 debug_asserts, device-side)
+    for what, status, mutate in (("misaligned", 4, lambda o: o.__setitem__(5, o[5] + 8)),
+                                 ("past the end", 6, lambda o: o.__setitem__(5, total - 64)),
+                                 ("far outside", 6, lambda o: o.__setitem__(5, 1 << 40))):
+        boff = off.copy()
+        mutate(boff)
+        dboff = torch.from_numpy(boff).cuda()
+        with pytest.raises(fl.FastLanesError) as ei:
+            fl.unpack_widths(dw, dboff, to_dev(col))
+        assert ei.value.status == status, what
+        out = torch.zeros(n * 1024, dtype=tdt, device="cuda:0")
+        fl.unpack_widths(dw, dboff, to_dev(col), output=out, check=False)
+        g = to_np(out, ty)
+        assert np.array_equal(g[:5 * 1024], want[:5 * 1024]) and np.array_equal(g[6 * 1024:], want[6 * 1024:]), what
+        assert not g[5 * 1024:6 * 1024].any(), what
+        guard2 = guard.clone()
+        with pytest.raises(fl.FastLanesError) as ei:
+            fl.pack_widths(dw, dboff, to_dev(v), guard2)
+        assert ei.value.status == status, what
+        after2 = to_np(guard2, ty)
+        lo5, k5 = off[5] // esz, packed_len(ty, int(widths[5]))
+        keep = np.ones(after.size, dtype=bool)          # block 5 was written nowhere; every other byte as in the good run
+        keep[lo5:lo5 + k5] = False
+        assert np.array_equal(after2[keep], after[keep]), what
+        assert np.array_equal(after2[lo5:lo5 + k5], before[lo5:lo5 + k5]), what
+        if what != "misaligned":     # a lookup only needs element alignment
+            with pytest.raises(fl.FastLanesError) as ei:
+                fl.unpack_single_widths(dw, dboff, to_dev(col), torch.tensor([5 * 1024 + 9], dtype=torch.int64).cuda())
+            assert ei.value.status == 6, what
+    # an undersized packed tensor: the blocks that do not fit are skipped, not read out of bounds
+    short = to_dev(col[:(total - int(sizes[0])) // esz + 1])                # block 0 lives at the END of the reversed column
+    with pytest.raises(fl.FastLanesError) as ei:
+        fl.unpack_widths(dw, doff, short)
+    assert ei.value.status == 6
+    # indices must be integer tensors of the same device (a float64 tensor has 8-byte elements too)
+    with pytest.raises(TypeError):
+        fl.unpack_single_widths(dw, doff, to_dev(col), torch.tensor([1.0], dtype=torch.float64).cuda())
+    with pytest.raises(TypeError):
+        fl.unpack_single_widths(dw, doff, to_dev(col), torch.tensor([1], dtype=torch.int64))
     # empty column
     e8 = torch.empty(0, dtype=torch.uint8, device="cuda:0")
     o0, t0 = fl.widths_to_offsets(ty, e8)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B on the GPU box: Delta's kernels (undelta_pack, undelta, delta) through the cell-column kernels vs the
 wave-per-block chain kernels (fl_chain.hpp) at several occupancies, interleaved on the SAME buffers via
-fl_set_kernel_policy (1 = cell-column; 2 + 256*n = wave-per-block at n waves/SIMD).  GB/s of algorithmic bytes."""
+fl_internal_set_kernel_policy (1 = cell-column; 2 + 256*n = wave-per-block at n waves/SIMD).  GB/s of algorithmic bytes."""
 import os
 import sys
 
@@ -42,10 +42,10 @@ for ty, W in cases:
         ops["delta"] = (lambda: fl.Delta.delta(un, bases, output=out), n * (256 * T + 128))
     for name, (f, nbytes) in ops.items():
         res_t = pk_out if name == "transp_delta_pack" else out
-        lib.fl_set_kernel_policy(1)
+        lib.fl_internal_set_kernel_policy(1)
         f()
         ref = res_t.clone()
-        lib.fl_set_kernel_policy(2)
+        lib.fl_internal_set_kernel_policy(2)
         f()
         same = torch.equal(ref.view(torch.uint8), res_t.view(torch.uint8))
         del ref
@@ -53,7 +53,7 @@ for ty, W in cases:
         pols = [1] + [2 + 256 * w for w in WAVES]
         for _ in range(ROUNDS):
             for p in pols:
-                lib.fl_set_kernel_policy(p)
+                lib.fl_internal_set_kernel_policy(p)
                 f()
                 torch.cuda.synchronize()
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -62,5 +62,5 @@ for ty, W in cases:
                 res.setdefault(p, []).append(a.elapsed_time(b))
         g = [nbytes / sorted(res[p])[len(res[p]) // 2] / 1e6 for p in pols]
         print(f"{ty:3s} W={W:<2d} {name:17s}{'' if same else ' MISMATCH'} | cc {g[0]:6.0f}  wpb " + " ".join(f"{x:6.0f}" for x in g[1:]), flush=True)
-    lib.fl_set_kernel_policy(0)
+    lib.fl_internal_set_kernel_policy(0)
     del pk, un, out, bases

@@ -126,7 +126,7 @@ int main(int argc, char** argv)
         printf("device scan: total %s, offsets %s\n", h_total == pbytes ? "ok" : "WRONG", a == b ? "identical to the host plan" : "DIFFERENT");
     }
 
-    WidthsArgs wa{packed, out_new, d_w, d_off, d_err, nullptr, 0, n, 0, 0, 1};
+    WidthsArgs wa{packed, out_new, d_w, d_off, d_err, nullptr, 0, n, 0, 0, 1, pbytes};
     // correctness: plan kernel (shipped in round 1, parity-tested) vs every new shape
     FLCK(fl_u32_unpack_mixed(plan, (const uint32_t*)packed, (uint32_t*)out_ref, nullptr));
     CK(hipDeviceSynchronize());
@@ -141,7 +141,7 @@ int main(int argc, char** argv)
     check("wave-per-block, 3 waves/SIMD", [&] { launch_v<uint32_t>(wa, 3); });
     // pack round trip: pack_widths(unpack) must reproduce the packed column where the values fit
     {
-        WidthsArgs pa{repacked, out_ref, d_w, d_off, d_err, nullptr, 0, n, 0, 0, 1};
+        WidthsArgs pa{repacked, out_ref, d_w, d_off, d_err, nullptr, 0, n, 0, 0, 1, pbytes};
         CK(hipMemset(repacked, 0x5A, pbytes));
         launch_p<uint32_t>(pa, 6);
         CK(hipDeviceSynchronize());
@@ -158,7 +158,7 @@ int main(int argc, char** argv)
     add("library fl_u32_unpack_mixed", [=] { fl_u32_unpack_mixed(plan, (const uint32_t*)packed, (uint32_t*)out_ref, nullptr); }, bytes);
     for (int wv : {3, 4, 5, 6, 8}) add("wave-per-block, " + std::to_string(wv) + " waves/SIMD", [=] { launch_v<uint32_t>(wa, wv); }, bytes);
     {
-        WidthsArgs pa{repacked, out_ref, d_w, d_off, d_err, nullptr, 0, n, 0, 0, 1};
+        WidthsArgs pa{repacked, out_ref, d_w, d_off, d_err, nullptr, 0, n, 0, 0, 1, pbytes};
         for (int wv : {3, 4, 5, 6, 8}) add("pack_widths, " + std::to_string(wv) + " waves/SIMD", [=] { launch_p<uint32_t>(pa, wv); }, bytes);
         add("library fl_u32_pack_mixed", [=] { fl_u32_pack_mixed(plan, (const uint32_t*)out_ref, (uint32_t*)repacked, nullptr); }, bytes);
     }

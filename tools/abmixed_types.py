@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B on the GPU box: mixed-width columns of every element type (seeded-random widths 1..T), unpack_widths and pack_widths at
-several blocks-per-wavefront x waves-per-SIMD, same buffers (fl_set_kernel_policy 2 + 256*waves + 65536*bpw).  GB/s."""
+several blocks-per-wavefront x waves-per-SIMD, same buffers (fl_internal_set_kernel_policy 2 + 256*waves + 65536*bpw).  GB/s."""
 import os
 import sys
 
@@ -32,7 +32,7 @@ for ty in ("u8", "u16", "u32", "u64"):
         for bpw in (1, 2, 4, 8):
             row = []
             for waves in (3, 4, 6, 8):
-                lib.fl_set_kernel_policy(2 + 256 * waves + 65536 * bpw)
+                lib.fl_internal_set_kernel_policy(2 + 256 * waves + 65536 * bpw)
                 t = []
                 for _ in range(3):
                     f(); torch.cuda.synchronize()
@@ -41,5 +41,5 @@ for ty in ("u8", "u16", "u32", "u64"):
                     t.append(a.elapsed_time(b))
                 row.append(nbytes / sorted(t)[1] / 1e6)
             print(f"{ty:3s} {name:13s} bpw {bpw} | " + " ".join(f"{x:6.0f}" for x in row), flush=True)
-    lib.fl_set_kernel_policy(0)
+    lib.fl_internal_set_kernel_policy(0)
     del pk, un, vals, pk2, widths, offsets

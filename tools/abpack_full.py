@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B on the GPU box at BASELINE's full 10 M blocks: pack / unpack of configs 2 and 3 through the cell-column kernels vs the
-wave-per-block kernels at several occupancies, same buffers, full-entropy inputs (fl_set_kernel_policy)."""
+wave-per-block kernels at several occupancies, same buffers, full-entropy inputs (fl_internal_set_kernel_policy)."""
 import os
 import sys
 
@@ -27,7 +27,7 @@ for ty, tdt, T, W in (("u32", torch.uint32, 32, 7), ("u64", torch.uint64, 64, 17
         pols = [0, 1] + [2 + 256 * w for w in WAVES]
         for _ in range(5):
             for p in pols:
-                lib.fl_set_kernel_policy(p)
+                lib.fl_internal_set_kernel_policy(p)
                 f(); torch.cuda.synchronize()
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record(); f(); b.record(); torch.cuda.synchronize()
@@ -36,5 +36,5 @@ for ty, tdt, T, W in (("u32", torch.uint32, 32, 7), ("u64", torch.uint64, 64, 17
         print(f"{ty} W={W:<2d} {name:6s} | auto {g[0]:6.0f} | cc {g[1]:6.0f} | wpb " + " ".join(f"{x:6.0f}" for x in g[2:]), flush=True)
         if name == "pack":
             un = rand_u8(n * 1024 * esz, 4, dev).view(tdt)      # unpack overwrote nothing yet, but keep inputs fresh per op
-    lib.fl_set_kernel_policy(0)
+    lib.fl_internal_set_kernel_policy(0)
     del un, pk

@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 #include "fastlanes_amd.h"
+#include "fastlanes_amd_internal.h"
 #include "fl_widths.hpp"
 
 using namespace fl;
@@ -69,7 +70,7 @@ template <typename T> void run(unsigned W, int rounds)
     WidthsArgs up{g_pk, g_un2, nullptr, nullptr, nullptr, nullptr, 0, n, 0, W, 1};
     WidthsArgs pa{g_pk2, g_un, nullptr, nullptr, nullptr, nullptr, 0, n, 0, W, 1};
     // correctness on these very buffers (library forced onto its cell-column kernels: policy 1)
-    fl_set_kernel_policy(1);
+    fl_internal_set_kernel_policy(1);
     Abi<T>::unpack(W, pk, un, n, nullptr);
     launch_w<T, false>(up, 6);
     CK(hipDeviceSynchronize());
