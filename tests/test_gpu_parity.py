@@ -461,7 +461,7 @@ def test_unpack_pack_widths_device_resident(fl, oracle, ty):
         g = to_np(out, ty)
         assert np.array_equal(g[:5 * 1024], want[:5 * 1024]) and np.array_equal(g[6 * 1024:], want[6 * 1024:]), what
         assert not g[5 * 1024:6 * 1024].any(), what
-        guard2 = guard.clone()
+        guard2 = torch.full((total // esz,), 0x5A if ty == "u8" else 0x5A5A, dtype=tdt, device="cuda:0")
         with pytest.raises(fl.FastLanesError) as ei:
             fl.pack_widths(dw, dboff, to_dev(v), guard2)
         assert ei.value.status == status, what
@@ -688,6 +688,46 @@ def test_plain_c_caller_of_the_c_abi(fl):
     import __graft_entry__ as ge
     r = subprocess.run([ge.build_examples()["column_decode"]], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip() == "ok", (r.returncode, r.stdout, r.stderr)
+
+
+def test_multi_device_driver_through_the_c_abi(fl):
+    """examples/multi_gpu_decode.c: one process, one host thread per visible device (hipSetDevice + its own stream), no
+    torch, no RCCL -- the weak-scaled config-2 column on every device and the strong-scaled config-5 column split by
+    contiguous block range, each slice's first / last / sampled blocks verified against a scalar decode.
+    Runs on however many devices exist; --replicas 2 drives the N-thread path on a 1-GPU box as well."""
+    import subprocess
+    import torch
+    import __graft_entry__ as ge
+    exe = ge.build_examples()["multi_gpu_decode"]
+    ndev = torch.cuda.device_count()
+    for extra, threads in ((["--replicas", "1"], ndev), (["--replicas", "2"], 2 * ndev)):
+        r = subprocess.run([exe, "--blocks", "300000", "--strong-blocks", "600001", "--steps", "3", "--warmup", "1"] + extra,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+        d = json.loads(r.stdout)
+        assert d["devices"] == ndev and d["threads"] == threads and d["correct"] is True and d["collective"] == "none"
+        weak, strong = d["weak_u32_w7_unpack"], d["strong_u32_mixed_unpack"]
+        assert all(t["correct"] and t["GBps"] > 0 for t in weak["per_thread"]) and weak["Gint_per_s"] > 0
+        sl = strong["per_thread"]
+        assert sum(t["blocks"] for t in sl) == 600001 and sl[0]["first_block"] == 0
+        assert all(sl[i]["first_block"] + sl[i]["blocks"] == sl[i + 1]["first_block"] for i in range(len(sl) - 1))
+        assert all(t["correct"] and t["GBps"] > 0 for t in sl) and strong["Gint_per_s"] > 0
+        assert sorted({t["device"] for t in sl}) == list(range(ndev))
+
+
+def test_fill_random_is_the_counter_based_stream(fl):
+    """fl_fill_random writes splitmix64 of the global word index: identical to tests/datagen.py, so a host
+    can regenerate any part of a device-resident column."""
+    import torch
+    from datagen import splitmix64
+    lib = fl.load()
+    for n_words, seed in ((1, 0), (1000, 42), (65536 * 256 + 77, 1234)):
+        t = torch.zeros(n_words + 2, dtype=torch.int64, device="cuda:0")
+        assert lib.fl_fill_random(t.data_ptr() + 8, n_words * 8, seed, None) == 0
+        torch.cuda.synchronize()
+        got = t.cpu().numpy().view(np.uint64)
+        assert got[0] == 0 and got[-1] == 0                     # nothing outside the range
+        assert np.array_equal(got[1:-1], splitmix64(n_words, seed))
 
 
 def test_functor_api_user_kernel_on_iterate_rows(fl, oracle):
