@@ -7,7 +7,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfastlanes_amd.so")
+# FL_LIB=<path> selects another build of the same library -- the A/B tools use it to load libfastlanes_amd_full.so
+# (make -C fastlanes_amd/csrc FULL=1: every cell-column instance, whatever the dispatch table says).  Never a fallback.
+LIB_PATH = os.environ.get("FL_LIB") or os.path.join(_HERE, "libfastlanes_amd.so")
 
 TYPES = ("u8", "u16", "u32", "u64")
 CTYPE = {"u8": ctypes.c_uint8, "u16": ctypes.c_uint16, "u32": ctypes.c_uint32, "u64": ctypes.c_uint64}

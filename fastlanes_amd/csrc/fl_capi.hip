@@ -9,7 +9,6 @@
 #include "fl_widths.hpp"
 #include "fl_chain.hpp"
 #include "fl_scan.hpp"
-#include "fl_dispatch.hpp"
 #include "fl_consume.hpp"
 
 #include <atomic>
@@ -22,18 +21,22 @@ using namespace fl;
 
 thread_local int g_last_hip_error = 0;
 
-// fl_internal_set_kernel_policy: 0 = measured choice (fl_dispatch.hpp), 1 = cell-column kernels only, 2 = wave-per-block
-// kernels wherever they exist.  Results are bit-identical; only speed differs.
+// fl_internal_set_kernel_policy: 0 = the generated table (fl_dispatch.hpp), 1 = cell-column kernels wherever they are
+// built, 2 = wave-per-block kernels wherever they exist.  Results are bit-identical; only speed differs.
 std::atomic<int> g_kernel_policy{0};
 
+// waves per SIMD to run the wave-per-block kernel at, or 0 = use the cell-column kernel.  The per-(T,W) cell-column
+// families are only built where the table chose them (cell_column_built); Delta's / Transpose's per-type cell-column
+// kernels (no width parameter) always exist.
 inline int chosen_waves(unsigned type_bits, unsigned w, fl::WaveOp op)
 {
     const int p = g_kernel_policy.load(std::memory_order_relaxed);
-    if ((p & 0xff) == 1) return 0;
-    const int waves = fl::wave_policy(type_bits, w, op);
-    if ((p & 0xff) != 2) return waves;
+    const int table = fl::wave_policy(type_bits, w, op);
+    const bool per_type = op == fl::WAVE_UNDELTA || op == fl::WAVE_DELTA || op == fl::WAVE_TRANSPOSE || op == fl::WAVE_UNTRANSPOSE;
+    if ((p & 0xff) == 1) return (per_type || fl::cell_column_built(type_bits, w, op)) ? 0 : table;
+    if ((p & 0xff) != 2) return table;
     if ((p >> 8) & 0xff) return (p >> 8) & 0xff;     // A/B tools: policy 2 + 256 * waves forces the occupancy too
-    return waves ? waves : fl::mixed_waves(type_bits, op == fl::WAVE_PACK);
+    return table ? table : fl::wave_fallback(type_bits, op == fl::WAVE_PACK || op == fl::WAVE_TRANSPOSE_DELTA_PACK);
 }
 
 
@@ -555,7 +558,11 @@ void fl_internal_set_kernel_policy(int policy)
 }
 int fl_internal_get_kernel_policy(void) { return g_kernel_policy.load(std::memory_order_relaxed); }
 
+#ifdef FL_ALL_CELL_COLUMN
+const char* fl_version(void) { return "fastlanes_amd 0.3.0 (gfx950; wire format of spiraldb/fastlanes 0.1.8; FULL build: every cell-column instance, for A/B sweeps)"; }
+#else
 const char* fl_version(void) { return "fastlanes_amd 0.3.0 (gfx950; wire format of spiraldb/fastlanes 0.1.8)"; }
+#endif
 
 const char* fl_status_string(int status)
 {

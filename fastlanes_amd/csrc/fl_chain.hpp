@@ -133,7 +133,7 @@ template <typename T> __device__ __forceinline__ void tile_transpose(const Cell<
         for (int j = 0; j < N; ++j) out[e].x[j] = in[j].x[e];
 }
 
-template <typename T, int SRC, int BODY, int SNK>
+template <typename T, int SRC, int BODY, int SNK, int RD = RD_VGPR>
 __global__ __launch_bounds__(WG) void k_chain(ChainArgs a)
 {
     using G = WaveBlock<T>;
@@ -159,23 +159,35 @@ __global__ __launch_bounds__(WG) void k_chain(ChainArgs a)
     const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(a.in) + blk * (uint64_t)in_bytes, 0, in_bytes, 0x00020000);
     const unsigned w_in = SRC == SRC_PACKED ? w : (unsigned)TB;
-    u32x4 img[G::GROUPS];
-    static_for<G::GROUPS>([&](auto Gi) {
-        constexpr int g = decltype(Gi)::value;
-        if (8u * g < w_in) img[g] = __builtin_amdgcn_raw_buffer_load_b128(in_rs, lane * 16u + g * 1024u, 0, SRC == SRC_PACKED ? 0 : 2);
-    });
-    // base[lane] of this cell column (delta.rs:26,38,56): one 16-byte cell per column, behind the data loads
+    // LDS-DMA writes lane-linear 1 KiB pieces: usable wherever the source image is linear (not the padded original-order one)
+    constexpr bool DMA = rd_is_dma(RD) && !(SRC == SRC_ORIGINAL && sizeof(T) >= 4);
     Cell<T> base = Cell<T>::zero();
-    if constexpr (BODY != CHAIN_NONE)
-        base = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(a.bases + blk * 128u + c16 + opaque_zero()));
-    static_for<G::GROUPS>([&](auto Gi) {
-        constexpr int g = decltype(Gi)::value;
-        if (8u * g < w_in) {
-            unsigned at = lane * 16u + g * 1024u;
-            if constexpr (SRC == SRC_ORIGINAL) at = OriginalImage<T>::pad(at);
-            *reinterpret_cast<u32x4*>(lds + at) = img[g];
-        }
-    });
+    if constexpr (!DMA) {
+        u32x4 img[G::GROUPS];
+        static_for<G::GROUPS>([&](auto Gi) {
+            constexpr int g = decltype(Gi)::value;
+            if (8u * g < w_in) img[g] = __builtin_amdgcn_raw_buffer_load_b128(in_rs, lane * 16u + g * 1024u, 0, (SRC != SRC_PACKED || RD == RD_VGPR_NT) ? 2 : 0);
+        });
+        // base[lane] of this cell column (delta.rs:26,38,56): one 16-byte cell per column, behind the data loads
+        if constexpr (BODY != CHAIN_NONE)
+            base = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(a.bases + blk * 128u + c16 + opaque_zero()));
+        static_for<G::GROUPS>([&](auto Gi) {
+            constexpr int g = decltype(Gi)::value;
+            if (8u * g < w_in) {
+                unsigned at = lane * 16u + g * 1024u;
+                if constexpr (SRC == SRC_ORIGINAL) at = OriginalImage<T>::pad(at);
+                *reinterpret_cast<u32x4*>(lds + at) = img[g];
+            }
+        });
+    } else {
+        static_for<G::GROUPS>([&](auto Gi) {
+            constexpr int g = decltype(Gi)::value;
+            if (8u * g < w_in) dma_1k_to_lds<DMA ? RD : 0, g * 1024>(in_rs, lds, lane);
+        });
+        if constexpr (BODY != CHAIN_NONE)
+            base = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(a.bases + blk * 128u + c16 + opaque_zero()));
+        wait_lds_dma();
+    }
     wave_lds_fence();
 
     // ---- this lane's R consecutive rows of cell column c --------------------------------------------------------
@@ -285,7 +297,7 @@ __global__ __launch_bounds__(WG) void k_chain(ChainArgs a)
 
 typedef hipError_t (*chain_launch_t)(const ChainArgs&, int waves, hipStream_t);
 
-template <typename T, int SRC, int BODY, int SNK>
+template <typename T, int SRC, int BODY, int SNK, int RD = RD_VGPR>
 hipError_t launch_chain(const ChainArgs& a0, int waves, hipStream_t s)
 {
     if (a0.n_blocks == 0) return hipSuccess;
@@ -296,7 +308,7 @@ hipError_t launch_chain(const ChainArgs& a0, int waves, hipStream_t s)
     const unsigned need = (WG / 64) * chain_wave_lds<T, SRC, SNK>();
     if (waves < 3) waves = 3;
     const unsigned pad = (CU_LDS_BYTES / (unsigned)waves) & ~1023u;
-    hipLaunchKernelGGL((k_chain<T, SRC, BODY, SNK>), dim3((unsigned)(a.tiles_per_xcd * 8)), dim3(WG), pad > need ? pad : need, s, a);
+    hipLaunchKernelGGL((k_chain<T, SRC, BODY, SNK, RD>), dim3((unsigned)(a.tiles_per_xcd * 8)), dim3(WG), pad > need ? pad : need, s, a);
     return hipGetLastError();
 }
 

@@ -9,6 +9,7 @@
 // and only to shape global stores (WaveRowStore below, RunExchange in fl_device.hpp).
 #pragma once
 #include "fl_device.hpp"
+#include "fl_dispatch.hpp"
 
 namespace fl {
 
@@ -355,15 +356,33 @@ hipError_t launch_delta(const StreamArgs& a0, hipStream_t s)
 // Runtime width -> instance table, index 0..T inclusive.
 template <typename T> struct WidthTable { stream_launch_t fn[Elem<T>::BITS + 1]; };
 
+// Only the (T, W) instances the dispatch table actually sends calls to are built (fl_dispatch.hpp: cell_column_built);
+// the other entries are nullptr and the C ABI serves those widths with the runtime-width wave-per-block kernels.
+constexpr WaveOp wave_op_of_body(int body)
+{
+    return body == BODY_UNDELTA ? WAVE_UNDELTA_PACK : body == BODY_UNDELTA_UNTRANSPOSE ? WAVE_UNDELTA_PACK_UNTRANSPOSE : WAVE_UNPACK;
+}
+constexpr WaveOp wave_op_of_mode(int mode) { return mode == PACK_TRANSPOSE_DELTA ? WAVE_TRANSPOSE_DELTA_PACK : WAVE_PACK; }
+
+template <typename T, int W, int BODY> constexpr stream_launch_t unpack_entry()
+{
+    if constexpr (cell_column_built(Elem<T>::BITS, W, wave_op_of_body(BODY))) return &launch_unpack<T, W, BODY>;
+    else return nullptr;
+}
+template <typename T, int W, int MODE> constexpr stream_launch_t pack_entry()
+{
+    if constexpr (cell_column_built(Elem<T>::BITS, W, wave_op_of_mode(MODE))) return &launch_pack<T, W, MODE>;
+    else return nullptr;
+}
 template <typename T, int BODY, int... Ws>
 constexpr WidthTable<T> make_unpack_table(std::integer_sequence<int, Ws...>)
 {
-    return WidthTable<T>{{&launch_unpack<T, Ws, BODY>...}};
+    return WidthTable<T>{{unpack_entry<T, Ws, BODY>()...}};
 }
 template <typename T, int MODE, int... Ws>
 constexpr WidthTable<T> make_pack_table(std::integer_sequence<int, Ws...>)
 {
-    return WidthTable<T>{{&launch_pack<T, Ws, MODE>...}};
+    return WidthTable<T>{{pack_entry<T, Ws, MODE>()...}};
 }
 
 // Specialised once per (element type, family) in fl_inst.hip

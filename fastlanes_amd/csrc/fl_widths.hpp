@@ -169,11 +169,64 @@ template <typename T> __device__ __forceinline__ Cell<T> block_ref(const WidthsA
     return Cell<T>::splat(static_cast<const T*>(a.refs)[blk * a.ref_stride + opaque_zero()]);
 }
 
+// How a wavefront's input block reaches its LDS image: through VGPRs (global load + ds_write_b128), or by LDS-DMA
+// (`buffer_load_dwordx4 ... lds`: 1 KiB per instruction straight into LDS, no staging registers, no ds_write pass) with the
+// default or the non-temporal cache policy.  hipcc does not order a ds_read behind a pending LDS-DMA (it emits no vmcnt
+// wait for it; only the issuing wave's own vmcnt does, MI355X_MICROARCH.md item 7), hence the explicit wait.
+// RD_AUTO is what the library ships (profiles/ab_ldsdma_r03.txt, two boxes, same buffers): packed input that is streamed
+// once and is a sizeable share of the traffic -- every mixed-width column, and uniform widths with 2*W >= T -- gains 3-5 %
+// from the NON-TEMPORAL policy on the read side (the LDS-DMA and the VGPR route tie there, the DMA route is ahead by
+// 1-3 % on mixed-width columns and needs no staging registers), while narrow uniform widths and every unpacked-block read
+// (pack, Delta, transposes) measured equal or worse with LDS-DMA and keep the VGPR route.
+enum ReadPath { RD_AUTO = -2, RD_VGPR = -1, RD_VGPR_NT = -3, RD_DMA = 0, RD_DMA_NT = 2 };
+constexpr bool rd_is_dma(int rd) { return rd >= 0; }
+
+typedef __attribute__((address_space(3))) void* lds_dma_ptr_t;
+
+template <int RD, int BYTE_OFF>
+__device__ __forceinline__ void dma_1k_to_lds(__amdgpu_buffer_rsrc_t rs, char* lds, unsigned lane)
+{
+    // memory address = descriptor base + voffset + soffset + inst_offset;  LDS address = M0 base + inst_offset + lane*16:
+    // the 12-bit instruction offset advances BOTH sides, so one M0 value serves 4 consecutive KiB; the 4-KiB step beyond
+    // that goes into the scalar offset (memory side) and the M0 base (LDS side).  Bytes past the descriptor arrive as 0.
+    constexpr int HI = BYTE_OFF & ~4095, LO = BYTE_OFF & 4095;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_dma_ptr_t)(lds + HI), 16, lane * 16u, HI, LO, RD);
+}
+__device__ __forceinline__ void wait_lds_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+
+// the W packed rows of one block -> the wave's LDS image; FoR's reference rides behind the data loads
+template <typename T, int RD>
+__device__ __forceinline__ void packed_block_to_lds(const WidthsArgs& a, uint64_t blk, __amdgpu_buffer_rsrc_t rs, unsigned w,
+                                                    char* lds, unsigned lane, Cell<T>& ref)
+{
+    using G = WaveBlock<T>;
+    if constexpr (!rd_is_dma(RD)) {
+        u32x4 pk[G::GROUPS];
+        static_for<G::GROUPS>([&](auto Gi) {
+            constexpr int g = decltype(Gi)::value;
+            if (8u * g < w) pk[g] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16u + g * 1024u, 0, RD == RD_VGPR_NT ? 2 : 0);
+        });
+        if (a.refs) ref = block_ref<T>(a, blk);                             // behind the data loads
+        static_for<G::GROUPS>([&](auto Gi) {
+            constexpr int g = decltype(Gi)::value;
+            if (8u * g < w) *reinterpret_cast<u32x4*>(lds + lane * 16u + g * 1024u) = pk[g];
+        });
+    } else {
+        static_for<G::GROUPS>([&](auto Gi) {
+            constexpr int g = decltype(Gi)::value;
+            if (8u * g < w) dma_1k_to_lds<RD, g * 1024>(rs, lds, lane);
+        });
+        if (a.refs) ref = block_ref<T>(a, blk);
+        wait_lds_dma();
+    }
+}
+
 // unchecked_unpack over per-block widths (bitpacking.rs:109-129); with a.refs also FoR::unfor_pack's body
 // `out[idx] = elem + reference` (ffor.rs:46-48).  One block at a time per wavefront (a.bpw consecutive ones, 1 except
 // for u8 mixed-width columns); the wave's LDS image is BLOCK_BYTES of the DYNAMIC shared memory -- the launcher pads the
 // request to steer occupancy (fewer, or more, concurrent DRAM streams) without compiling per-occupancy variants.
-template <typename T>
+template <typename T, int RD = RD_AUTO>
 __device__ __forceinline__ void unpack_block_wave(const WidthsArgs& a, uint64_t blk, char* lds, unsigned lane)
 {
     using G = WaveBlock<T>;
@@ -197,16 +250,13 @@ __device__ __forceinline__ void unpack_block_wave(const WidthsArgs& a, uint64_t 
     }
     // wave-uniform descriptor over exactly this block's 128*w bytes: cells past it read as 0, no fault
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.packed) + off, 0, 128u * w, 0x00020000);
-    u32x4 pk[G::GROUPS];
-    static_for<G::GROUPS>([&](auto Gi) {
-        constexpr int g = decltype(Gi)::value;
-        if (8u * g < w) pk[g] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16u + g * 1024u, 0, 0);
-    });
-    const Cell<T> ref = a.refs ? block_ref<T>(a, blk) : Cell<T>::zero();   // behind the data loads
-    static_for<G::GROUPS>([&](auto Gi) {
-        constexpr int g = decltype(Gi)::value;
-        if (8u * g < w) *reinterpret_cast<u32x4*>(lds + lane * 16u + g * 1024u) = pk[g];
-    });
+    Cell<T> ref = Cell<T>::zero();
+    if constexpr (RD == RD_AUTO) {
+        if (a.widths || 2u * w >= (unsigned)TB) packed_block_to_lds<T, RD_DMA_NT>(a, blk, rs, w, lds, lane, ref);   // wave-uniform
+        else packed_block_to_lds<T, RD_VGPR>(a, blk, rs, w, lds, lane, ref);
+    } else {
+        packed_block_to_lds<T, RD>(a, blk, rs, w, lds, lane, ref);
+    }
     wave_lds_fence();
     const unsigned c16 = (lane & 7u) * 16u;
     const typename G::word_t m = G::field_mask(w);
@@ -249,10 +299,10 @@ __device__ __forceinline__ void for_each_block_of_wave(const WidthsArgs& a, F&& 
     }
 }
 
-template <typename T>
+template <typename T, int RD = RD_AUTO>
 __global__ __launch_bounds__(WG) void k_unpack_widths(WidthsArgs a)
 {
-    for_each_block_of_wave<T>(a, [&](uint64_t blk, char* lds, unsigned lane) { unpack_block_wave<T>(a, blk, lds, lane); });
+    for_each_block_of_wave<T>(a, [&](uint64_t blk, char* lds, unsigned lane) { unpack_block_wave<T, RD>(a, blk, lds, lane); });
 }
 
 // The W packed rows of one block assembled from the wave's LDS image of the UNPACKED block (transposed layout, cell of
@@ -363,7 +413,7 @@ __device__ __forceinline__ void pack_from_lds_image(char* lds, unsigned w, char*
 // then assembles packed cells (w = i + 8m, c): word w of an FL lane's stream holds bits [w*T, (w+1)*T), i.e. the
 // fields of rows floor(w*T/W) .. floor(((w+1)*T-1)/W) (macros.rs:72-92 regrouped by destination word instead of by
 // source row).
-template <typename T>
+template <typename T, int RD = RD_VGPR>
 __device__ __forceinline__ void pack_block_wave(const WidthsArgs& a, uint64_t blk, char* lds, unsigned lane)
 {
     using G = WaveBlock<T>;
@@ -378,25 +428,30 @@ __device__ __forceinline__ void pack_block_wave(const WidthsArgs& a, uint64_t bl
     if (w == 0) return;                                       // macros.rs:52-53: W == 0 writes nothing
     const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(
         a.unpacked + blk * G::BLOCK_BYTES, 0, G::BLOCK_BYTES, 0x00020000);
-    u32x4 un[G::GROUPS];
-    static_for<G::GROUPS>([&](auto K) {
-        un[decltype(K)::value] = __builtin_amdgcn_raw_buffer_load_b128(in_rs, decltype(K)::value * 1024u + lane * 16u, 0, 2 /* nt */);
-    });
-    const Cell<T> ref = a.refs ? block_ref<T>(a, blk) : Cell<T>::zero();   // behind the data loads
-    static_for<G::GROUPS>([&](auto K) {
-        Cell<T> v = __builtin_bit_cast(Cell<T>, un[decltype(K)::value]);
-        if (a.refs) v = v.sub(ref);                                         // ffor.rs:32-34 (before the mask of macros.rs:73)
-        *reinterpret_cast<u32x4*>(lds + lane * 16u + decltype(K)::value * 1024u) = __builtin_bit_cast(u32x4, v);
-    });
+    if (!rd_is_dma(RD) || a.refs) {                           // FoR subtracts on the way into the image: through VGPRs
+        u32x4 un[G::GROUPS];
+        static_for<G::GROUPS>([&](auto K) {
+            un[decltype(K)::value] = __builtin_amdgcn_raw_buffer_load_b128(in_rs, decltype(K)::value * 1024u + lane * 16u, 0, 2 /* nt */);
+        });
+        const Cell<T> ref = a.refs ? block_ref<T>(a, blk) : Cell<T>::zero();   // behind the data loads
+        static_for<G::GROUPS>([&](auto K) {
+            Cell<T> v = __builtin_bit_cast(Cell<T>, un[decltype(K)::value]);
+            if (a.refs) v = v.sub(ref);                                         // ffor.rs:32-34 (before the mask of macros.rs:73)
+            *reinterpret_cast<u32x4*>(lds + lane * 16u + decltype(K)::value * 1024u) = __builtin_bit_cast(u32x4, v);
+        });
+    } else {
+        static_for<G::GROUPS>([&](auto K) { dma_1k_to_lds<rd_is_dma(RD) ? RD : 0, decltype(K)::value * 1024>(in_rs, lds, lane); });
+        wait_lds_dma();
+    }
     wave_lds_fence();
     pack_from_lds_image<T>(lds, w, const_cast<char*>(a.packed) + off, lane);
     wave_lds_fence();                                         // the image is reused by the wavefront's next block
 }
 
-template <typename T>
+template <typename T, int RD = RD_VGPR>
 __global__ __launch_bounds__(WG) void k_pack_widths(WidthsArgs a)
 {
-    for_each_block_of_wave<T>(a, [&](uint64_t blk, char* lds, unsigned lane) { pack_block_wave<T>(a, blk, lds, lane); });
+    for_each_block_of_wave<T>(a, [&](uint64_t blk, char* lds, unsigned lane) { pack_block_wave<T, RD>(a, blk, lds, lane); });
 }
 
 typedef hipError_t (*widths_launch_t)(const WidthsArgs&, int waves, hipStream_t);
@@ -417,7 +472,7 @@ template <typename T> inline unsigned widths_lds_bytes(int waves)
     return pad > need ? pad : need;
 }
 
-template <typename T, bool PACK>
+template <typename T, bool PACK, int RD = (PACK ? RD_VGPR : RD_AUTO)>
 hipError_t launch_widths(const WidthsArgs& a0, int waves, hipStream_t s)
 {
     if (a0.n_blocks == 0) return hipSuccess;
@@ -429,8 +484,8 @@ hipError_t launch_widths(const WidthsArgs& a0, int waves, hipStream_t s)
     if (a.tiles_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;   // > 2^33 blocks in one launch
     const dim3 grid((unsigned)(a.tiles_per_xcd * 8));
     const unsigned lds = widths_lds_bytes<T>(waves);
-    if constexpr (PACK) hipLaunchKernelGGL((k_pack_widths<T>), grid, dim3(WG), lds, s, a);
-    else hipLaunchKernelGGL((k_unpack_widths<T>), grid, dim3(WG), lds, s, a);
+    if constexpr (PACK) hipLaunchKernelGGL((k_pack_widths<T, RD>), grid, dim3(WG), lds, s, a);
+    else hipLaunchKernelGGL((k_unpack_widths<T, RD>), grid, dim3(WG), lds, s, a);
     return hipGetLastError();
 }
 

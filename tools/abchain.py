@@ -15,15 +15,20 @@ lib = fl.load()
 dev = torch.device("cuda", 0)
 TD = {"u8": (torch.uint8, 8), "u16": (torch.uint16, 16), "u32": (torch.uint32, 32), "u64": (torch.uint64, 64)}
 WAVES = (3, 4, 5, 6, 8)
-ROUNDS = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+ROUNDS = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 3
 cases = [("u32", 12), ("u32", 7), ("u32", 3), ("u32", 20), ("u32", 28), ("u64", 20), ("u64", 5), ("u64", 40), ("u64", 60),
          ("u16", 9), ("u16", 3), ("u16", 14), ("u8", 4), ("u8", 7)]
+ALL = "--all" in sys.argv          # every width of every type: the basis of tools/make_dispatch.py
+GB = 12
+if ALL:
+    cases = [(ty, w) for ty in ("u32", "u64", "u16", "u8") for w in range(TD[ty][1] + 1)]
+    GB = 6
 print("GB/s, median of %d; cc = cell-column, then wave-per-block at %s waves/SIMD" % (ROUNDS, " ".join(map(str, WAVES))))
 seen_plain = set()
 for ty, W in cases:
     tdt, T = TD[ty]
     esz = T // 8
-    n = (12 << 30) // (128 * W + 128 * T + 128)
+    n = (GB << 30) // (128 * W + 128 * T + 128)
     pk = rand_u8(n * 128 * W, 2, dev).view(tdt)
     un = rand_u8(n * 1024 * esz, 1, dev).view(tdt)
     out = torch.empty(n * 1024, dtype=tdt, device=dev)

@@ -3,7 +3,7 @@
 // wave-per-block kernel of fl_widths.hpp in several launch shapes, next to a bare tuned stream of
 // the same read:write mix (the ceiling of the memory system for this traffic).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I fastlanes_amd/csrc -I include tools/abmixed.hip
-//        -L fastlanes_amd -lfastlanes_amd -Wl,-rpath,'$ORIGIN/../fastlanes_amd' -o tools/abmixed
+//        -L fastlanes_amd -lfastlanes_amd_full -Wl,-rpath,'$ORIGIN/../fastlanes_amd' -o tools/abmixed
 // Run on the GPU box: tools/abmixed [n_blocks] [rounds]
 #include <hip/hip_runtime.h>
 #include <algorithm>
