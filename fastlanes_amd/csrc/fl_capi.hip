@@ -112,6 +112,7 @@ int run_wave_uniform(bool pack, int waves, unsigned w, const T* packed, T* unpac
     a.uniform_width = w;
     a.bpw = 1;
     a.packed_bytes = 0;      // not read: uniform-width calls are validated here, on the host side
+    a.prefetch = 0;
     hipError_t e = widths_launcher<T>(pack)(a, waves, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
@@ -459,11 +460,13 @@ int run_widths(bool pack, const uint8_t* widths, const uint64_t* offsets, const 
     a.tiles_per_xcd = 0;
     a.uniform_width = 0;
     a.packed_bytes = packed_bytes;
-    a.bpw = mixed_blocks_per_wave(Elem<T>::BITS);
+    a.bpw = mixed_blocks_per_wave(Elem<T>::BITS, pack);
+    a.prefetch = mixed_prefetch(Elem<T>::BITS);
     int waves = mixed_waves(Elem<T>::BITS, pack);
-    const int pol = g_kernel_policy.load(std::memory_order_relaxed);       // A/B tools: 2 + 256*waves + 65536*blocks-per-wavefront
+    const int pol = g_kernel_policy.load(std::memory_order_relaxed);       // A/B tools: 2 + 256*waves + 65536*blocks-per-wavefront (+ 2^24: prefetch)
     if ((pol & 0xff) == 2 && ((pol >> 8) & 0xff)) waves = (pol >> 8) & 0xff;
-    if ((pol & 0xff) == 2 && ((pol >> 16) & 0xff)) a.bpw = (pol >> 16) & 0xff;
+    if ((pol & 0xff) == 2 && ((pol >> 16) & 0xff)) { a.bpw = (pol >> 16) & 0xff; a.prefetch = (pol >> 24) & 1; }
+    if (a.prefetch && (WG / 64) * a.bpw * WaveBlock<T>::BLOCK_BYTES > 64u * 1024u) a.prefetch = 0;   // images would not fit a workgroup's LDS
     hipError_t e = widths_launcher<T>(pack)(a, waves, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
@@ -551,9 +554,9 @@ const uint8_t* fl_mixed_plan_widths(const fl_mixed_plan* p) { return p ? p->d_wi
 void fl_host_release(void) { g_host.release(); }
 void fl_internal_set_kernel_policy(int policy)
 {
-    const int mode = policy & 0xff, waves = (policy >> 8) & 0xff, bpw = (policy >> 16) & 0xff;
-    const bool ok = policy >= 0 && (policy >> 24) == 0 && mode <= 2 && (waves == 0 || (waves >= 3 && waves <= 8)) && bpw <= 16
-                    && (mode == 2 || (waves == 0 && bpw == 0));
+    const int mode = policy & 0xff, waves = (policy >> 8) & 0xff, bpw = (policy >> 16) & 0xff, prefetch = policy >> 24;
+    const bool ok = policy >= 0 && prefetch <= 1 && mode <= 2 && (waves == 0 || (waves >= 3 && waves <= 8)) && bpw <= 16
+                    && (mode == 2 || (waves == 0 && bpw == 0)) && (prefetch == 0 || bpw >= 2);
     g_kernel_policy.store(ok ? policy : 0, std::memory_order_relaxed);
 }
 int fl_internal_get_kernel_policy(void) { return g_kernel_policy.load(std::memory_order_relaxed); }

@@ -11,6 +11,14 @@
 
 namespace fl {
 
+// Waves per SIMD of the consumer kernels (same-buffer A/B of builds capped at 2..6 waves, profiles/abconsume_r03.txt).
+// A thread keeps all W packed cells of its column in registers; uncapped, hipcc allocates ~62 VGPRs to reach 8 waves per
+// SIMD and serialises the loads of the wider widths.  Narrow widths are VALU-bound (profiles/r03_pmc_sq_counters.csv: up to
+// 87 % of the VALU issue slots at u16 W=3) and need every wave; from W = 6 up fewer, fatter waves with every load in flight
+// stream better: compare +3...6 % (u64 W=56: +17 %), sums +2...6 % at W = 6..12.
+constexpr int compare_max_waves(int w) { return w <= 5 ? 8 : w <= 9 ? 3 : 2; }
+constexpr int sums_max_waves(int w) { return (w >= 6 && w <= 12) ? 3 : 8; }
+
 struct ReduceArgs {
     const u32x4* in;
     void* out0;            // sums (uint64 per block) or mins (T per block)
@@ -67,7 +75,7 @@ template <typename T> __device__ __forceinline__ T group8_minmax(T v, bool want_
 }
 
 template <typename T, int W>
-__global__ __launch_bounds__(WG) void k_unpack_block_sums(ReduceArgs a)
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, sums_max_waves(W)))) void k_unpack_block_sums(ReduceArgs a)
 {
     uint64_t tile;
     if (!tile_of_workgroup(a, tile)) return;
@@ -247,7 +255,7 @@ __device__ __forceinline__ void compare_block_lds(const Cell<T>* in, T k, unsign
 }
 
 template <typename T, int W, bool IS_EQ>
-__global__ __launch_bounds__(WG) void k_unpack_compare(CompareArgs a)
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, compare_max_waves(W)))) void k_unpack_compare(CompareArgs a)
 {
     const uint64_t n_tiles = (a.n_blocks + BLOCKS_PER_WG - 1) / BLOCKS_PER_WG;
     const uint64_t tile = (uint64_t)(blockIdx.x & 7u) * a.tiles_per_xcd + (blockIdx.x >> 3);
@@ -263,8 +271,12 @@ __global__ __launch_bounds__(WG) void k_unpack_compare(CompareArgs a)
     if constexpr (sizeof(T) == 8) {
         compare_block_dpp<T, W, IS_EQ>(in, (T)a.constant, c, keep);
     } else {
-        __shared__ __attribute__((aligned(16))) char lds[BLOCKS_PER_WG * 128];
-        compare_block_lds<T, W, IS_EQ>(in, (T)a.constant, c, lds + (tid >> 3) * 128, keep);
+        // 144-byte stride between the mask images of a wavefront's 8 blocks: at 128 bytes (= all 32 banks) the same byte
+        // of every block falls into the same bank and each ds_write is an 8-way conflict (profiles/r03_pmc_sq_counters.csv:
+        // SQ_LDS_BANK_CONFLICT = 0.71-0.74 of SQ_LDS_IDX_ACTIVE before); 36 dwords shift each block by 4 banks
+        constexpr unsigned MASK_STRIDE = 144;
+        __shared__ __attribute__((aligned(16))) char lds[BLOCKS_PER_WG * MASK_STRIDE];
+        compare_block_lds<T, W, IS_EQ>(in, (T)a.constant, c, lds + (tid >> 3) * MASK_STRIDE, keep);
     }
     const uint32_t flip = a.invert ? ~0u : 0u;
     u32x4 out = {keep[0] ^ flip, keep[1] ^ flip, keep[2] ^ flip, keep[3] ^ flip};

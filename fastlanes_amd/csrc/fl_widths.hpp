@@ -39,6 +39,7 @@ struct WidthsArgs {
     unsigned uniform_width;
     unsigned bpw;              // consecutive blocks per wavefront (>= 1); a workgroup takes 4*bpw blocks
     uint64_t packed_bytes;     // size of the packed column: a block must lie inside [0, packed_bytes) (only read when widths != nullptr)
+    unsigned prefetch;         // bpw > 1: 1 = request all bpw blocks of the wavefront up front by LDS-DMA (one LDS image per block)
 };
 
 template <typename T> struct WaveBlock {
@@ -226,6 +227,10 @@ __device__ __forceinline__ void packed_block_to_lds(const WidthsArgs& a, uint64_
 // `out[idx] = elem + reference` (ffor.rs:46-48).  One block at a time per wavefront (a.bpw consecutive ones, 1 except
 // for u8 mixed-width columns); the wave's LDS image is BLOCK_BYTES of the DYNAMIC shared memory -- the launcher pads the
 // request to steer occupancy (fewer, or more, concurrent DRAM streams) without compiling per-occupancy variants.
+template <typename T> __device__ __forceinline__ void unpack_zero_width_block(const WidthsArgs& a, uint64_t blk, unsigned lane);
+template <typename T> __device__ __forceinline__ void unpack_lds_image_to_global(const WidthsArgs& a, uint64_t blk, unsigned w, const char* lds,
+                                                                                  unsigned lane, const Cell<T>& ref);
+
 template <typename T, int RD = RD_AUTO>
 __device__ __forceinline__ void unpack_block_wave(const WidthsArgs& a, uint64_t blk, char* lds, unsigned lane)
 {
@@ -238,14 +243,8 @@ __device__ __forceinline__ void unpack_block_wave(const WidthsArgs& a, uint64_t 
         raise_device_error(a.err_flag, e, lane);
         return;
     }
-    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(
-        a.unpacked + blk * G::BLOCK_BYTES, 0, G::BLOCK_BYTES, 0x00020000);
-    const unsigned out_base = lane * 16u;
     if (w == 0) {                                             // macros.rs:118-125: every position gets 0 (+ reference)
-        const Cell<T> ref = a.refs ? block_ref<T>(a, blk) : Cell<T>::zero();
-        static_for<G::GROUPS>([&](auto K) {
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ref), out_rs, out_base + decltype(K)::value * 1024u, 0, STORE_AUX);
-        });
+        unpack_zero_width_block<T>(a, blk, lane);
         return;
     }
     // wave-uniform descriptor over exactly this block's 128*w bytes: cells past it read as 0, no fault
@@ -258,6 +257,34 @@ __device__ __forceinline__ void unpack_block_wave(const WidthsArgs& a, uint64_t 
         packed_block_to_lds<T, RD>(a, blk, rs, w, lds, lane, ref);
     }
     wave_lds_fence();
+    unpack_lds_image_to_global<T>(a, blk, w, lds, lane, ref);
+    wave_lds_fence();                                         // the image is reused by the wavefront's next block
+}
+
+// W == 0: every position gets 0 (+ FoR's reference)  (macros.rs:118-125)
+template <typename T>
+__device__ __forceinline__ void unpack_zero_width_block(const WidthsArgs& a, uint64_t blk, unsigned lane)
+{
+    using G = WaveBlock<T>;
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(
+        a.unpacked + blk * G::BLOCK_BYTES, 0, G::BLOCK_BYTES, 0x00020000);
+    const Cell<T> ref = a.refs ? block_ref<T>(a, blk) : Cell<T>::zero();
+    static_for<G::GROUPS>([&](auto K) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ref), out_rs, lane * 16u + decltype(K)::value * 1024u, 0, STORE_AUX);
+    });
+}
+
+// the LDS image of a packed block (w >= 1 rows) -> the unpacked block in HBM: lane (i, c) funnel-shifts the cell of
+// address-row 8k+i, column c of every 1-KiB group k (macros.rs:144-164 with the shift in a register)
+template <typename T>
+__device__ __forceinline__ void unpack_lds_image_to_global(const WidthsArgs& a, uint64_t blk, unsigned w, const char* lds,
+                                                           unsigned lane, const Cell<T>& ref)
+{
+    using G = WaveBlock<T>;
+    constexpr int TB = G::TB;
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(
+        a.unpacked + blk * G::BLOCK_BYTES, 0, G::BLOCK_BYTES, 0x00020000);
+    const unsigned out_base = lane * 16u;
     const unsigned c16 = (lane & 7u) * 16u;
     const typename G::word_t m = G::field_mask(w);
     unsigned bit = G::row_base(lane >> 3) * w;
@@ -274,7 +301,54 @@ __device__ __forceinline__ void unpack_block_wave(const WidthsArgs& a, uint64_t 
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rs, out_base + decltype(K)::value * 1024u, 0, STORE_AUX);
         bit += step;
     });
-    wave_lds_fence();                                         // the image is reused by the wavefront's next block
+}
+
+// Several consecutive blocks per wavefront, ALL their packed rows requested up front: one LDS image per block, filled by
+// LDS-DMA (no staging registers, so the depth costs only LDS), one wait, then the blocks are decoded back to back.  A narrow
+// element type's block is small (u8: at most 1 KiB packed, 1 KiB unpacked): with one block in flight per wavefront the wave
+// spends its life waiting for a single short request; with `count` of them in flight it has count times the bytes
+// outstanding for the same number of resident waves.
+template <typename T>
+__device__ __forceinline__ void unpack_blocks_wave_prefetched(const WidthsArgs& a, uint64_t first, unsigned count, char* lds, unsigned lane)
+{
+    using G = WaveBlock<T>;
+    constexpr int TB = G::TB;
+    // per-lane metadata of block first + lane (count <= 16 <= 64 lanes); broadcast per block with readlane
+    const uint64_t mine = first + (lane < count ? lane : 0u);
+    unsigned wv = a.uniform_width;
+    if (a.widths) wv = a.widths[mine];
+    uint64_t ov = mine * (uint64_t)(128u * wv);
+    if (a.offsets) ov = a.offsets[mine];
+    for (unsigned j = 0; j < count; ++j) {                    // wave-uniform loop
+        const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)wv, (int)j);
+        const uint64_t off = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ov >> 32), (int)j) << 32) |
+                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ov, (int)j);
+        if (block_precondition(a, w, off, TB) || w == 0) continue;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.packed) + off, 0, 128u * w, 0x00020000);
+        char* img = lds + j * G::BLOCK_BYTES;
+        static_for<G::GROUPS>([&](auto Gi) {
+            constexpr int g = decltype(Gi)::value;
+            if (8u * g < w) dma_1k_to_lds<RD_DMA_NT, g * 1024>(rs, img, lane);
+        });
+    }
+    wait_lds_dma();
+    wave_lds_fence();
+    for (unsigned j = 0; j < count; ++j) {
+        const uint64_t blk = first + j;
+        const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)wv, (int)j);
+        const uint64_t off = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ov >> 32), (int)j) << 32) |
+                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ov, (int)j);
+        if (const uint32_t e = block_precondition(a, w, off, TB)) {   // bitpacking.rs:126 unreachable!(), :111-113
+            raise_device_error(a.err_flag, e, lane);
+            continue;
+        }
+        if (w == 0) {
+            unpack_zero_width_block<T>(a, blk, lane);
+            continue;
+        }
+        const Cell<T> ref = a.refs ? block_ref<T>(a, blk) : Cell<T>::zero();
+        unpack_lds_image_to_global<T>(a, blk, w, lds + j * G::BLOCK_BYTES, lane, ref);
+    }
 }
 
 // Wavefront -> blocks: workgroup `tile` (XCD-contiguous map) owns 4*bpw consecutive blocks, wavefront `wave` the bpw
@@ -290,19 +364,23 @@ __device__ __forceinline__ void for_each_block_of_wave(const WidthsArgs& a, F&& 
     if (tile >= n_tiles) return;
     const unsigned tid = threadIdx.x;
     const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
-    char* lds = lds_all + wave * G::BLOCK_BYTES;
+    char* lds = lds_all + wave * G::BLOCK_BYTES * (a.prefetch ? a.bpw : 1u);
     const uint64_t first = tile * tile_blocks + (uint64_t)wave * a.bpw;
-    for (unsigned j = 0; j < a.bpw; ++j) {
-        const uint64_t blk = first + j;
-        if (blk >= a.n_blocks) return;
-        f(blk, lds, lane);
-    }
+    if (first >= a.n_blocks) return;
+    const uint64_t left = a.n_blocks - first;
+    f(first, left < a.bpw ? (unsigned)left : a.bpw, lds, lane);
 }
 
 template <typename T, int RD = RD_AUTO>
 __global__ __launch_bounds__(WG) void k_unpack_widths(WidthsArgs a)
 {
-    for_each_block_of_wave<T>(a, [&](uint64_t blk, char* lds, unsigned lane) { unpack_block_wave<T, RD>(a, blk, lds, lane); });
+    for_each_block_of_wave<T>(a, [&](uint64_t first, unsigned count, char* lds, unsigned lane) {
+        if (a.prefetch && count > 1) {
+            unpack_blocks_wave_prefetched<T>(a, first, count, lds, lane);
+            return;
+        }
+        for (unsigned j = 0; j < count; ++j) unpack_block_wave<T, RD>(a, first + j, lds, lane);
+    });
 }
 
 // The W packed rows of one block assembled from the wave's LDS image of the UNPACKED block (transposed layout, cell of
@@ -448,10 +526,49 @@ __device__ __forceinline__ void pack_block_wave(const WidthsArgs& a, uint64_t bl
     wave_lds_fence();                                         // the image is reused by the wavefront's next block
 }
 
+// pack's counterpart of unpack_blocks_wave_prefetched: the `count` unpacked blocks of the wavefront arrive by LDS-DMA, one
+// image each, before the first one is packed (plain BitPacking only: FoR subtracts on the way into the image).
+template <typename T>
+__device__ __forceinline__ void pack_blocks_wave_prefetched(const WidthsArgs& a, uint64_t first, unsigned count, char* lds, unsigned lane)
+{
+    using G = WaveBlock<T>;
+    constexpr int TB = G::TB;
+    const uint64_t mine = first + (lane < count ? lane : 0u);
+    unsigned wv = a.uniform_width;
+    if (a.widths) wv = a.widths[mine];
+    uint64_t ov = mine * (uint64_t)(128u * wv);
+    if (a.offsets) ov = a.offsets[mine];
+    for (unsigned j = 0; j < count; ++j) {                    // wave-uniform loop
+        const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(
+            a.unpacked + (first + j) * G::BLOCK_BYTES, 0, G::BLOCK_BYTES, 0x00020000);
+        char* img = lds + j * G::BLOCK_BYTES;
+        static_for<G::GROUPS>([&](auto K) { dma_1k_to_lds<RD_DMA_NT, decltype(K)::value * 1024>(in_rs, img, lane); });
+    }
+    wait_lds_dma();
+    wave_lds_fence();
+    for (unsigned j = 0; j < count; ++j) {
+        const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)wv, (int)j);
+        const uint64_t off = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ov >> 32), (int)j) << 32) |
+                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ov, (int)j);
+        if (const uint32_t e = block_precondition(a, w, off, TB)) {   // bitpacking.rs:93 unreachable!(), :78-80
+            raise_device_error(a.err_flag, e, lane);
+            continue;
+        }
+        if (w == 0) continue;                                 // macros.rs:52-53: W == 0 writes nothing
+        pack_from_lds_image<T>(lds + j * G::BLOCK_BYTES, w, const_cast<char*>(a.packed) + off, lane);
+    }
+}
+
 template <typename T, int RD = RD_VGPR>
 __global__ __launch_bounds__(WG) void k_pack_widths(WidthsArgs a)
 {
-    for_each_block_of_wave<T>(a, [&](uint64_t blk, char* lds, unsigned lane) { pack_block_wave<T, RD>(a, blk, lds, lane); });
+    for_each_block_of_wave<T>(a, [&](uint64_t first, unsigned count, char* lds, unsigned lane) {
+        if (a.prefetch && count > 1 && !a.refs) {
+            pack_blocks_wave_prefetched<T>(a, first, count, lds, lane);
+            return;
+        }
+        for (unsigned j = 0; j < count; ++j) pack_block_wave<T, RD>(a, first + j, lds, lane);
+    });
 }
 
 typedef hipError_t (*widths_launch_t)(const WidthsArgs&, int waves, hipStream_t);
@@ -464,9 +581,9 @@ typedef hipError_t (*widths_launch_t)(const WidthsArgs&, int waves, hipStream_t)
 // read:write stream of the same bytes reaches 6.23-6.53 TB/s where this kernel reaches 6.37-6.66.  The shipped
 // occupancy / blocks-per-wavefront per type live in fl_dispatch.hpp (mixed_waves, mixed_blocks_per_wave).
 constexpr unsigned CU_LDS_BYTES = 160 * 1024;
-template <typename T> inline unsigned widths_lds_bytes(int waves)
+template <typename T> inline unsigned widths_lds_bytes(int waves, unsigned images_per_wave = 1)
 {
-    const unsigned need = (WG / 64) * WaveBlock<T>::BLOCK_BYTES;
+    const unsigned need = (WG / 64) * WaveBlock<T>::BLOCK_BYTES * images_per_wave;
     if (waves < 3) waves = 3;                     // 53 KiB per workgroup: stays below the 64 KiB default dynamic-LDS limit
     unsigned pad = (CU_LDS_BYTES / (unsigned)waves) & ~1023u;
     return pad > need ? pad : need;
@@ -483,7 +600,9 @@ hipError_t launch_widths(const WidthsArgs& a0, int waves, hipStream_t s)
     a.tiles_per_xcd = (n_tiles + 7) / 8;
     if (a.tiles_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;   // > 2^33 blocks in one launch
     const dim3 grid((unsigned)(a.tiles_per_xcd * 8));
-    const unsigned lds = widths_lds_bytes<T>(waves);
+    if (a.bpw < 2 || a.bpw > 16) a.prefetch = 0;
+    const unsigned lds = widths_lds_bytes<T>(waves, a.prefetch ? a.bpw : 1u);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;         // beyond the default dynamic-LDS limit
     if constexpr (PACK) hipLaunchKernelGGL((k_pack_widths<T, RD>), grid, dim3(WG), lds, s, a);
     else hipLaunchKernelGGL((k_unpack_widths<T, RD>), grid, dim3(WG), lds, s, a);
     return hipGetLastError();

@@ -69,10 +69,10 @@ def test_internal_kernel_policy_is_validated(lib):
     """include/fastlanes_amd_internal.h: mode 0..2, waves 0 or 3..8 and blocks-per-wave 0..16 (mode 2 only); anything
     else resets to 0 -- a stray value must not select a kernel shape that was never tested."""
     try:
-        for ok in (0, 1, 2, 2 + 256 * 3, 2 + 256 * 8, 2 + 65536 * 16, 2 + 256 * 6 + 65536 * 8):
+        for ok in (0, 1, 2, 2 + 256 * 3, 2 + 256 * 8, 2 + 65536 * 16, 2 + 256 * 6 + 65536 * 8, 2 + 65536 * 8 + (1 << 24)):
             lib.fl_internal_set_kernel_policy(ok)
             assert lib.fl_internal_get_kernel_policy() == ok
-        for bad in (-1, 3, 255, 2 + 256 * 2, 2 + 256 * 9, 2 + 65536 * 17, 1 + 256 * 4, 65536 * 2, 1 << 24, 2 + (1 << 30)):
+        for bad in (-1, 3, 255, 2 + 256 * 2, 2 + 256 * 9, 2 + 65536 * 17, 1 + 256 * 4, 65536 * 2, 1 << 24, 2 + (1 << 24), 2 + 65536 * 4 + (2 << 24), 2 + (1 << 30)):
             lib.fl_internal_set_kernel_policy(bad)
             assert lib.fl_internal_get_kernel_policy() == 0, bad
     finally:

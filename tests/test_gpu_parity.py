@@ -494,7 +494,7 @@ def test_unpack_pack_widths_device_resident(fl, oracle, ty):
 
 def test_mixed_width_fuzz_shapes_and_occupancies(fl, oracle, kernel_policy):
     """Seeded fuzz of the device-resident mixed-width kernels over (type, block count, widths incl. 0 and T, waves per SIMD,
-    blocks per wavefront): unpack_widths / pack_widths / unpack_single_widths against the oracle's per-block loop."""
+    blocks per wavefront, prefetch): unpack_widths / pack_widths / unpack_single_widths against the oracle's per-block loop."""
     import torch
     rng = np.random.default_rng(int(os.environ.get("FL_FUZZ_SEED", "2025")))
     for _ in range(int(os.environ.get("FL_FUZZ_ITERS", "48"))):
@@ -505,7 +505,8 @@ def test_mixed_width_fuzz_shapes_and_occupancies(fl, oracle, kernel_policy):
         n = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 31, 32, 33, 63, 65, 127, 129, 300]))
         waves = int(rng.choice([0, 3, 4, 6, 8]))
         bpw = int(rng.choice([0, 1, 2, 3, 8]))
-        kernel_policy(2 + 256 * waves + 65536 * bpw)
+        prefetch = int(rng.integers(0, 2)) if bpw >= 2 else 0      # all of a wavefront's blocks requested up front by LDS-DMA
+        kernel_policy(2 + 256 * waves + 65536 * bpw + (prefetch << 24))
         widths = rng.integers(0, T + 1, size=n).astype(np.uint8)
         off = np.concatenate([[0], np.cumsum(widths.astype(np.int64) * 128)])
         seed = int(rng.integers(0, 1 << 30))

@@ -29,10 +29,13 @@ for ty in ("u8", "u16", "u32", "u64"):
     nbytes = pbytes + n * 1024 * esz
     for name, f in (("unpack_widths", lambda: fl.unpack_widths(widths, offsets, pk, output=un, check=False)),
                     ("pack_widths", lambda: fl.pack_widths(widths, offsets, vals, pk2, check=False))):
-        for bpw in (1, 2, 4, 8):
+        shapes = [(1, 0), (2, 0), (4, 0), (8, 0)]
+        # + all of a wavefront's blocks requested up front by LDS-DMA (needs bpw * block bytes of LDS per wave)
+        shapes += [(b, 1) for b in (2, 4, 8, 16) if 4 * b * 128 * T <= 65536]
+        for bpw, prefetch in shapes:
             row = []
             for waves in (3, 4, 6, 8):
-                lib.fl_internal_set_kernel_policy(2 + 256 * waves + 65536 * bpw)
+                lib.fl_internal_set_kernel_policy(2 + 256 * waves + 65536 * bpw + (prefetch << 24))
                 t = []
                 for _ in range(3):
                     f(); torch.cuda.synchronize()
@@ -40,6 +43,6 @@ for ty in ("u8", "u16", "u32", "u64"):
                     a.record(); f(); b.record(); torch.cuda.synchronize()
                     t.append(a.elapsed_time(b))
                 row.append(nbytes / sorted(t)[1] / 1e6)
-            print(f"{ty:3s} {name:13s} bpw {bpw} | " + " ".join(f"{x:6.0f}" for x in row), flush=True)
+            print(f"{ty:3s} {name:13s} bpw {bpw:2d}{' prefetch' if prefetch else '         '} | " + " ".join(f"{x:6.0f}" for x in row), flush=True)
     lib.fl_internal_set_kernel_policy(0)
     del pk, un, vals, pk2, widths, offsets

@@ -1,6 +1,6 @@
 // abuniform.hip -- uniform-width columns: the shipped per-(T,W) cell-column kernels (fl_<ty>_pack / _unpack) vs the
 // generic wave-per-block kernels of fl_widths.hpp run with one width for every block, interleaved in one process on the
-// same buffers.  Build like tools/abmixed.hip; run on the GPU box: tools/abuniform [rounds]
+// same buffers.  Build like tools/abmixed.hip (against libfastlanes_amd_full.so); run on the GPU box: tools/abuniform [rounds] [width stride] [GiB per launch]
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -46,6 +46,8 @@ struct Variant { std::string name; std::function<void()> launch; std::vector<flo
 
 static char *g_un, *g_pk, *g_un2, *g_pk2;
 static unsigned long long* g_count;
+static uint64_t g_gb = 16;       // bytes moved per launch (GiB): BASELINE's configs are 50-100 GB columns, and the best occupancy
+                                 // of a few (T, W) moves with the column size (u64 W=15..17: 3 waves at 16 GB, 4+ at 100 GB)
 
 static uint64_t diff(const void* a, const void* b, uint64_t bytes)
 {
@@ -64,7 +66,7 @@ template <typename T> void run(unsigned W, int rounds)
 {
     constexpr unsigned TB = sizeof(T) * 8;
     const uint64_t bpb = 128ull * W + 128ull * TB;
-    const uint64_t n = (16ull << 30) / bpb;
+    const uint64_t n = (g_gb << 30) / bpb;
     const double bytes = (double)n * bpb;
     T* un = (T*)g_un; T* pk = (T*)g_pk; T* pk2 = (T*)g_pk2;
     WidthsArgs up{g_pk, g_un2, nullptr, nullptr, nullptr, nullptr, 0, n, 0, W, 1};
@@ -129,14 +131,15 @@ int main(int argc, char** argv)
 {
     setvbuf(stdout, nullptr, _IONBF, 0);
     const int rounds = argc > 1 ? atoi(argv[1]) : 5;
-    const uint64_t cap = (17ull << 30);
+    if (argc > 3) g_gb = strtoull(argv[3], nullptr, 10);
+    const uint64_t cap = ((g_gb + 1) << 30);
     CK(hipMalloc(&g_un, cap)); CK(hipMalloc(&g_pk, cap)); CK(hipMalloc(&g_un2, cap)); CK(hipMalloc(&g_pk2, cap));
     CK(hipMalloc(&g_count, 8));
     hipLaunchKernelGGL(k_fill, dim3(65536), dim3(256), 0, 0, (uint64_t*)g_pk, cap / 8);
     hipLaunchKernelGGL(k_fill, dim3(65536), dim3(256), 0, 0, (uint64_t*)g_un, cap / 8);
     CK(hipDeviceSynchronize());
     const int stride = argc > 2 ? atoi(argv[2]) : 1;
-    printf("GB/s (algorithmic bytes), median of %d; cc = shipped cell-column kernel, wpb = wave-per-block at 3 4 5 6 8 waves/SIMD\n", rounds);
+    printf("GB/s (algorithmic bytes), median of %d, %llu GiB per launch; cc = cell-column kernel, wpb = wave-per-block at 3 4 5 6 8 waves/SIMD\n", rounds, (unsigned long long)g_gb);
     run_all<uint32_t>(rounds, stride);
     run_all<uint64_t>(rounds, stride);
     run_all<uint16_t>(rounds, stride);

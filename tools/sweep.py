@@ -172,6 +172,76 @@ def main():
             print(f"unpack u32 W=7 n_blocks={nb:>7d}: {us:9.2f} us per call (back-to-back on one stream)  "
                   f"{nb * 1024 / us / 1e3:9.2f} Gint/s  {nb * 4992 / us / 1e3:8.1f} GB/s", flush=True)
         return
+    if args.cases == "refbench":
+        # What the reference's own criterion benches time (besides benches/bitpacking.rs, which bench.py's headline and
+        # cpu_baseline cover):
+        #   benches/delta.rs:10-44      fused undelta_pack::<W> vs unpack::<W> followed by undelta (u16 W=9), one block
+        #   benches/transpose.rs:8-19   transpose of one u16 block
+        # here batched over a column (HBM-resident, GB/s of algorithmic bytes) and as ONE-BLOCK device-tier calls (us per
+        # back-to-back call: launch-bound, the shape of the reference's bench).
+        def timed(f, reps):
+            for _ in range(3):
+                f()
+            torch.cuda.synchronize()
+            ms = []
+            for _ in range(reps):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); f(); b.record(); b.synchronize()
+                ms.append(a.elapsed_time(b))
+            return sorted(ms)[len(ms) // 2]
+
+        def per_call_us(f, reps=300):
+            for _ in range(20):
+                f()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                f()
+            b.record(); b.synchronize()
+            return a.elapsed_time(b) * 1e3 / reps
+
+        for ty, w in (("u16", 9), ("u32", 12)):
+            T = ESZ[ty] * 8
+            n = int(args.gb * 1e9 / (128 * w + 128 + 2 * 128 * T))
+            pk = rnd(n * 128 * w, 1).view(TDT[ty])
+            bases = rnd(n * 128, 3).view(TDT[ty])
+            out = torch.empty(n * 1024, dtype=TDT[ty], device=dev)
+            tmp = torch.empty(n * 1024, dtype=TDT[ty], device=dev)
+            fused = timed(lambda: fl.Delta.undelta_pack(w, pk, bases, output=out), args.reps)
+            want = out.clone()
+
+            def unfused():
+                fl.BitPacking.unpack(w, pk, output=tmp)
+                fl.Delta.undelta(tmp, bases, output=out)
+            unf = timed(unfused, args.reps)
+            same = torch.equal(want.view(torch.uint8), out.view(torch.uint8))
+            alg = n * (128 * w + 128 + 128 * T)
+            print(f"benches/delta.rs shape, {ty} W={w}, {n} blocks: fused undelta_pack {fused:8.4f} ms ({alg / fused / 1e6:7.1f} GB/s, "
+                  f"{n * 1024 / fused / 1e6:7.1f} Gint/s)  unpack + undelta {unf:8.4f} ms ({n * 1024 / unf / 1e6:7.1f} Gint/s)  "
+                  f"speed-up {unf / fused:.2f}x  results {'identical' if same else 'DIFFER'}", flush=True)
+            pk1, b1, o1, t1 = pk[:128 * w // ESZ[ty]], bases[:128 // ESZ[ty]], out[:1024], tmp[:1024]
+            f1 = per_call_us(lambda: fl.Delta.undelta_pack(w, pk1, b1, output=o1))
+
+            def unfused1():
+                fl.BitPacking.unpack(w, pk1, output=t1)
+                fl.Delta.undelta(t1, b1, output=o1)
+            u1 = per_call_us(unfused1)
+            print(f"    one block, device tier: fused {f1:6.2f} us per call, unpack + undelta {u1:6.2f} us  (speed-up {u1 / f1:.2f}x; launch-bound)", flush=True)
+            del pk, bases, out, tmp, want
+            torch.cuda.empty_cache()
+        for ty in ("u16",):
+            T = ESZ[ty] * 8
+            n = int(args.gb * 1e9 / (2 * 128 * T))
+            src = rnd(n * 128 * T, 1).view(TDT[ty])
+            dst = torch.empty_like(src)
+            for name, g in (("transpose", fl.Transpose.transpose), ("untranspose", fl.Transpose.untranspose)):
+                ms = timed(lambda: g(src, output=dst), args.reps)
+                s1, d1 = src[:1024], dst[:1024]
+                us = per_call_us(lambda: g(s1, output=d1))
+                print(f"benches/transpose.rs shape, {name} {ty}: {n} blocks {ms:8.4f} ms ({n * 2 * 128 * T / ms / 1e6:7.1f} GB/s, "
+                      f"{n * 1024 / ms / 1e6:7.1f} Gint/s); one block, device tier: {us:6.2f} us per call", flush=True)
+        return
     if args.cases == "single":
         # batched unpack_single (random access): 64 M random indices into a 1 M-block u32 W=7 column
         n, k = 1_000_000, 64_000_000
