@@ -554,6 +554,70 @@ def unpack_single_widths(widths, offsets, packed, index):
     return out
 
 
+class Batch:
+    """Many small arrays decoded / encoded in ONE launch (fl_<ty>_unpack_batch / _pack_batch): the shape of a columnar
+    engine's chunks -- Vortex keeps 64 Ki values (64 blocks) per chunk and loops `unchecked_unpack` over each
+    (bitpacking.rs:109-129), which is launch-bound as one call per chunk.  `packed[a]` / `unpacked[a]` are CUDA tensors of one
+    element type on one device (array a: n_blocks[a] blocks of width widths[a]); the constructor uploads the four per-array
+    device arrays (pointers, widths, block counts) once, unpack() / pack() are then one asynchronous launch each."""
+
+    def __init__(self, packed, unpacked, widths):
+        import torch
+        if not (len(packed) == len(unpacked) == len(widths)):
+            raise ValueError("packed, unpacked and widths must have one entry per array")
+        self.n = len(widths)
+        args_p = [_Arg(t) for t in packed]
+        args_u = [_Arg(t) for t in unpacked]
+        if self.n == 0:
+            raise ValueError("an empty batch has no element type")
+        self.ty = args_u[0].ty
+        T = _lib.BITS[self.ty]
+        w = np.asarray(list(widths), dtype=np.int64)
+        if (w < 0).any() or (w > T).any():
+            raise FastLanesError(1, f"fl_{self.ty}_unpack_batch")      # bitpacking.rs:93,126 unreachable!()
+        nb = []
+        for a, (p, u) in enumerate(zip(args_p, args_u)):
+            if p.ty != self.ty or u.ty != self.ty or not p.torch:
+                raise TypeError("all arrays of a batch are CUDA tensors of one element type")
+            _same_tier(args_u[0], p, u)
+            if u.n % 1024:
+                raise ValueError(f"array {a}: the unpacked array must hold 1024 elements per block")
+            if p.n != (u.n // 1024) * packed_len(self.ty, int(w[a])):
+                raise ValueError(f"array {a}: packed length {p.n} does not match {u.n // 1024} blocks of width {int(w[a])}")
+            nb.append(u.n // 1024)
+        self.device = args_u[0].x.device
+        self._keep = (list(packed), list(unpacked))                     # the pointer arrays below refer to these
+        up = lambda a, dt: torch.from_numpy(np.asarray(a, dtype=dt)).to(self.device)
+        self.d_packed = up([a.ptr for a in args_p], np.int64)
+        self.d_unpacked = up([a.ptr for a in args_u], np.int64)
+        self.d_widths = up(w, np.uint8)
+        self.d_n_blocks = up(nb, np.int32)
+        self.max_blocks = max(nb)
+        self.unpacked = list(unpacked)
+        self.packed = list(packed)
+
+    def _run(self, method, first, second, check):
+        import torch
+        err = torch.zeros(1, dtype=torch.int32, device=self.device) if check else None
+        with torch.cuda.device(self.device):
+            st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            _check(getattr(_lib.load(), f"fl_{self.ty}_{method}")(first.data_ptr(), second.data_ptr(), self.d_widths.data_ptr(),
+                                                                 self.d_n_blocks.data_ptr(), self.n, self.max_blocks,
+                                                                 err.data_ptr() if check else None, st), f"fl_{self.ty}_{method}")
+        if check:
+            _check_flag(err, f"fl_{self.ty}_{method}")
+
+    def unpack(self, check=False):
+        """packed[a] -> unpacked[a] for every array; returns the list of unpacked tensors."""
+        self._run("unpack_batch", self.d_packed, self.d_unpacked, check)
+        return self.unpacked
+
+    def pack(self, check=False):
+        """unpacked[a] -> packed[a] for every array; returns the list of packed tensors."""
+        self._run("pack_batch", self.d_unpacked, self.d_packed, check)
+        return self.packed
+
+
 class MixedWidthPlan:
     """A column whose blocks each have their own width (BASELINE.json config 5): the
     reference's caller loop `for b: T::unchecked_unpack(widths[b], ..)` (bitpacking.rs:109-129)

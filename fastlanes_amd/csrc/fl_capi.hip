@@ -8,6 +8,7 @@
 #include "fl_misc.hpp"
 #include "fl_widths.hpp"
 #include "fl_chain.hpp"
+#include "fl_batch.hpp"
 #include "fl_scan.hpp"
 #include "fl_consume.hpp"
 
@@ -110,9 +111,9 @@ int run_wave_uniform(bool pack, int waves, unsigned w, const T* packed, T* unpac
     a.n_blocks = n_blocks;
     a.tiles_per_xcd = 0;
     a.uniform_width = w;
-    a.bpw = 1;
+    a.bpw = uniform_blocks_per_wave(Elem<T>::BITS, pack);
     a.packed_bytes = 0;      // not read: uniform-width calls are validated here, on the host side
-    a.prefetch = 0;
+    a.prefetch = a.bpw > 1;
     hipError_t e = widths_launcher<T>(pack)(a, waves, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
@@ -471,6 +472,26 @@ int run_widths(bool pack, const uint8_t* widths, const uint64_t* offsets, const 
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
 
+// many small arrays, device arrays of pointers (fl_batch.hpp)
+template <typename T>
+int run_batch(bool pack, const void* const* packed, void* const* unpacked, const uint8_t* widths, const uint32_t* n_blocks,
+              size_t n_arrays, uint32_t max_blocks, uint32_t* err_flag, void* stream)
+{
+    if (n_arrays == 0 || max_blocks == 0) return FL_OK;
+    if (!packed || !unpacked || !widths || !n_blocks) return FL_ERR_NULL;
+    BatchArgs b;
+    b.packed = reinterpret_cast<const char* const*>(packed);
+    b.unpacked = reinterpret_cast<char* const*>(unpacked);
+    b.widths = widths;
+    b.n_blocks = n_blocks;
+    b.err_flag = err_flag;
+    b.n_arrays = n_arrays;
+    b.tiles_per_xcd = 0;
+    b.tiles_per_array = 0;
+    hipError_t e = batch_launcher<T>(pack)(b, max_blocks, mixed_waves(Elem<T>::BITS, pack), static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? FL_OK : hip_fail(e);
+}
+
 template <typename T>
 int run_mixed(bool pack, const fl_mixed_plan* p, const void* packed, void* unpacked, void* stream)
 {
@@ -622,6 +643,12 @@ size_t fl_packed_len(unsigned type_bits, unsigned width)
     { return run_widths<T>(false, w, o, pk, pb, out, n, ef, s); }                                         \
     int fl_##S##_pack_widths(const uint8_t* w, const uint64_t* o, const T* in, T* pk, size_t pb, size_t n, uint32_t* ef, void* s) \
     { return run_widths<T>(true, w, o, pk, pb, const_cast<T*>(in), n, ef, s); }                           \
+    int fl_##S##_unpack_batch(const T* const* pk, T* const* out, const uint8_t* w, const uint32_t* nb, size_t na, uint32_t mb, \
+                              uint32_t* ef, void* s)                                                      \
+    { return run_batch<T>(false, reinterpret_cast<const void* const*>(pk), reinterpret_cast<void* const*>(out), w, nb, na, mb, ef, s); } \
+    int fl_##S##_pack_batch(const T* const* in, T* const* pk, const uint8_t* w, const uint32_t* nb, size_t na, uint32_t mb, \
+                            uint32_t* ef, void* s)                                                        \
+    { return run_batch<T>(true, reinterpret_cast<const void* const*>(pk), (void* const*)in, w, nb, na, mb, ef, s); } \
     int fl_##S##_unpack_single_widths(const uint8_t* w, const uint64_t* o, const T* pk, size_t pb, size_t n, const uint64_t* idx, \
                                       size_t ni, T* out, uint32_t* ef, void* s)                           \
     { return dev_unpack_single_widths<T>(w, o, pk, pb, n, idx, ni, out, ef, s); }                         \

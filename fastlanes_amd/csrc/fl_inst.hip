@@ -10,6 +10,7 @@
 #include "fl_misc.hpp"
 #include "fl_widths.hpp"
 #include "fl_chain.hpp"
+#include "fl_batch.hpp"
 #include "fl_consume.hpp"
 
 namespace fl {
@@ -48,6 +49,10 @@ template <> hipError_t unpack_single_launch<T>(const SingleArgs& a, hipStream_t 
 template <> widths_launch_t widths_launcher<T>(bool pack)
 {
     return pack ? &launch_widths<T, true> : &launch_widths<T, false>;
+}
+template <> batch_launch_t batch_launcher<T>(bool pack)
+{
+    return pack ? &launch_batch<T, true> : &launch_batch<T, false>;
 }
 template <> chain_launch_t chain_launcher<T>(int op)
 {

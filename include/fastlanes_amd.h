@@ -219,6 +219,18 @@ const uint8_t *fl_mixed_plan_widths(const fl_mixed_plan *plan);
                                       const T *packed, size_t packed_bytes, size_t n_blocks,      \
                                       const uint64_t *indices, size_t n_indices, T *out,          \
                                       uint32_t *err_flag, void *stream);                          \
+    /* MANY SMALL ARRAYS in one launch -- the shape of a columnar engine's chunks (Vortex: 64 Ki values = 64 blocks per   \
+     * chunk), whose per-chunk loop over unchecked_unpack / unchecked_pack (bitpacking.rs:109-129, :76-96) is launch-bound  \
+     * when every chunk is its own call.  Four DEVICE arrays of length n_arrays: packed[a] / out[a] are device pointers      \
+     * (16-byte aligned) to array a's packed and unpacked blocks, widths[a] its width, n_blocks[a] its block count;          \
+     * max_blocks (host) >= every n_blocks[a] sizes the grid.  An array with a width > T or a misaligned / NULL pointer is    \
+     * skipped and FL_DEVERR_WIDTH / FL_DEVERR_ALIGN is ORed into *err_flag. */                                               \
+    int fl_##S##_unpack_batch(const T *const *packed, T *const *out, const uint8_t *widths,       \
+                              const uint32_t *n_blocks, size_t n_arrays, uint32_t max_blocks,     \
+                              uint32_t *err_flag, void *stream);                                  \
+    int fl_##S##_pack_batch(const T *const *in, T *const *packed, const uint8_t *widths,          \
+                            const uint32_t *n_blocks, size_t n_arrays, uint32_t max_blocks,       \
+                            uint32_t *err_flag, void *stream);                                    \
     /* the same over a mixed-width plan (see fl_mixed_plan) */                                     \
     int fl_##S##_unpack_mixed(const fl_mixed_plan *plan, const T *packed, T *out, void *stream); \
     int fl_##S##_pack_mixed(const fl_mixed_plan *plan, const T *in, T *packed, void *stream);    \

@@ -492,6 +492,53 @@ def test_unpack_pack_widths_device_resident(fl, oracle, ty):
     assert fl.unpack_widths(e8, o0, torch.empty(0, dtype=tdt, device="cuda:0")).numel() == 0
 
 
+@pytest.mark.parametrize("ty", TYS)
+def test_batch_of_small_arrays_vs_oracle(fl, oracle, ty):
+    """fl_<ty>_unpack_batch / _pack_batch: many small arrays (a columnar engine's chunks), each with its own width and block
+    count, given as device arrays of pointers -- ONE launch; every array against the oracle's per-block loop
+    (bitpacking.rs:109-129, :76-96).  Ragged counts incl. 0, widths incl. 0 and T, over-wide pack inputs, guard bytes."""
+    import torch
+    T = tbits(ty)
+    esz = T // 8
+    tdt = {"u8": torch.uint8, "u16": torch.uint16, "u32": torch.uint32, "u64": torch.uint64}[ty]
+    rng = np.random.default_rng(99 + T)
+    counts = [64, 1, 0, 5, 64, 33, 7, 64, 2, 130] + [int(x) for x in rng.integers(0, 70, size=40)]
+    widths = [int(x) for x in rng.integers(0, T + 1, size=len(counts))]
+    widths[0], widths[1], widths[4] = T, 0, 7 % (T + 1)
+    packed_np = [values(ty, n * packed_len(ty, w), 7000 + a) for a, (n, w) in enumerate(zip(counts, widths))]
+    packed = [to_dev(p) if p.size else torch.empty(0, dtype=tdt, device="cuda:0") for p in packed_np]
+    guard = 0xA5 if ty == "u8" else 0xA5A5
+    outs = [torch.full((n * 1024 + 64,), guard, dtype=tdt, device="cuda:0") for n in counts]
+    batch = fl.Batch(packed, [o[:n * 1024] for o, n in zip(outs, counts)], widths)
+    batch.unpack(check=True)
+    for a, (n, w) in enumerate(zip(counts, widths)):
+        got = to_np(outs[a], ty)
+        want = oracle.batch("unpack", ty, w, packed_np[a], n_blocks=n) if n else np.zeros(0, dtype=TYPES[ty][0])
+        assert np.array_equal(got[:n * 1024], want), (ty, a, n, w)
+        assert (got[n * 1024:] == guard).all(), "wrote past the end of an array"
+    # pack back from full-entropy values: truncation exactly like pack::<W> (macros.rs:73; none for W == T, :58)
+    vals_np = [values(ty, n * 1024, 8000 + a) for a, n in enumerate(counts)]
+    vals = [to_dev(v) if v.size else torch.empty(0, dtype=tdt, device="cuda:0") for v in vals_np]
+    pouts = [torch.full((n * packed_len(ty, w) + 64,), guard, dtype=tdt, device="cuda:0") for n, w in zip(counts, widths)]
+    fl.Batch([p[:n * packed_len(ty, w)] for p, n, w in zip(pouts, counts, widths)], vals, widths).pack(check=True)
+    for a, (n, w) in enumerate(zip(counts, widths)):
+        got = to_np(pouts[a], ty)
+        k = n * packed_len(ty, w)
+        want = oracle.batch("pack", ty, w, vals_np[a]) if k else np.zeros(0, dtype=TYPES[ty][0])
+        assert np.array_equal(got[:k], want), (ty, a, n, w)
+        assert (got[k:] == guard).all()
+    # errors: a width > T is refused on the host side of the mirror, and flagged by the kernel when it arrives in HBM
+    with pytest.raises(fl.FastLanesError):
+        fl.Batch(packed[:1], [outs[0][:counts[0] * 1024]], [T + 1])
+    b2 = fl.Batch(packed[:2], [outs[0][:counts[0] * 1024], outs[1][:counts[1] * 1024]], widths[:2])
+    b2.d_widths[0] = T + 1
+    with pytest.raises(fl.FastLanesError) as ei:
+        b2.unpack(check=True)
+    assert ei.value.status == 1
+    with pytest.raises(ValueError):
+        fl.Batch(packed[:1], [outs[0][:1024 * (counts[0] - 1)]], widths[:1])
+
+
 def test_mixed_width_fuzz_shapes_and_occupancies(fl, oracle, kernel_policy):
     """Seeded fuzz of the device-resident mixed-width kernels over (type, block count, widths incl. 0 and T, waves per SIMD,
     blocks per wavefront, prefetch): unpack_widths / pack_widths / unpack_single_widths against the oracle's per-block loop."""

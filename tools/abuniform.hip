@@ -1,10 +1,11 @@
 // abuniform.hip -- uniform-width columns: the shipped per-(T,W) cell-column kernels (fl_<ty>_pack / _unpack) vs the
 // generic wave-per-block kernels of fl_widths.hpp run with one width for every block, interleaved in one process on the
-// same buffers.  Build like tools/abmixed.hip (against libfastlanes_amd_full.so); run on the GPU box: tools/abuniform [rounds] [width stride] [GiB per launch]
+// same buffers.  Build like tools/abmixed.hip (against libfastlanes_amd_full.so); run on the GPU box: tools/abuniform [rounds] [width stride] [GiB per launch] [blocks per wavefront, prefetched; 0 = library default] [types, e.g. u8u16]
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <string>
 #include <vector>
@@ -46,6 +47,7 @@ struct Variant { std::string name; std::function<void()> launch; std::vector<flo
 
 static char *g_un, *g_pk, *g_un2, *g_pk2;
 static unsigned long long* g_count;
+static unsigned g_bpw = 0;       // 0 = what the library uses for uniform-width calls (fl_dispatch.hpp: uniform_blocks_per_wave); else forced, prefetched
 static uint64_t g_gb = 16;       // bytes moved per launch (GiB): BASELINE's configs are 50-100 GB columns, and the best occupancy
                                  // of a few (T, W) moves with the column size (u64 W=15..17: 3 waves at 16 GB, 4+ at 100 GB)
 
@@ -69,8 +71,9 @@ template <typename T> void run(unsigned W, int rounds)
     const uint64_t n = (g_gb << 30) / bpb;
     const double bytes = (double)n * bpb;
     T* un = (T*)g_un; T* pk = (T*)g_pk; T* pk2 = (T*)g_pk2;
-    WidthsArgs up{g_pk, g_un2, nullptr, nullptr, nullptr, nullptr, 0, n, 0, W, 1};
-    WidthsArgs pa{g_pk2, g_un, nullptr, nullptr, nullptr, nullptr, 0, n, 0, W, 1};
+    const unsigned bpw_u = g_bpw ? g_bpw : uniform_blocks_per_wave(TB, false), bpw_p = g_bpw ? g_bpw : uniform_blocks_per_wave(TB, true);
+    WidthsArgs up{g_pk, g_un2, nullptr, nullptr, nullptr, nullptr, 0, n, 0, W, bpw_u, 0, bpw_u > 1};
+    WidthsArgs pa{g_pk2, g_un, nullptr, nullptr, nullptr, nullptr, 0, n, 0, W, bpw_p, 0, bpw_p > 1};
     // correctness on these very buffers (library forced onto its cell-column kernels: policy 1)
     fl_internal_set_kernel_policy(1);
     Abi<T>::unpack(W, pk, un, n, nullptr);
@@ -132,6 +135,7 @@ int main(int argc, char** argv)
     setvbuf(stdout, nullptr, _IONBF, 0);
     const int rounds = argc > 1 ? atoi(argv[1]) : 5;
     if (argc > 3) g_gb = strtoull(argv[3], nullptr, 10);
+    if (argc > 4) g_bpw = (unsigned)atoi(argv[4]);
     const uint64_t cap = ((g_gb + 1) << 30);
     CK(hipMalloc(&g_un, cap)); CK(hipMalloc(&g_pk, cap)); CK(hipMalloc(&g_un2, cap)); CK(hipMalloc(&g_pk2, cap));
     CK(hipMalloc(&g_count, 8));
@@ -140,9 +144,10 @@ int main(int argc, char** argv)
     CK(hipDeviceSynchronize());
     const int stride = argc > 2 ? atoi(argv[2]) : 1;
     printf("GB/s (algorithmic bytes), median of %d, %llu GiB per launch; cc = cell-column kernel, wpb = wave-per-block at 3 4 5 6 8 waves/SIMD\n", rounds, (unsigned long long)g_gb);
-    run_all<uint32_t>(rounds, stride);
-    run_all<uint64_t>(rounds, stride);
-    run_all<uint16_t>(rounds, stride);
-    run_all<uint8_t>(rounds, stride);
+    const char* only = argc > 5 ? argv[5] : "";      // e.g. "u8u16"
+    if (!*only || strstr(only, "u32")) run_all<uint32_t>(rounds, stride);
+    if (!*only || strstr(only, "u64")) run_all<uint64_t>(rounds, stride);
+    if (!*only || strstr(only, "u16")) run_all<uint16_t>(rounds, stride);
+    if (!*only || strstr(only, "u8")) run_all<uint8_t>(rounds, stride);
     return 0;
 }

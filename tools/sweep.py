@@ -172,6 +172,45 @@ def main():
             print(f"unpack u32 W=7 n_blocks={nb:>7d}: {us:9.2f} us per call (back-to-back on one stream)  "
                   f"{nb * 1024 / us / 1e3:9.2f} Gint/s  {nb * 4992 / us / 1e3:8.1f} GB/s", flush=True)
         return
+    if args.cases == "batch":
+        # many small arrays per launch (fl_<ty>_unpack_batch) next to one device-tier call per array: 10 000 chunks of
+        # 64 blocks (64 Ki values, the chunk size of the callers SURVEY.md 8(b) names), u32
+        for w in (7, 12, 20):
+            n_arr, nb = 10000, 64
+            pk_all = rnd(n_arr * nb * 128 * w, 1).view(torch.uint32)
+            out_all = torch.empty(n_arr * nb * 1024, dtype=torch.uint32, device=dev)
+            ppb, opb = nb * 32 * w, nb * 1024
+            packed = [pk_all[a * ppb:(a + 1) * ppb] for a in range(n_arr)]
+            outs = [out_all[a * opb:(a + 1) * opb] for a in range(n_arr)]
+            batch = fl.Batch(packed, outs, [w] * n_arr)
+            for _ in range(3):
+                batch.unpack()
+            torch.cuda.synchronize()
+            ms = []
+            for _ in range(args.reps):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); batch.unpack(); b.record(); b.synchronize()
+                ms.append(a.elapsed_time(b))
+            t = sorted(ms)[len(ms) // 2]
+            want = fl.BitPacking.unpack(w, pk_all)
+            same = torch.equal(want.view(torch.int32), out_all.view(torch.int32))
+            nbytes = n_arr * nb * (128 * w + 4096)
+            # the same arrays as one call each (what a chunk-at-a-time caller does today), through the raw C ABI
+            lib = fl.load()
+            f = lib.fl_u32_unpack
+            ptrs = [(p.data_ptr(), o.data_ptr()) for p, o in zip(packed, outs)]
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            a.record()
+            for p, o in ptrs:
+                f(w, p, o, nb, None)
+            b.record(); b.synchronize()
+            t1 = a.elapsed_time(b)
+            print(f"unpack_batch u32 W={w}: {n_arr} arrays x {nb} blocks in one launch {t:8.4f} ms  {n_arr * nb * 1024 / t / 1e6:7.1f} Gint/s  "
+                  f"{nbytes / t / 1e6:7.1f} GB/s ({nbytes / t / 8e9:.3f} of peak)  {'== one big unpack' if same else 'MISMATCH'} | "
+                  f"one call per array: {t1:8.3f} ms  {n_arr * nb * 1024 / t1 / 1e6:7.1f} Gint/s  (x{t1 / t:.1f})", flush=True)
+            del batch, pk_all, out_all, want
+        return
     if args.cases == "refbench":
         # What the reference's own criterion benches time (besides benches/bitpacking.rs, which bench.py's headline and
         # cpu_baseline cover):
