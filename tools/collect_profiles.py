@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Copies the judged summaries of a `bash tools/gpu/evidence.sh <round>` run from gpurun_out/<round>/ (scratch) into
+profiles/ (tracked), named <round>_*.      python tools/collect_profiles.py r03"""
+import glob
+import json
+import os
+import shutil
+import sys
+
+RD = sys.argv[1] if len(sys.argv) > 1 else "r03"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out", RD)
+P = os.path.join(ROOT, "profiles")
+
+
+def cp(src, dst):
+    if os.path.exists(src) and os.path.getsize(src) > 0:
+        shutil.copy(src, os.path.join(P, dst))
+        print("copied", dst)
+    else:
+        print("MISSING", src)
+
+
+cp(os.path.join(G, "bench_u32w7.json"), f"{RD}_bench_u32w7.json")
+cp(os.path.join(G, "bench_other.jsonl"), f"{RD}_bench_other_workloads.jsonl")
+cp(os.path.join(G, "host_latency.txt"), f"{RD}_host_latency.txt")
+cp(os.path.join(G, "bench_2ranks_gloo.json"), f"{RD}_bench_2ranks_one_device_gloo.json")
+cp(os.path.join(G, "bench_2ranks_auto.json"), f"{RD}_bench_2ranks_one_device_rccl_attempt.json")
+cp(os.path.join(G, "multi_gpu_decode.json"), f"{RD}_multi_gpu_decode_c_driver.json")
+cp(os.path.join(G, "multi_gpu_decode_2threads.json"), f"{RD}_multi_gpu_decode_c_driver_2threads.json")
+for c in ("quick", "fused", "consume", "refbench", "batch"):
+    cp(os.path.join(G, f"sweep_{c}.txt"), f"{RD}_sweep_{c}.txt")
+for tag, dst in (("prof_trace", f"{RD}_bench_u32w7"), ("prof_trace_mixed", f"{RD}_bench_u32_mixed")):
+    for f in glob.glob(os.path.join(G, tag, "**", "*kernel_stats.csv"), recursive=True):
+        cp(f, dst + "_kernel_stats.csv")
+for log, dst in (("bench_under_rocprof.log", f"{RD}_bench_u32w7_under_rocprof.json"),
+                 ("bench_mixed_under_rocprof.log", f"{RD}_bench_u32_mixed_under_rocprof.json")):
+    src = os.path.join(G, log)
+    if os.path.exists(src):
+        with open(src) as f, open(os.path.join(P, dst), "w") as o:
+            o.writelines(l for l in f if l.startswith('{"metric"'))
+try:
+    d = json.load(open(os.path.join(G, "bench_u32w7.json")))
+    print("HEADLINE", d["value"], d["roofline"]["achieved"], d["roofline"]["frac"], "traffic", d["roofline"]["traffic"],
+          "cpu", d["cpu_baseline"]["value"], "config5", d["config5_strong"]["value"], d["config5_strong"]["per_rank"][0]["frac"])
+except Exception as e:
+    print("no headline:", e)
+for l in open(os.path.join(G, "bench_other.jsonl")):
+    d = json.loads(l)
+    print(d["config"]["workload"][:60], d["value"], "Gint/s", d["roofline"]["achieved"], "GB/s", d["roofline"]["frac"],
+          "traffic", d["roofline"]["traffic"], "cpu", (d.get("cpu_baseline") or {}).get("value"))
