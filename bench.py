@@ -332,6 +332,20 @@ def nccl_probe_child(args):
     os._exit(0 if ok else 3)          # no destructors: a half-dead communicator must not hang the exit
 
 
+class stdout_to_stderr:
+    """Redirect file descriptor 1 to 2 for the duration (C++ libraries that print to stdout)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 class Control:
     """barrier / max / gather over the ranks.  The data path needs none of it, so RCCL is an
     option, never a requirement: `backend` is what is actually in use."""
@@ -346,7 +360,9 @@ class Control:
         if world == 1:
             return
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=30))
+        with stdout_to_stderr():          # gloo announces its connections on stdout; stdout carries exactly ONE JSON line
+            dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=30))
+            dist.barrier()
         self.backend = "gloo"
         if args.backend == "gloo" or (args.dry_run and not args.probe_nccl):
             return
@@ -378,10 +394,11 @@ class Control:
         # 2. the probe worked everywhere: the same thing in-process, still guarded
         try:
             os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")     # a timeout raises instead of aborting the process
-            g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=args.nccl_probe_timeout))
-            t = torch.ones(1, device=dev)
-            dist.all_reduce(t, group=g)
-            torch.cuda.synchronize()
+            with stdout_to_stderr():
+                g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=args.nccl_probe_timeout))
+                t = torch.ones(1, device=dev)
+                dist.all_reduce(t, group=g)
+                torch.cuda.synchronize()
             if int(t.item()) != world:
                 raise RuntimeError(f"all_reduce over RCCL returned {t.item()} for {world} ranks")
         except Exception as e:

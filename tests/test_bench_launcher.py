@@ -19,8 +19,9 @@ def _clean_env():
 
 
 def _one_json_line(stdout):
-    lines = [l for l in stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, stdout          # rank 0 prints ONE line, the other ranks nothing
+    lines = [l for l in stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), stdout     # stdout carries ONE line (rank 0's), nothing else --
+    #                                                                 not even gloo's "[Gloo] Rank 0 is connected ..." chatter
     return json.loads(lines[0])
 
 

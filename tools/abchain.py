@@ -23,12 +23,14 @@ GB = 12
 if ALL:
     cases = [(ty, w) for ty in ("u32", "u64", "u16", "u8") for w in range(TD[ty][1] + 1)]
     GB = 6
+if "--gb" in sys.argv:             # bytes moved per launch; BASELINE's config 4 is a 57.6 GB launch
+    GB = int(sys.argv[sys.argv.index("--gb") + 1])
 print("GB/s, median of %d; cc = cell-column, then wave-per-block at %s waves/SIMD" % (ROUNDS, " ".join(map(str, WAVES))))
 seen_plain = set()
 for ty, W in cases:
     tdt, T = TD[ty]
     esz = T // 8
-    n = (GB << 30) // (128 * W + 128 * T + 128)
+    n = min(10_000_000, (GB << 30) // (128 * W + 128 * T + 128))
     pk = rand_u8(n * 128 * W, 2, dev).view(tdt)
     un = rand_u8(n * 1024 * esz, 1, dev).view(tdt)
     out = torch.empty(n * 1024, dtype=tdt, device=dev)

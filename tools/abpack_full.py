@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
-"""A/B on the GPU box at BASELINE's full 10 M blocks: pack / unpack of configs 2 and 3 through the cell-column kernels vs the
-wave-per-block kernels at several occupancies, same buffers, full-entropy inputs (fl_internal_set_kernel_policy)."""
+"""A/B on the GPU box at BASELINE-like sizes: pack / unpack through the cell-column kernels vs the wave-per-block kernels at
+3/4/5/6/8 waves per SIMD, on the SAME torch-allocated buffers (the allocation pattern of bench.py), full-entropy inputs.
+    FL_LIB=$PWD/fastlanes_amd/libfastlanes_amd_full.so python tools/abpack_full.py [--all] [--gb 64] [--rounds 3]
+Default: BASELINE's configs 2, 3 (and u32 W=12) at the full 10 M blocks.  --all: every (T, W) at min(10 M blocks, --gb GB per
+launch), printed in tools/abuniform's row format -- the input of tools/make_dispatch.py (which kernel and which occupancy
+stream faster moves with the column size and the allocation: the 16-GiB hipMalloc sweeps of abuniform prefer fewer waves than
+a 50-100 GB column does)."""
 import os
 import sys
 
@@ -11,30 +16,44 @@ import fastlanes_amd as fl  # noqa: E402
 from bench import rand_u8  # noqa: E402
 
 lib = fl.load()
+assert b"FULL build" in lib.fl_version(), "run against libfastlanes_amd_full.so (FL_LIB=...): policy 1 must mean the cell-column kernel"
 dev = torch.device("cuda", 0)
-n = 10_000_000
+ALL = "--all" in sys.argv
+GB = float(sys.argv[sys.argv.index("--gb") + 1]) if "--gb" in sys.argv else 64.0
+ROUNDS = int(sys.argv[sys.argv.index("--rounds") + 1]) if "--rounds" in sys.argv else (3 if ALL else 5)
 WAVES = (3, 4, 5, 6, 8)
-print("GB/s at 10 M blocks, median of 5; cc, then wave-per-block at", WAVES, "waves/SIMD; '*' = what the automatic policy runs")
-for ty, tdt, T, W in (("u32", torch.uint32, 32, 7), ("u64", torch.uint64, 64, 17), ("u32", torch.uint32, 32, 12)):
+TD = {"u8": (torch.uint8, 8), "u16": (torch.uint16, 16), "u32": (torch.uint32, 32), "u64": (torch.uint64, 64)}
+cases = [("u32", 7), ("u64", 17), ("u32", 12)]
+if ALL:
+    cases = [(ty, w) for ty in ("u32", "u64", "u16", "u8") for w in range(TD[ty][1] + 1)]
+print(f"GB/s (algorithmic bytes), median of {ROUNDS}, min(10 M blocks, {GB:.0f} GB) per launch, torch allocations; cc = cell-column kernel, "
+      "wpb = wave-per-block at 3 4 5 6 8 waves/SIMD")
+cur = None
+for ty, W in cases:
+    tdt, T = TD[ty]
     esz = T // 8
-    un = rand_u8(n * 1024 * esz, 1, dev).view(tdt)
-    pk = rand_u8(n * 128 * W, 2, dev).view(tdt)
-    nbytes = n * (128 * W + 1024 * esz)
-    for name, f in (("pack", lambda: fl.BitPacking.pack(W, un, output=pk)), ("unpack", lambda: fl.BitPacking.unpack(W, pk, output=un))):
-        if name == "unpack":
-            pk = rand_u8(n * 128 * W, 3, dev).view(tdt)
+    bpb = 128 * W + 1024 * esz
+    n = min(10_000_000, int(GB * 1e9 / bpb))
+    if cur != (ty, n):           # the unpacked buffers are shared by every width of a type (same placement for all of them)
+        un = rand_u8(n * 1024 * esz, 1, dev).view(tdt)           # pack input: full-entropy values (pack truncates)
+        un_out = torch.empty(n * 1024, dtype=tdt, device=dev)
+        cur = (ty, n)
+    pk_in = rand_u8(n * 128 * W, 2, dev).view(tdt)
+    pk_out = torch.empty(n * 128 * W // esz, dtype=tdt, device=dev)
+    row = {}
+    for name, f in (("unpack", lambda: fl.BitPacking.unpack(W, pk_in, output=un_out, n_blocks=n)), ("pack", lambda: fl.BitPacking.pack(W, un, output=pk_out))):
         res = {}
-        pols = [0, 1] + [2 + 256 * w for w in WAVES]
-        for _ in range(5):
+        pols = [1] + [2 + 256 * w for w in WAVES]
+        for _ in range(ROUNDS):
             for p in pols:
                 lib.fl_internal_set_kernel_policy(p)
                 f(); torch.cuda.synchronize()
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record(); f(); b.record(); torch.cuda.synchronize()
                 res.setdefault(p, []).append(a.elapsed_time(b))
-        g = [nbytes / sorted(res[p])[2] / 1e6 for p in pols]
-        print(f"{ty} W={W:<2d} {name:6s} | auto {g[0]:6.0f} | cc {g[1]:6.0f} | wpb " + " ".join(f"{x:6.0f}" for x in g[2:]), flush=True)
-        if name == "pack":
-            un = rand_u8(n * 1024 * esz, 4, dev).view(tdt)      # unpack overwrote nothing yet, but keep inputs fresh per op
+        row[name] = [n * bpb / sorted(res[p])[len(res[p]) // 2] / 1e6 for p in pols]
     lib.fl_internal_set_kernel_policy(0)
-    del un, pk
+    u, p = row["unpack"], row["pack"]
+    print(f"u{T:<2d} W={W:<2d} | unpack cc {u[0]:6.0f}  wpb " + " ".join(f"{x:6.0f}" for x in u[1:]) +
+          f" | pack cc {p[0]:6.0f}  wpb " + " ".join(f"{x:6.0f}" for x in p[1:]), flush=True)
+    del pk_in, pk_out

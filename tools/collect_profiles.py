@@ -24,8 +24,12 @@ def cp(src, dst):
 cp(os.path.join(G, "bench_u32w7.json"), f"{RD}_bench_u32w7.json")
 cp(os.path.join(G, "bench_other.jsonl"), f"{RD}_bench_other_workloads.jsonl")
 cp(os.path.join(G, "host_latency.txt"), f"{RD}_host_latency.txt")
-cp(os.path.join(G, "bench_2ranks_gloo.json"), f"{RD}_bench_2ranks_one_device_gloo.json")
-cp(os.path.join(G, "bench_2ranks_auto.json"), f"{RD}_bench_2ranks_one_device_rccl_attempt.json")
+for src, dst in (("bench_2ranks_gloo.json", f"{RD}_bench_2ranks_one_device_gloo.json"),
+                 ("bench_2ranks_auto.json", f"{RD}_bench_2ranks_one_device_rccl_attempt.json")):
+    if os.path.exists(os.path.join(G, src)):
+        with open(os.path.join(G, src)) as f, open(os.path.join(P, dst), "w") as o:
+            o.writelines(l for l in f if l.startswith("{"))
+        print("copied", dst)
 cp(os.path.join(G, "multi_gpu_decode.json"), f"{RD}_multi_gpu_decode_c_driver.json")
 cp(os.path.join(G, "multi_gpu_decode_2threads.json"), f"{RD}_multi_gpu_decode_c_driver_2threads.json")
 for c in ("quick", "fused", "consume", "refbench", "batch"):
