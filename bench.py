@@ -382,8 +382,9 @@ class Control:
                    "--nccl-probe-timeout", str(args.nccl_probe_timeout)] + (["--single-device"] if args.single_device else [])
             r = subprocess.run(cmd, env=env, timeout=args.nccl_probe_timeout + 60, capture_output=True, text=True)
             if r.returncode != 0:
-                tail = (r.stderr or "").strip().splitlines()[-1:] or ["no stderr"]
-                err = f"RCCL probe exited {r.returncode}: {tail[0][:200]}"
+                lines = [l.strip() for l in (r.stderr or "").splitlines() if l.strip()]
+                telling = [l for l in lines if "Error" in l or "error" in l] or lines[-1:] or ["no stderr"]
+                err = f"RCCL probe exited {r.returncode}: {telling[-1][:240]}"
         except subprocess.TimeoutExpired:
             err = f"RCCL probe timed out after {args.nccl_probe_timeout + 60:.0f} s"
         except Exception as e:       # the probe must never take the bench down
