@@ -51,8 +51,11 @@ struct StreamArgs {
 //    LDS staging buffer, 1 KiB contiguous per store instruction (WaveRowStore):
 //    +1.7..3.4 % and less box-to-box spread.
 // ---------------------------------------------------------------------------
-constexpr int STORE_AUX = 18;   // nt (2) | sc1 (16)
+// nt (2) | sc1 (16).  Round 3 re-tried 2, 3, 16, 17 and 19 on the wave-per-block kernels (separate processes, so +-3 % of
+// placement noise): none stands out against 18; plain sc1 (16) is 2 % behind.
+constexpr int STORE_AUX = 18;
 
+// (u8 / u16 at 4, 5 and 8 waves per SIMD measured equal or worse on the same buffers, round 3; only u8 W=1 gained.)
 template <typename T, int W> struct UnpackPolicy {
     static constexpr int MAXW = 2;          // bodies that keep all T rows in registers, and the mixed path
     static constexpr int MAXW_ROWS = 3;     // stateless row-at-a-time bodies (store / FoR)

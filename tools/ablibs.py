@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""A/B on the GPU box: the same entry points of several BUILDS of the library on the same buffers, interleaved -- e.g. builds
+before / after a kernel change, or with an experiment macro set differently (round 3: waves-per-SIMD caps of the fused
+consumers, occupancy of the narrow types' cell-column kernels).
+    python tools/ablibs.py <rounds> <ops> <cases> lib_a.so lib_b.so ...
+      ops    comma list of: unpack pack undelta_pack compare sums
+      cases  comma list of type:width, e.g. u8:3,u8:6,u16:3   (or "consumers" = round 3's consumer sweep)
+GB/s of algorithmic bytes, median."""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from bench import rand_u8  # noqa: E402
+
+ROUNDS = int(sys.argv[1])
+OPS = sys.argv[2].split(",")
+if sys.argv[3] == "consumers":
+    cases = [("u32", w) for w in (2, 4, 7, 10, 12, 16, 20, 24, 28, 32)] + [("u64", w) for w in (4, 8, 12, 17, 24, 40, 56)] + \
+            [("u16", w) for w in (3, 6, 9, 12, 16)] + [("u8", w) for w in (3, 6, 8)]
+else:
+    cases = [(c.split(":")[0], int(c.split(":")[1])) for c in sys.argv[3].split(",")]
+libs = [(os.path.basename(p), ctypes.CDLL(os.path.abspath(p))) for p in sys.argv[4:]]
+dev = torch.device("cuda", 0)
+TD = {"u8": (torch.uint8, 8), "u16": (torch.uint16, 16), "u32": (torch.uint32, 32), "u64": (torch.uint64, 64)}
+CT = {"u8": ctypes.c_uint8, "u16": ctypes.c_uint16, "u32": ctypes.c_uint32, "u64": ctypes.c_uint64}
+P, Z, U = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint
+print("GB/s, median of %d; columns: %s" % (ROUNDS, "  ".join(n for n, _ in libs)))
+for ty, W in cases:
+    tdt, T = TD[ty]
+    esz = T // 8
+    for op in OPS:
+        bpb = {"compare": 128 * W + 128, "sums": 128 * W + 8, "undelta_pack": 128 * W + 128 + 128 * T}.get(op, 128 * W + 128 * T)
+        n = int(8e9 / bpb)
+        pk = rand_u8(n * 128 * W, 2, dev).view(tdt)
+        un = rand_u8(n * 128 * T, 3, dev).view(tdt) if op == "pack" else None
+        bases = rand_u8(n * 128, 4, dev).view(tdt) if op == "undelta_pack" else None
+        out_bytes = {"compare": n * 128, "sums": n * 8, "pack": n * 128 * W}.get(op, n * 128 * T)
+        out = torch.empty(max(out_bytes, 16) // 4, dtype=torch.int32, device=dev)
+        fns = []
+        for _, lib in libs:
+            if op == "compare":
+                f = getattr(lib, f"fl_{ty}_unpack_compare"); f.argtypes = [U, P, ctypes.c_int, CT[ty], Z, P, P]
+                fns.append(lambda f=f: f(W, pk.data_ptr(), 2, (1 << W) // 2, n, out.data_ptr(), None))
+            elif op == "sums":
+                f = getattr(lib, f"fl_{ty}_unpack_block_sums"); f.argtypes = [U, P, Z, P, P]
+                fns.append(lambda f=f: f(W, pk.data_ptr(), n, out.data_ptr(), None))
+            elif op == "unpack":
+                f = getattr(lib, f"fl_{ty}_unpack"); f.argtypes = [U, P, P, Z, P]
+                fns.append(lambda f=f: f(W, pk.data_ptr(), out.data_ptr(), n, None))
+            elif op == "pack":
+                f = getattr(lib, f"fl_{ty}_pack"); f.argtypes = [U, P, P, Z, P]
+                fns.append(lambda f=f: f(W, un.data_ptr(), out.data_ptr(), n, None))
+            else:
+                f = getattr(lib, f"fl_{ty}_undelta_pack"); f.argtypes = [U, P, P, P, Z, P]
+                fns.append(lambda f=f: f(W, pk.data_ptr(), bases.data_ptr(), out.data_ptr(), n, None))
+        ref, same = None, True
+        for f in fns:
+            out.zero_()
+            assert f() == 0
+            torch.cuda.synchronize()
+            if ref is None:
+                ref = out.clone()
+            else:
+                same = same and torch.equal(ref, out)
+        ms = [[] for _ in fns]
+        for _ in range(ROUNDS):
+            for k, f in enumerate(fns):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); f(); b.record(); b.synchronize()
+                ms[k].append(a.elapsed_time(b))
+        g = [n * bpb / sorted(m)[len(m) // 2] / 1e6 for m in ms]
+        print(f"{ty:3s} W={W:<2d} {op:12s}{'' if same else ' MISMATCH'} | " + " ".join(f"{x:6.0f}" for x in g), flush=True)
+        del pk, out, ref, un, bases
