@@ -74,6 +74,27 @@ template <typename T> __device__ __forceinline__ T group8_minmax(T v, bool want_
     return v;
 }
 
+// Narrow widths are VALU-bound when every field is extracted (profiles/r03_pmc_sq_derived.txt: 0.80 of the issue rate at u16
+// W=3).  The SUM of a block does not need the fields: bit p of an FL lane's stream is bit (p mod W) of field p / W
+// (macros.rs:72-92), so
+//     sum over all 1024 values = sum_{b < W} 2^b * popcount(packed bits whose stream position is = b mod W),
+// and a packed 32-bit register holds stream positions  row*T + (bit mod T)  of 32/T lanes at once: one v_and + one
+// accumulating v_bcnt per (register, class), 2*W operations per register = W*W/16 per value (0.56 at W=3 instead of 2.2).
+// Pays for W <= 5; exact (the counts are small integers, the weighted sum fits 64 bits).
+template <typename T, int W> constexpr bool sums_by_bit_class() { return W >= 1 && W <= 5 && W < (int)(sizeof(T) * 8); }
+
+// 32-bit mask of the bits of packed row `row` (register half `half` of a u64 word) whose stream position is = b mod W
+template <typename T, int W> constexpr uint32_t bit_class_mask(int row, int half, int b)
+{
+    constexpr int TB = (int)sizeof(T) * 8;
+    uint32_t m = 0;
+    for (int i = 0; i < 32; ++i) {
+        const int j = TB >= 32 ? i + 32 * half : i % TB;          // bit inside the T-bit word
+        if ((row * TB + j) % W == b) m |= 1u << i;
+    }
+    return m;
+}
+
 template <typename T, int W>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, sums_max_waves(W)))) void k_unpack_block_sums(ReduceArgs a)
 {
@@ -87,7 +108,25 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, sums_max_
     const u32x4* pk = a.in + blk * (uint64_t)(8 * W) + c;
     static_for<W>([&](auto Wd) { in[decltype(Wd)::value] = load_cell<T, true>(pk + 8 * decltype(Wd)::value); });
     uint64_t acc = 0;
-    unpack_rows<T, W>(in, [&](auto, const Cell<T>& v) { acc += cell_hsum<T>(v); });
+    if constexpr (sums_by_bit_class<T, W>()) {
+        uint32_t cnt[W];
+        static_for<W>([&](auto B) { cnt[decltype(B)::value] = 0; });
+        static_for<W>([&](auto Row) {
+            constexpr int row = decltype(Row)::value;
+            const u32x4 r = __builtin_bit_cast(u32x4, in[row]);
+            static_for<4>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                static_for<W>([&](auto B) {
+                    constexpr int b = decltype(B)::value;
+                    constexpr uint32_t m = bit_class_mask<T, W>(row, sizeof(T) == 8 ? (k & 1) : 0, b);
+                    cnt[b] += __builtin_popcount(r[k] & m);
+                });
+            });
+        });
+        static_for<W>([&](auto B) { acc += (uint64_t)cnt[decltype(B)::value] << decltype(B)::value; });
+    } else {
+        unpack_rows<T, W>(in, [&](auto, const Cell<T>& v) { acc += cell_hsum<T>(v); });
+    }
     acc = group8_sum(acc);
     if (c == 0) static_cast<uint64_t*>(a.out0)[blk] = acc;
 }

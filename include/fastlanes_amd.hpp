@@ -63,6 +63,8 @@ template <typename T> struct Abi;
         static constexpr auto unpack_widths = fl_##S##_unpack_widths;                                \
         static constexpr auto pack_widths = fl_##S##_pack_widths;                                    \
         static constexpr auto unpack_single_widths = fl_##S##_unpack_single_widths;                  \
+        static constexpr auto unpack_batch = fl_##S##_unpack_batch;                                  \
+        static constexpr auto pack_batch = fl_##S##_pack_batch;                                      \
         static constexpr auto pack_host = fl_##S##_pack_host;                                        \
         static constexpr auto unpack_host = fl_##S##_unpack_host;                                    \
         static constexpr auto unpack_single_host = fl_##S##_unpack_single_host;                      \
@@ -263,5 +265,15 @@ template <typename T>
 inline void widths_to_offsets_device(const std::uint8_t* d_widths, std::size_t n_blocks, std::uint64_t* d_offsets,
                                      std::uint64_t* d_total_bytes = nullptr, std::uint32_t* d_err_flag = nullptr, void* stream = nullptr)
 { detail::check(fl_widths_to_offsets(sizeof(T) * 8, d_widths, n_blocks, d_offsets, d_total_bytes, d_err_flag, stream), "widths_to_offsets"); }
+
+// Many small arrays (a columnar engine's chunks) in one launch: device arrays of device pointers / widths / block counts.
+template <typename T>
+inline void unpack_batch_device(const T* const* d_packed, T* const* d_out, const std::uint8_t* d_widths, const std::uint32_t* d_n_blocks,
+                                std::size_t n_arrays, std::uint32_t max_blocks, std::uint32_t* d_err_flag = nullptr, void* stream = nullptr)
+{ detail::check(detail::Abi<T>::unpack_batch(d_packed, d_out, d_widths, d_n_blocks, n_arrays, max_blocks, d_err_flag, stream), "unpack_batch"); }
+template <typename T>
+inline void pack_batch_device(const T* const* d_in, T* const* d_packed, const std::uint8_t* d_widths, const std::uint32_t* d_n_blocks,
+                              std::size_t n_arrays, std::uint32_t max_blocks, std::uint32_t* d_err_flag = nullptr, void* stream = nullptr)
+{ detail::check(detail::Abi<T>::pack_batch(d_in, d_packed, d_widths, d_n_blocks, n_arrays, max_blocks, d_err_flag, stream), "pack_batch"); }
 
 }  // namespace fastlanes

@@ -223,6 +223,22 @@ static void test_device_tier()
     EXPECT(dmu2.down() == v);
     EXPECT(derr.down()[0] == 0u);
     EXPECT(hipDeviceSynchronize() == hipSuccess);
+    // the same blocks as MANY SMALL ARRAYS in one launch (device arrays of pointers): 4 arrays of N/4 blocks, widths 7 / 9 / 7 / 9
+    // are not uniform per array here, so take arrays of ONE block each with that block's width -- N arrays
+    std::vector<const uint32_t*> hp(N);
+    std::vector<uint32_t*> ho(N);
+    std::vector<uint64_t> hoff = doff.down();
+    std::vector<uint32_t> hnb(N, 1u);
+    DevVec<uint32_t> dmu3(N * 1024);
+    for (size_t b = 0; b < N; ++b) { hp[b] = dm2.p + hoff[b] / 4; ho[b] = dmu3.p + b * 1024; }
+    DevVec<const uint32_t*> dpp(N);
+    DevVec<uint32_t*> dop(N);
+    DevVec<uint32_t> dnb(N);
+    dpp.up(hp); dop.up(ho); dnb.up(hnb);
+    unpack_batch_device<uint32_t>(dpp.p, dop.p, dw.p, dnb.p, N, 1, derr.p);
+    EXPECT(dmu3.down() == v);
+    EXPECT(derr.down()[0] == 0u);
+    EXPECT(hipDeviceSynchronize() == hipSuccess);
 }
 
 int main()
