@@ -21,6 +21,7 @@ struct BatchArgs {
     uint64_t n_arrays;
     uint64_t tiles_per_xcd;
     unsigned tiles_per_array;    // ceil(max_blocks / 4)
+    unsigned max_blocks;         // the caller's bound on n_blocks[a]
 };
 
 template <typename T, bool PACK>
@@ -35,7 +36,10 @@ __global__ __launch_bounds__(WG) void k_batch(BatchArgs b)
     const unsigned tid = threadIdx.x;
     const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
     const uint64_t blk = (tile - arr * b.tiles_per_array) * (WG / 64) + wave;
-    if (blk >= b.n_blocks[arr]) return;
+    const unsigned nb = b.n_blocks[arr];
+    if (blk >= nb) return;
+    // a bound that is too small would leave the array's tail undecoded without a trace: flag it (once per array)
+    if (blk == 0 && nb > b.max_blocks) raise_device_error(b.err_flag, DEVERR_BOUNDS, lane);
     WidthsArgs a;
     a.packed = b.packed[arr];
     a.unpacked = b.unpacked[arr];
@@ -44,7 +48,7 @@ __global__ __launch_bounds__(WG) void k_batch(BatchArgs b)
     a.err_flag = b.err_flag;
     a.refs = nullptr;
     a.ref_stride = 0;
-    a.n_blocks = b.n_blocks[arr];
+    a.n_blocks = nb;
     a.tiles_per_xcd = 0;
     a.uniform_width = b.widths[arr];
     a.bpw = 1;
@@ -70,6 +74,7 @@ hipError_t launch_batch(const BatchArgs& b0, uint32_t max_blocks, int waves, hip
     if (b0.n_arrays == 0 || max_blocks == 0) return hipSuccess;
     BatchArgs b = b0;
     b.tiles_per_array = (max_blocks + (WG / 64) - 1) / (WG / 64);
+    b.max_blocks = max_blocks;
     const uint64_t n_tiles = b.n_arrays * b.tiles_per_array;
     b.tiles_per_xcd = (n_tiles + 7) / 8;
     if (b.tiles_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;

@@ -488,6 +488,7 @@ int run_batch(bool pack, const void* const* packed, void* const* unpacked, const
     b.n_arrays = n_arrays;
     b.tiles_per_xcd = 0;
     b.tiles_per_array = 0;
+    b.max_blocks = max_blocks;
     hipError_t e = batch_launcher<T>(pack)(b, max_blocks, mixed_waves(Elem<T>::BITS, pack), static_cast<hipStream_t>(stream));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }

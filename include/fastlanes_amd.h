@@ -224,7 +224,8 @@ const uint8_t *fl_mixed_plan_widths(const fl_mixed_plan *plan);
      * when every chunk is its own call.  Four DEVICE arrays of length n_arrays: packed[a] / out[a] are device pointers      \
      * (16-byte aligned) to array a's packed and unpacked blocks, widths[a] its width, n_blocks[a] its block count;          \
      * max_blocks (host) >= every n_blocks[a] sizes the grid.  An array with a width > T or a misaligned / NULL pointer is    \
-     * skipped and FL_DEVERR_WIDTH / FL_DEVERR_ALIGN is ORed into *err_flag. */                                               \
+     * skipped and FL_DEVERR_WIDTH / FL_DEVERR_ALIGN is ORed into *err_flag; an array with n_blocks[a] > max_blocks has only  \
+     * its first max_blocks (rounded up to 4) blocks processed and raises FL_DEVERR_BOUNDS. */                                \
     int fl_##S##_unpack_batch(const T *const *packed, T *const *out, const uint8_t *widths,       \
                               const uint32_t *n_blocks, size_t n_arrays, uint32_t max_blocks,     \
                               uint32_t *err_flag, void *stream);                                  \

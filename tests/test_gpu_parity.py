@@ -537,6 +537,12 @@ def test_batch_of_small_arrays_vs_oracle(fl, oracle, ty):
     assert ei.value.status == 1
     with pytest.raises(ValueError):
         fl.Batch(packed[:1], [outs[0][:1024 * (counts[0] - 1)]], widths[:1])
+    # a bound smaller than an array's block count would leave its tail undecoded: the kernel flags it
+    b3 = fl.Batch(packed[:1], [outs[0][:counts[0] * 1024]], widths[:1])
+    b3.max_blocks = counts[0] - 8
+    with pytest.raises(fl.FastLanesError) as ei:
+        b3.unpack(check=True)
+    assert ei.value.status == 6
 
 
 def test_mixed_width_fuzz_shapes_and_occupancies(fl, oracle, kernel_policy):
