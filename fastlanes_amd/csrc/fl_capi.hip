@@ -271,6 +271,8 @@ int dev_unpack_single_widths(const uint8_t* widths, const uint64_t* offsets, con
                              const uint64_t* idx, size_t n_idx, T* out, uint32_t* err_flag, void* s)
 {
     if (n_idx == 0) return FL_OK;
+    static const T no_bytes[16 / sizeof(T)] __attribute__((aligned(16))) = {0};
+    if (!packed && packed_bytes == 0) packed = no_bytes;      // a column of width-0 blocks has no packed bytes (every lookup is 0)
     if (!widths || !offsets || !idx || !out || !packed) return FL_ERR_NULL;
     SingleArgs a{packed, idx, out, err_flag, n_blocks, n_idx, 0, widths, offsets, packed_bytes};
     hipError_t e = unpack_single_launch<T>(a, static_cast<hipStream_t>(s));
@@ -447,6 +449,10 @@ int run_widths(bool pack, const uint8_t* widths, const uint64_t* offsets, const 
                size_t n_blocks, uint32_t* err_flag, void* stream)
 {
     if (n_blocks == 0) return FL_OK;
+    // a column whose blocks all have width 0 has no packed bytes at all: its packed pointer may be NULL (any block with a
+    // width > 0 then fails the kernel's bounds check against packed_bytes == 0)
+    static const char no_bytes[16] __attribute__((aligned(16))) = {0};
+    if (!packed && packed_bytes == 0) packed = no_bytes;
     if (!widths || !offsets || !packed || !unpacked) return FL_ERR_NULL;
     if (misaligned(packed) || misaligned(unpacked)) return FL_ERR_ALIGN;
     WidthsArgs a;
@@ -500,9 +506,8 @@ int run_mixed(bool pack, const fl_mixed_plan* p, const void* packed, void* unpac
     if (p->type_bits != (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
     if (p->n_blocks == 0) return FL_OK;
     if (!unpacked || (p->packed_bytes && !packed)) return FL_ERR_NULL;
-    // widths were validated at plan creation; an all-zero-width column has no packed bytes at all
-    static const char dummy[16] __attribute__((aligned(16))) = {0};
-    return run_widths<T>(pack, p->d_widths, p->d_offsets, p->packed_bytes ? packed : dummy, p->packed_bytes, unpacked, p->n_blocks, nullptr, stream);
+    // widths were validated at plan creation; an all-zero-width column has no packed bytes at all (run_widths accepts NULL then)
+    return run_widths<T>(pack, p->d_widths, p->d_offsets, p->packed_bytes ? packed : nullptr, p->packed_bytes, unpacked, p->n_blocks, nullptr, stream);
 }
 
 }  // namespace

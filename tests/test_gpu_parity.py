@@ -485,6 +485,15 @@ def test_unpack_pack_widths_device_resident(fl, oracle, ty):
         fl.unpack_single_widths(dw, doff, to_dev(col), torch.tensor([1.0], dtype=torch.float64).cuda())
     with pytest.raises(TypeError):
         fl.unpack_single_widths(dw, doff, to_dev(col), torch.tensor([1], dtype=torch.int64))
+    # a column of width-0 blocks only has no packed bytes at all (a NULL packed pointer): zeros out, nothing packed
+    z = torch.zeros(3, dtype=torch.uint8, device="cuda:0")
+    zoff, ztot = fl.widths_to_offsets(ty, z)
+    assert int(ztot.item()) == 0
+    zo = fl.unpack_widths(z, zoff, torch.empty(0, dtype=tdt, device="cuda:0"))
+    assert zo.numel() == 3 * 1024 and not to_np(zo, ty).any()
+    fl.pack_widths(z, zoff, to_dev(values(ty, 3 * 1024, 1)), torch.empty(0, dtype=tdt, device="cuda:0"))
+    assert not to_np(fl.unpack_single_widths(z, zoff, torch.empty(0, dtype=tdt, device="cuda:0"),
+                                             torch.tensor([0, 1500, 3071], dtype=torch.int64).cuda()), ty).any()
     # empty column
     e8 = torch.empty(0, dtype=torch.uint8, device="cuda:0")
     o0, t0 = fl.widths_to_offsets(ty, e8)
