@@ -238,6 +238,48 @@ __device__ __forceinline__ uint32_t row_predicate_bits(const Cell<T>& v, T k)
     }
 }
 
+// The same verdict bits for one logical row straight from the PACKED words where that is cheaper: for u8 / u16, a field that
+// lies inside one packed word below its top bit ((row*W) % T + W <= T - 1) is compared IN PLACE -- masked where it sits
+// (one v_and instead of shift + and) against the constant shifted to the same position, the element's top bit serving as
+// the SWAR guard (2 operations instead of 3).  k is clamped to the field's range first (x <= k is true for every W-bit x once
+// k >= 2^W - 1; x == k is false for k >= 2^W), so the shifted constant always fits.  ~20 instead of ~32 VALU operations per
+// row of a u16 column at the narrow widths, which are VALU-bound (profiles/r03_pmc_sq_derived.txt).
+template <typename T, int W, int ROW, bool IS_EQ>
+__device__ __forceinline__ uint32_t row_predicate_bits_of_row(const Cell<T>* in, T k)
+{
+    constexpr int TB = Elem<T>::BITS;
+    constexpr int sh = W ? (ROW * W) % TB : 0;
+    if constexpr (sizeof(T) <= 2 && W >= 1 && W < TB && sh + W <= TB - 1) {
+        constexpr int word = (ROW * W) / TB;
+        constexpr uint32_t H = sizeof(T) == 2 ? 0x80008000u : 0x80808080u;
+        constexpr uint32_t L = ~H;
+        constexpr T FM = (T)((1u << W) - 1u);
+        constexpr uint32_t M = Cell<T>::rep(W) << sh;                     // the field where it sits, in every element
+        const bool beyond = k > FM;                                       // wave-uniform
+        const uint32_t ks = Cell<T>::splat((T)((beyond ? FM : k) << sh)).x[0];
+        uint32_t p[4];
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t x = in[word].x[i] & M;
+            if constexpr (IS_EQ) {
+                const uint32_t y = x ^ ks;                                // bits of the field only (top bit clear)
+                p[i] = beyond ? 0u : (~((y + L) | y) & H);                // field == 0
+            } else {
+                p[i] = ((ks | H) - x) & H;                                // no borrow across elements: x, ks < 2^(T-1)
+            }
+        }
+        if constexpr (sizeof(T) == 2) {
+            const uint32_t q = (p[0] >> 15) | (p[1] >> 13) | (p[2] >> 11) | (p[3] >> 9);
+            return (q & 0x55u) | ((q >> 15) & 0xAAu);
+        } else {
+            uint32_t bits = 0;
+            for (int i = 0; i < 4; ++i) bits |= (((p[i] >> 7) * 0x01020408u) >> 24) << (4 * i);
+            return bits;
+        }
+    } else {
+        return row_predicate_bits<T, W, IS_EQ>(unpack_row<T, W, ROW>(in), k);
+    }
+}
+
 // u64: the 8 column threads OR their 2-bit pieces together with three DPP steps per 32-bit mask word.
 template <typename T, int W, bool IS_EQ>
 __device__ __forceinline__ void compare_block_dpp(const Cell<T>* in, T k, unsigned c, uint32_t (&keep)[4])
@@ -277,7 +319,7 @@ __device__ __forceinline__ void compare_block_lds(const Cell<T>* in, T k, unsign
     static_for<TB>([&](auto J) {
         constexpr int j = decltype(J)::value;
         constexpr int row = fl_order((j % PER_S) * (8 / PER_S)) * 8 + j / PER_S;
-        const uint32_t bits = row_predicate_bits<T, W, IS_EQ>(unpack_row<T, W, row>(in), k);
+        const uint32_t bits = row_predicate_bits_of_row<T, W, row, IS_EQ>(in, k);
         if constexpr (sizeof(T) == 1) {
             *reinterpret_cast<uint16_t*>(lds_blk + j * 16 + c * 2) = (uint16_t)bits;
         } else if constexpr (sizeof(T) == 2) {

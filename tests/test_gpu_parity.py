@@ -1014,12 +1014,15 @@ def test_unpack_compare_vs_oracle(fl, oracle, ty):
     T = tbits(ty)
     n = 41
     ops = {"==": operator.eq, "!=": operator.ne, "<": operator.lt, "<=": operator.le, ">": operator.gt, ">=": operator.ge}
-    for w in sorted({0, 1, 3, T // 2, T - 1, T}):
+    # every width of the SWAR types (their kernels compare most fields in place, per-(W, row) code), a spread of the others
+    widths = range(T + 1) if T <= 16 else sorted({0, 1, 3, 7, T // 2, T // 2 + 5, T - 1, T})
+    for w in widths:
         pk = values(ty, n * packed_len(ty, w), 15000 + 64 * T + w)
         un = oracle.batch("unpack", ty, w, pk, n_blocks=n)
         dpk = to_dev(pk)
         maxv = (1 << w) - 1 if w else 0
-        consts = sorted({0, 1, maxv // 2, maxv, int(un[5]), (1 << T) - 1})
+        # incl. constants beyond the field's range (k > 2^W - 1: every x <= k, no x == k) and with the element's top bit set
+        consts = sorted({0, 1, maxv // 2, maxv, min(maxv + 1, (1 << T) - 1), 1 << (T - 1), int(un[5]), (1 << T) - 1})
         for k in consts:
             for name, f in ops.items():
                 got = fl.BitPacking.unpack_compare(w, dpk, name, k, n_blocks=n).cpu().numpy().view(np.uint8)
