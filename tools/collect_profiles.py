@@ -24,7 +24,8 @@ def cp(src, dst):
 cp(os.path.join(G, "bench_u32w7.json"), f"{RD}_bench_u32w7.json")
 cp(os.path.join(G, "bench_other.jsonl"), f"{RD}_bench_other_workloads.jsonl")
 cp(os.path.join(G, "host_latency.txt"), f"{RD}_host_latency.txt")
-for src, dst in (("bench_2ranks_gloo.json", f"{RD}_bench_2ranks_one_device_gloo.json"),
+for src, dst in (("bench_8ranks_one_device.json", f"{RD}_bench_8ranks_one_device_gloo.json"),
+                 ("bench_2ranks_gloo.json", f"{RD}_bench_2ranks_one_device_gloo.json"),
                  ("bench_2ranks_auto.json", f"{RD}_bench_2ranks_one_device_rccl_attempt.json")):
     if os.path.exists(os.path.join(G, src)):
         with open(os.path.join(G, src)) as f, open(os.path.join(P, dst), "w") as o:

@@ -22,6 +22,8 @@ timeout 120 tools/host_latency > $R/host_latency.txt 2>&1
 # GPU: the fallback path on real hardware)
 timeout 600 python bench.py --gpus 2 --single-device --backend gloo --blocks 2000000 --steps 5 > $R/bench_2ranks_gloo.json 2> $R/bench_2ranks_gloo.err; echo "2 ranks gloo rc=$?"
 timeout 900 python bench.py --gpus 2 --single-device --backend auto --nccl-probe-timeout 60 --blocks 2000000 --steps 5 > $R/bench_2ranks_auto.json 2> $R/bench_2ranks_auto.err; echo "2 ranks auto rc=$?"
+# the driver's 8-rank shape on this one device: 8 processes, the 10 B-integer column split 1 220 704 + 7 x 1 220 703
+timeout 900 python bench.py --gpus 8 --single-device --backend gloo --blocks 1000000 --steps 3 --warmup 1 > $R/bench_8ranks_one_device.json 2> $R/bench_8ranks_one_device.err; echo "8 ranks gloo rc=$?"
 timeout 600 ./examples/multi_gpu_decode --steps 10 > $R/multi_gpu_decode.json 2> $R/multi_gpu_decode.err; echo "c driver rc=$?"
 timeout 600 ./examples/multi_gpu_decode --steps 5 --replicas 2 --blocks 4000000 > $R/multi_gpu_decode_2threads.json 2>> $R/multi_gpu_decode.err; echo "c driver x2 rc=$?"
 cat $R/bench_u32w7.json
