@@ -54,6 +54,7 @@ __global__ __launch_bounds__(WG) void k_batch(BatchArgs b)
     a.bpw = 1;
     a.packed_bytes = 0;
     a.prefetch = 0;
+    a.linear_map = 0;
     // per-array preconditions the host cannot check (the pointers live in HBM): 16-byte alignment; the width check
     // (bitpacking.rs:93,126) is the block kernel's
     if (((reinterpret_cast<uintptr_t>(a.packed) | reinterpret_cast<uintptr_t>(a.unpacked)) & 15u) != 0 ||

@@ -114,6 +114,7 @@ int run_wave_uniform(bool pack, int waves, unsigned w, const T* packed, T* unpac
     a.bpw = uniform_blocks_per_wave(Elem<T>::BITS, pack);
     a.packed_bytes = 0;      // not read: uniform-width calls are validated here, on the host side
     a.prefetch = a.bpw > 1;
+    a.linear_map = 0;
     hipError_t e = widths_launcher<T>(pack)(a, waves, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
@@ -469,6 +470,7 @@ int run_widths(bool pack, const uint8_t* widths, const uint64_t* offsets, const 
     a.packed_bytes = packed_bytes;
     a.bpw = mixed_blocks_per_wave(Elem<T>::BITS, pack);
     a.prefetch = mixed_prefetch(Elem<T>::BITS);
+    a.linear_map = 0;
     int waves = mixed_waves(Elem<T>::BITS, pack);
     const int pol = g_kernel_policy.load(std::memory_order_relaxed);       // A/B tools: 2 + 256*waves + 65536*blocks-per-wavefront (+ 2^24: prefetch)
     if ((pol & 0xff) == 2 && ((pol >> 8) & 0xff)) waves = (pol >> 8) & 0xff;

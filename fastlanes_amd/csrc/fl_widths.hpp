@@ -40,6 +40,7 @@ struct WidthsArgs {
     unsigned bpw;              // consecutive blocks per wavefront (>= 1); a workgroup takes 4*bpw blocks
     uint64_t packed_bytes;     // size of the packed column: a block must lie inside [0, packed_bytes) (only read when widths != nullptr)
     unsigned prefetch;         // bpw > 1: 1 = request all bpw blocks of the wavefront up front by LDS-DMA (one LDS image per block)
+    unsigned linear_map;       // A/B tools: 1 = workgroup b takes tile b instead of the XCD-contiguous map
 };
 
 template <typename T> struct WaveBlock {
@@ -360,7 +361,9 @@ __device__ __forceinline__ void for_each_block_of_wave(const WidthsArgs& a, F&& 
     extern __shared__ __attribute__((aligned(16))) char lds_all[];
     const unsigned tile_blocks = a.bpw * (WG / 64);
     const uint64_t n_tiles = (a.n_blocks + tile_blocks - 1) / tile_blocks;
-    const uint64_t tile = (uint64_t)(blockIdx.x & 7u) * a.tiles_per_xcd + (blockIdx.x >> 3);
+    // XCD-contiguous map (workgroup ids go round-robin over the 8 XCDs: XCD x owns one contiguous eighth of the column);
+    // linear_map (A/B tools only) = workgroup b takes tile b
+    const uint64_t tile = a.linear_map ? (uint64_t)blockIdx.x : (uint64_t)(blockIdx.x & 7u) * a.tiles_per_xcd + (blockIdx.x >> 3);
     if (tile >= n_tiles) return;
     const unsigned tid = threadIdx.x;
     const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;

@@ -97,6 +97,11 @@ template <typename T, bool PACK> void add_widths(std::vector<Variant>& vs, Width
         vs.push_back({nm(RD_DMA), [=](char* o) { go_widths<T, PACK, RD_DMA>(a, o, wv); }, {}});
         vs.push_back({nm(RD_DMA_NT), [=](char* o) { go_widths<T, PACK, RD_DMA_NT>(a, o, wv); }, {}});
         if (!PACK) vs.push_back({nm(RD_AUTO), [=](char* o) { go_widths<T, PACK, RD_AUTO>(a, o, wv); }, {}});
+        {   // the shipped read path with workgroup b -> tile b instead of the XCD-contiguous map
+            WidthsArgs lin = a;
+            lin.linear_map = 1;
+            vs.push_back({"shipped, LINEAR tile map, " + std::to_string(wv) + " w", [=](char* o) { go_widths<T, PACK, (PACK ? RD_VGPR : RD_AUTO)>(lin, o, wv); }, {}});
+        }
     }
 }
 
