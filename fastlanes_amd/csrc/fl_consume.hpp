@@ -8,6 +8,7 @@
 //                          (bits(max - min)) before calling for_pack::<W> (ffor.rs:24-36).
 #pragma once
 #include "fl_kernels.hpp"
+#include "fl_widths.hpp"
 
 namespace fl {
 
@@ -382,6 +383,98 @@ constexpr CompareTable<T> make_compare_table(std::integer_sequence<int, Ws...>)
 }
 // the two primitives live in separate translation units (families 11 / 12) to build in parallel
 template <typename T, bool IS_EQ> const CompareTable<T>& compare_table_impl();
+
+// ---------------------------------------------------------------------------
+// unpack_compare on the wave-per-block mapping (u32 / u64, runtime width): the packed block arrives in the wave's LDS image by
+// non-temporal LDS-DMA (1 KiB-contiguous reads, fl_widths.hpp), lane (i, c) funnel-shifts the cell of address-row 8k+i,
+// column c of every 1-KiB group k -- N = 16/sizeof(T) elements with CONSECUTIVE element indices k*1024/sizeof(T) + lane*N --
+// so its N verdicts are N consecutive mask bits; the 8 lanes of a lane group (u64: 16 lanes) OR them into one 32-bit mask
+// word with DPP steps, and 32 lanes store the block's 32 words.  More VALU per value than the cell-column kernel (the
+// shift is a register, not a constant), but the wide widths are nowhere near VALU-bound there (0.26-0.38 of the issue
+// rate) and read 1 KiB contiguous here instead of 8 x 128 B.
+// ---------------------------------------------------------------------------
+template <typename T, bool IS_EQ>
+__global__ __launch_bounds__(WG) void k_compare_wave(CompareArgs a, unsigned w)
+{
+    static_assert(sizeof(T) >= 4, "SWAR types stay on the cell-column kernel");
+    using G = WaveBlock<T>;
+    constexpr int TB = G::TB;
+    constexpr int N = 16 / (int)sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) char lds_all[];
+    const uint64_t n_tiles = (a.n_blocks + (WG / 64) - 1) / (WG / 64);
+    const uint64_t tile = (uint64_t)(blockIdx.x & 7u) * a.tiles_per_xcd + (blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
+    const unsigned tid = threadIdx.x;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
+    const uint64_t blk = tile * (WG / 64) + wave;
+    if (blk >= a.n_blocks) return;
+    char* lds = lds_all + wave * G::BLOCK_BYTES;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(a.in)) + blk * (uint64_t)(128u * w), 0, 128u * w, 0x00020000);
+    static_for<G::GROUPS>([&](auto Gi) {
+        constexpr int g = decltype(Gi)::value;
+        if (8u * g < w) dma_1k_to_lds<RD_DMA_NT, g * 1024>(rs, lds, lane);
+    });
+    wait_lds_dma();
+    wave_lds_fence();
+    const T k = (T)a.constant;
+    const unsigned i = lane >> 3, c = lane & 7u, c16 = c * 16u;
+    const typename G::word_t m = G::field_mask(w);
+    unsigned bit = G::row_base(i) * w;
+    const unsigned step = G::KSTEP * w;
+    const unsigned last = (w - 1u) * 128u;
+    uint32_t mine = 0;
+    static_for<G::GROUPS>([&](auto K) {
+        constexpr unsigned kk = decltype(K)::value;
+        const unsigned word = bit >> G::LOG_TB, sh = bit & (TB - 1u);
+        const unsigned a0 = word * 128u;
+        const unsigned a1 = a0 + 128u < last ? a0 + 128u : last;            // macros.rs:156
+        const Cell<T> cur = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(lds + a0 + c16));
+        const Cell<T> nxt = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(lds + a1 + c16));
+        const Cell<T> v = G::funnel(cur, nxt, sh, m);
+        uint32_t bits = 0;
+        static_for<N>([&](auto E) {
+            const T x = (T)cell_get<T>(v, decltype(E)::value);
+            const uint32_t p = IS_EQ ? (x == k) : (x <= k);
+            bits |= p << decltype(E)::value;
+        });
+        // this cell's N elements are mask bits [kk*(1024/sizeof(T))... ] = element index kk*64*N + lane*N
+        if constexpr (sizeof(T) == 4) {
+            uint32_t wd = or_allreduce8(bits << (4u * c));                  // 8 lanes x 4 bits = mask word kk*8 + i
+            if (c == kk) mine = wd;                                          // GROUPS = 4: lanes c < 4 keep a word each
+        } else {
+            uint32_t wd = or_allreduce8(bits << (2u * c + 16u * (i & 1u)));  // 8 lanes x 2 bits in the lane group's half ...
+            wd |= (uint32_t)__shfl_xor((int)wd, 8, 64);                      // ... + the neighbouring group = mask word kk*4 + i/2
+            if (c == kk) mine = wd;                                          // GROUPS = 8: lanes (i even, c) keep a word each
+        }
+        bit += step;
+    });
+    const uint32_t flip = a.invert ? ~0u : 0u;
+    uint32_t* out = reinterpret_cast<uint32_t*>(a.mask) + blk * 32u;
+    if constexpr (sizeof(T) == 4) {
+        if (c < 4u) out[c * 8u + i] = mine ^ flip;
+    } else {
+        if ((i & 1u) == 0u) out[c * 4u + (i >> 1)] = mine ^ flip;
+    }
+}
+
+typedef hipError_t (*compare_wave_launch_t)(const CompareArgs&, unsigned w, int waves, hipStream_t);
+template <typename T, bool IS_EQ> hipError_t launch_compare_wave(const CompareArgs& a0, unsigned w, int waves, hipStream_t s)
+{
+    if (a0.n_blocks == 0) return hipSuccess;
+    if constexpr (sizeof(T) >= 4) {
+        CompareArgs a = a0;
+        const uint64_t n_tiles = (a.n_blocks + (WG / 64) - 1) / (WG / 64);
+        a.tiles_per_xcd = (n_tiles + 7) / 8;
+        if (a.tiles_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((k_compare_wave<T, IS_EQ>), dim3((unsigned)(a.tiles_per_xcd * 8)), dim3(WG), widths_lds_bytes<T>(waves), s, a, w);
+        return hipGetLastError();
+    } else {
+        return hipErrorInvalidValue;
+    }
+}
+// nullptr for the SWAR types (u8 / u16)
+template <typename T, bool IS_EQ> compare_wave_launch_t compare_wave_launcher();
 
 typedef hipError_t (*reduce_launch_t)(const ReduceArgs&, hipStream_t);
 

@@ -8,8 +8,9 @@
 // consecutive blocks).  The width is wave-uniform (an SGPR), so the width
 // dispatch of bitpacking.rs:115-128 is plain scalar arithmetic -- one kernel per element type, no
 // per-width code:
-//   * the packed block (128*W bytes, W rows of 8 cells) is fetched with 1-KiB-contiguous 16-byte
-//     loads (cell g*64+lane) and parked in a wave-private LDS image;
+//   * the packed block (128*W bytes, W rows of 8 cells) is fetched 1 KiB at a time (cell g*64+lane) into a
+//     wave-private LDS image -- through VGPRs, or non-temporally by LDS-DMA where that pays (ReadPath / RD_AUTO below);
+//     narrow element types keep several blocks in flight per wavefront (*_blocks_wave_prefetched);
 //   * lane (i = lane/8, c = lane%8) then produces, for each 1-KiB group k of the unpacked block,
 //     the cell of address-row 8k+i, column c: logical row r = row_at(8k+i) starts at bit r*W of every
 //     FL lane's stream, so the lane reads packed cells (r*W/T, c) and (r*W/T + 1, c) from LDS and
@@ -20,7 +21,8 @@
 //
 // The same two kernels serve UNIFORM-width columns (widths == nullptr: every block has `uniform_width`, offsets are
 // b*128*W) and the FoR bodies (refs != nullptr): for most (T, W) of the 16/32/64-bit types they out-run the
-// per-(T,W) cell-column kernels of fl_kernels.hpp (profiles/abuniform_r02*.txt); fl_dispatch.hpp holds the choice.
+// per-(T,W) cell-column kernels of fl_kernels.hpp; the generated fl_dispatch_table.inc holds the choice (fl_dispatch.hpp).
+// Per-block preconditions of the mixed-width form are checked here, on the device (block_precondition).
 #pragma once
 #include "fl_kernels.hpp"
 
