@@ -1006,6 +1006,27 @@ def test_random_shapes_fuzz(fl, oracle, kernel_policy, policy):
         assert np.array_equal(to_np(got, ty), want), (ty, w, op, n, seed)
 
 
+@pytest.mark.parametrize("policy", [0, 1, 2])
+def test_unpack_compare_both_designs(fl, oracle, kernel_policy, policy):
+    """unpack_compare has two designs for u32 / u64 as well: the cell-column kernels and the wave-per-block form
+    (k_compare_wave).  Every width and all six predicates under the automatic choice and with each design forced."""
+    import operator
+    kernel_policy(policy)
+    ops = {"==": operator.eq, "!=": operator.ne, "<": operator.lt, "<=": operator.le, ">": operator.gt, ">=": operator.ge}
+    for ty in ("u32", "u64"):
+        T = tbits(ty)
+        n = 13
+        for w in range(T + 1):
+            pk = values(ty, n * packed_len(ty, w), 16000 + 64 * T + w)
+            un = oracle.batch("unpack", ty, w, pk, n_blocks=n)
+            dpk = to_dev(pk)
+            maxv = (1 << w) - 1 if w else 0
+            for k in sorted({0, maxv // 3, maxv, int(un[7]), (1 << T) - 1}):
+                for name, f in ops.items():
+                    got = fl.BitPacking.unpack_compare(w, dpk, name, k, n_blocks=n).cpu().numpy().view(np.uint8)
+                    assert np.array_equal(got, np.packbits(f(un, TYPES[ty][0](k)), bitorder="little")), (ty, w, name, k, policy)
+
+
 @pytest.mark.parametrize("ty", TYS)
 def test_unpack_compare_vs_oracle(fl, oracle, ty):
     """unpack_compare (extension): mask = numpy compare of the oracle's unpack
