@@ -376,15 +376,21 @@ class Control:
                 port[0] = sk.getsockname()[1]
         dist.broadcast(port, 0)
         try:
-            env = dict(os.environ, MASTER_PORT=str(int(port.item())))
+            # its own rendezvous: a fresh port, and none of torchrun's TORCHELASTIC_* variables (with
+            # TORCHELASTIC_USE_AGENT_STORE every rank would look for the agent's store on that port instead of rank 0 hosting one)
+            env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+            env["MASTER_PORT"] = str(int(port.item()))
             env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             cmd = [sys.executable, os.path.abspath(__file__), "--nccl-probe-child", "--gpus", str(world),
                    "--nccl-probe-timeout", str(args.nccl_probe_timeout)] + (["--single-device"] if args.single_device else [])
             r = subprocess.run(cmd, env=env, timeout=args.nccl_probe_timeout + 60, capture_output=True, text=True)
             if r.returncode != 0:
-                lines = [l.strip() for l in (r.stderr or "").splitlines() if l.strip()]
-                telling = [l for l in lines if "Error" in l or "error" in l] or lines[-1:] or ["no stderr"]
-                err = f"RCCL probe exited {r.returncode}: {telling[-1][:240]}"
+                lines = [l.strip() for l in (r.stderr or "").splitlines() if l.strip() and "destroy_process_group" not in l]
+                # the exception line, plus what RCCL printed after "Last error:" (e.g. "Duplicate GPU detected ...")
+                exc = [l for l in lines if "Error" in l and not l.startswith(("File ", "Traceback"))]
+                last = [lines[i + 1] for i, l in enumerate(lines[:-1]) if l.startswith("Last error")]
+                telling = " / ".join((exc[-1:] + last[-1:])) or (lines[-1] if lines else "no stderr")
+                err = f"RCCL probe exited {r.returncode}: {telling[:300]}"
         except subprocess.TimeoutExpired:
             err = f"RCCL probe timed out after {args.nccl_probe_timeout + 60:.0f} s"
         except Exception as e:       # the probe must never take the bench down
