@@ -47,6 +47,8 @@ def _signatures(ty):
         "unpack_single_widths": [_P, _P, _P, _Z, _Z, _P, _Z, _P, _P, _P],
         "unpack_batch": [_P, _P, _P, _P, _Z, ctypes.c_uint32, _P, _P],
         "pack_batch": [_P, _P, _P, _P, _Z, ctypes.c_uint32, _P, _P],
+        "unfor_pack_batch": [_P, _P, _P, _P, _P, _Z, ctypes.c_uint32, _P, _P],
+        "for_pack_batch": [_P, _P, _P, _P, _P, _Z, ctypes.c_uint32, _P, _P],
     }
     host = {
         "pack_host": [_U, _P, _P, _Z],

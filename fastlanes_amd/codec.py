@@ -561,7 +561,9 @@ class Batch:
     element type on one device (array a: n_blocks[a] blocks of width widths[a]); the constructor uploads the four per-array
     device arrays (pointers, widths, block counts) once, unpack() / pack() are then one asynchronous launch each."""
 
-    def __init__(self, packed, unpacked, widths):
+    def __init__(self, packed, unpacked, widths, references=None):
+        """`references` (optional): one FoR reference per array -- unpack() / pack() then run unfor_pack::<W> / for_pack::<W>
+        (ffor.rs:24-50) on every block of array a with references[a]."""
         import torch
         if not (len(packed) == len(unpacked) == len(widths)):
             raise ValueError("packed, unpacked and widths must have one entry per array")
@@ -593,17 +595,27 @@ class Batch:
         self.d_widths = up(w, np.uint8)
         self.d_n_blocks = up(nb, np.int32)
         self.max_blocks = max(nb)
+        self.d_refs = None
+        if references is not None:
+            r = [int(x) & ((1 << T) - 1) for x in references]          # python ints: a u64 reference may exceed int64
+            if len(r) != self.n:
+                raise ValueError("references must hold one entry per array")
+            self.d_refs = up(np.array(r, dtype=np.uint64).astype(_NP_DTYPE[self.ty]).view(np.uint8), np.uint8)
         self.unpacked = list(unpacked)
         self.packed = list(packed)
 
     def _run(self, method, first, second, check):
         import torch
         err = torch.zeros(1, dtype=torch.int32, device=self.device) if check else None
+        if self.d_refs is not None:
+            method = {"unpack_batch": "unfor_pack_batch", "pack_batch": "for_pack_batch"}[method]
         with torch.cuda.device(self.device):
             st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-            _check(getattr(_lib.load(), f"fl_{self.ty}_{method}")(first.data_ptr(), second.data_ptr(), self.d_widths.data_ptr(),
-                                                                 self.d_n_blocks.data_ptr(), self.n, self.max_blocks,
-                                                                 err.data_ptr() if check else None, st), f"fl_{self.ty}_{method}")
+            args = [first.data_ptr(), second.data_ptr(), self.d_widths.data_ptr()]
+            if self.d_refs is not None:
+                args.append(self.d_refs.data_ptr())
+            args += [self.d_n_blocks.data_ptr(), self.n, self.max_blocks, err.data_ptr() if check else None, st]
+            _check(getattr(_lib.load(), f"fl_{self.ty}_{method}")(*args), f"fl_{self.ty}_{method}")
         if check:
             _check_flag(err, f"fl_{self.ty}_{method}")
 

@@ -18,6 +18,7 @@ struct BatchArgs {
     const uint8_t* widths;       // [n_arrays]
     const uint32_t* n_blocks;    // [n_arrays]
     uint32_t* err_flag;          // FL_DEVERR_* bits; may be nullptr
+    const void* refs;            // FoR: references[a], one per ARRAY (ffor.rs:24-50); nullptr = plain BitPacking
     uint64_t n_arrays;
     uint64_t tiles_per_xcd;
     unsigned tiles_per_array;    // ceil(max_blocks / 4)
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(WG) void k_batch(BatchArgs b)
     a.widths = nullptr;
     a.offsets = nullptr;
     a.err_flag = b.err_flag;
-    a.refs = nullptr;
+    a.refs = b.refs ? static_cast<const char*>(b.refs) + arr * sizeof(T) : nullptr;   // every block of the array shares it
     a.ref_stride = 0;
     a.n_blocks = nb;
     a.tiles_per_xcd = 0;

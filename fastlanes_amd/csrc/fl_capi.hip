@@ -495,17 +495,18 @@ int run_widths(bool pack, const uint8_t* widths, const uint64_t* offsets, const 
 
 // many small arrays, device arrays of pointers (fl_batch.hpp)
 template <typename T>
-int run_batch(bool pack, const void* const* packed, void* const* unpacked, const uint8_t* widths, const uint32_t* n_blocks,
-              size_t n_arrays, uint32_t max_blocks, uint32_t* err_flag, void* stream)
+int run_batch(bool pack, const void* const* packed, void* const* unpacked, const uint8_t* widths, const void* refs, bool with_refs,
+              const uint32_t* n_blocks, size_t n_arrays, uint32_t max_blocks, uint32_t* err_flag, void* stream)
 {
     if (n_arrays == 0 || max_blocks == 0) return FL_OK;
-    if (!packed || !unpacked || !widths || !n_blocks) return FL_ERR_NULL;
+    if (!packed || !unpacked || !widths || !n_blocks || (with_refs && !refs)) return FL_ERR_NULL;
     BatchArgs b;
     b.packed = reinterpret_cast<const char* const*>(packed);
     b.unpacked = reinterpret_cast<char* const*>(unpacked);
     b.widths = widths;
     b.n_blocks = n_blocks;
     b.err_flag = err_flag;
+    b.refs = with_refs ? refs : nullptr;
     b.n_arrays = n_arrays;
     b.tiles_per_xcd = 0;
     b.tiles_per_array = 0;
@@ -666,10 +667,16 @@ size_t fl_packed_len(unsigned type_bits, unsigned width)
     { return run_widths<T>(true, w, o, pk, pb, const_cast<T*>(in), n, ef, s); }                           \
     int fl_##S##_unpack_batch(const T* const* pk, T* const* out, const uint8_t* w, const uint32_t* nb, size_t na, uint32_t mb, \
                               uint32_t* ef, void* s)                                                      \
-    { return run_batch<T>(false, reinterpret_cast<const void* const*>(pk), reinterpret_cast<void* const*>(out), w, nb, na, mb, ef, s); } \
+    { return run_batch<T>(false, reinterpret_cast<const void* const*>(pk), reinterpret_cast<void* const*>(out), w, nullptr, false, nb, na, mb, ef, s); } \
+    int fl_##S##_unfor_pack_batch(const T* const* pk, T* const* out, const uint8_t* w, const T* refs, const uint32_t* nb, size_t na, \
+                                  uint32_t mb, uint32_t* ef, void* s)                                     \
+    { return run_batch<T>(false, reinterpret_cast<const void* const*>(pk), reinterpret_cast<void* const*>(out), w, refs, true, nb, na, mb, ef, s); } \
+    int fl_##S##_for_pack_batch(const T* const* in, T* const* pk, const uint8_t* w, const T* refs, const uint32_t* nb, size_t na, \
+                                uint32_t mb, uint32_t* ef, void* s)                                       \
+    { return run_batch<T>(true, reinterpret_cast<const void* const*>(pk), (void* const*)in, w, refs, true, nb, na, mb, ef, s); } \
     int fl_##S##_pack_batch(const T* const* in, T* const* pk, const uint8_t* w, const uint32_t* nb, size_t na, uint32_t mb, \
                             uint32_t* ef, void* s)                                                        \
-    { return run_batch<T>(true, reinterpret_cast<const void* const*>(pk), (void* const*)in, w, nb, na, mb, ef, s); } \
+    { return run_batch<T>(true, reinterpret_cast<const void* const*>(pk), (void* const*)in, w, nullptr, false, nb, na, mb, ef, s); } \
     int fl_##S##_unpack_single_widths(const uint8_t* w, const uint64_t* o, const T* pk, size_t pb, size_t n, const uint64_t* idx, \
                                       size_t ni, T* out, uint32_t* ef, void* s)                           \
     { return dev_unpack_single_widths<T>(w, o, pk, pb, n, idx, ni, out, ef, s); }                         \

@@ -232,6 +232,14 @@ const uint8_t *fl_mixed_plan_widths(const fl_mixed_plan *plan);
     int fl_##S##_pack_batch(const T *const *in, T *const *packed, const uint8_t *widths,          \
                             const uint32_t *n_blocks, size_t n_arrays, uint32_t max_blocks,       \
                             uint32_t *err_flag, void *stream);                                    \
+    /* ... with FoR's bodies (ffor.rs:24-50): references[a] (a DEVICE array, one scalar per ARRAY -- a chunk's frame of       \
+     * reference) is added to / subtracted from every value of array a: unfor_pack::<W> / for_pack::<W> per block. */         \
+    int fl_##S##_unfor_pack_batch(const T *const *packed, T *const *out, const uint8_t *widths,   \
+                                  const T *references, const uint32_t *n_blocks, size_t n_arrays, \
+                                  uint32_t max_blocks, uint32_t *err_flag, void *stream);         \
+    int fl_##S##_for_pack_batch(const T *const *in, T *const *packed, const uint8_t *widths,      \
+                                const T *references, const uint32_t *n_blocks, size_t n_arrays,   \
+                                uint32_t max_blocks, uint32_t *err_flag, void *stream);           \
     /* the same over a mixed-width plan (see fl_mixed_plan) */                                     \
     int fl_##S##_unpack_mixed(const fl_mixed_plan *plan, const T *packed, T *out, void *stream); \
     int fl_##S##_pack_mixed(const fl_mixed_plan *plan, const T *in, T *packed, void *stream);    \

@@ -65,6 +65,8 @@ template <typename T> struct Abi;
         static constexpr auto unpack_single_widths = fl_##S##_unpack_single_widths;                  \
         static constexpr auto unpack_batch = fl_##S##_unpack_batch;                                  \
         static constexpr auto pack_batch = fl_##S##_pack_batch;                                      \
+        static constexpr auto unfor_pack_batch = fl_##S##_unfor_pack_batch;                          \
+        static constexpr auto for_pack_batch = fl_##S##_for_pack_batch;                              \
         static constexpr auto pack_host = fl_##S##_pack_host;                                        \
         static constexpr auto unpack_host = fl_##S##_unpack_host;                                    \
         static constexpr auto unpack_single_host = fl_##S##_unpack_single_host;                      \

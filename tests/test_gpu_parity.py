@@ -536,6 +536,21 @@ def test_batch_of_small_arrays_vs_oracle(fl, oracle, ty):
         want = oracle.batch("pack", ty, w, vals_np[a]) if k else np.zeros(0, dtype=TYPES[ty][0])
         assert np.array_equal(got[:k], want), (ty, a, n, w)
         assert (got[k:] == guard).all()
+    # ... and with FoR's bodies: one reference per array (a chunk's frame of reference), unfor_pack::<W> / for_pack::<W> per block
+    refs = [int(x) for x in values(ty, len(counts), 9100)]
+    fouts = [torch.full((n * 1024 + 64,), guard, dtype=tdt, device="cuda:0") for n in counts]
+    fl.Batch(packed, [o[:n * 1024] for o, n in zip(fouts, counts)], widths, references=refs).unpack(check=True)
+    fpouts = [torch.full((n * packed_len(ty, w) + 64,), guard, dtype=tdt, device="cuda:0") for n, w in zip(counts, widths)]
+    fl.Batch([p[:n * packed_len(ty, w)] for p, n, w in zip(fpouts, counts, widths)], vals, widths, references=refs).pack(check=True)
+    for a, (n, w) in enumerate(zip(counts, widths)):
+        if n == 0:
+            continue
+        r = np.full(n, refs[a], dtype=TYPES[ty][0])
+        assert np.array_equal(to_np(fouts[a], ty)[:n * 1024], oracle.batch("unfor_pack", ty, w, packed_np[a], aux=r, n_blocks=n)), (ty, a, "unfor")
+        k = n * packed_len(ty, w)
+        if k:
+            assert np.array_equal(to_np(fpouts[a], ty)[:k], oracle.batch("for_pack", ty, w, vals_np[a], aux=r)), (ty, a, "for")
+        assert (to_np(fouts[a], ty)[n * 1024:] == guard).all() and (to_np(fpouts[a], ty)[k:] == guard).all()
     # errors: a width > T is refused on the host side of the mirror, and flagged by the kernel when it arrives in HBM
     with pytest.raises(fl.FastLanesError):
         fl.Batch(packed[:1], [outs[0][:counts[0] * 1024]], [T + 1])
