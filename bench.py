@@ -79,6 +79,11 @@ def parse():
                     help="control plane for the barrier / max-time reduction: auto = RCCL if every rank gets it working, "
                          "else gloo; nccl = the same (the fallback still applies, the line reports it); gloo = never try RCCL")
     ap.add_argument("--no-check", action="store_true", help="skip the per-rank oracle check of the timed output")
+    ap.add_argument("--placement", default="zoned", choices=("zoned", "separate"),
+                    help="zoned (default): a workload's input and output are carved from one allocation, 64 GiB apart, so that they "
+                         "lie in different 64-GiB zones of the device memory (fastlanes_amd/placement.py; the same kernels on "
+                         "separately allocated buffers are timed next to it and reported as roofline.separate_allocations); "
+                         "separate: one allocation per buffer, wherever the driver puts it")
     ap.add_argument("--probe-nccl", action="store_true", help="with --dry-run: still attempt the RCCL probe (exercises the "
                     "fallback on a box without GPUs)")
     ap.add_argument("--inject-mismatch", type=int, default=-1, help="with --dry-run: pretend this rank's oracle check failed "
@@ -121,6 +126,12 @@ def spawn_ranks(args):
                 for q in live:            # a dead rank leaves the others in a barrier: stop exactly our children
                     q.terminate()
     return rc
+
+
+def ctypes_stream(dev):
+    import ctypes
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
 def rand_u8(nbytes, seed, dev):
@@ -229,9 +240,13 @@ def cpu_baseline(args, ty, width, op):
 class Workload:
     """One rank's share of a workload: device buffers + step()."""
 
-    def __init__(self, name, n, first_block, rank, dev):
+    def __init__(self, name, n, first_block, rank, dev, placement="zoned"):
+        """placement: "zoned" = input and output carved from ONE allocation, the output exactly 64 GiB after the input, so that
+        they lie in different 64-GiB zones of the device memory (fastlanes_amd/placement.py; falls back to "separate" when the
+        slab does not fit); "separate" = one torch allocation per buffer, wherever the driver puts them."""
         import torch
         import fastlanes_amd as fl
+        from fastlanes_amd import placement as pl
         self.name = name
         self.ty, self.width, self.op, _ = WORKLOADS[name]
         self.n = n
@@ -240,23 +255,43 @@ class Workload:
         esz = ESZ[ty]
         un_bytes = 1024 * esz
         self.bases = None
+        self.slab = None
+        lib = fl.load()
+
+        def buffers(in_bytes, out_bytes, aux_bytes=0):
+            """(input, aux, output) as uint8 tensors; the input (and aux) filled with counter-based random bytes on the device"""
+            if placement == "zoned" and pl.fits(in_bytes, out_bytes, dev, aux_bytes):
+                self.slab, src, aux, dst = pl.column_pair(in_bytes, out_bytes, dev, aux_bytes)
+                self.placement = "zoned"
+            else:
+                src = torch.empty(in_bytes, dtype=torch.uint8, device=dev)
+                aux = torch.empty(aux_bytes, dtype=torch.uint8, device=dev)
+                dst = torch.empty(out_bytes, dtype=torch.uint8, device=dev)
+                self.placement = "separate"
+            st = ctypes_stream(dev)
+            for t, seed in ((src, 1234 + rank), (aux, 99 + rank)):
+                nb = t.numel() & ~7
+                if nb and lib.fl_fill_random(t.data_ptr(), nb, seed, st) != 0:
+                    raise RuntimeError("fl_fill_random failed")
+            return src, aux, dst
+
         if op == "unpack_mixed":
             # widths and offsets are DEVICE arrays, built on the device: nothing about the column touches the host
             self.widths = (1 + (torch.arange(n, dtype=torch.int64, device=dev) + first_block) % 32).to(torch.uint8)
             self.offsets, total = fl.widths_to_offsets(ty, self.widths)
             packed_bytes = int(total.item())
-            self.src = rand_u8(packed_bytes, 1234 + rank, dev).view(tdt)
-            self.dst = torch.empty(n * 1024, dtype=tdt, device=dev)
+            src, _, dst = buffers(packed_bytes, n * un_bytes)
+            self.src, self.dst = src.view(tdt), dst.view(tdt)
             self.in_bytes, self.out_bytes = packed_bytes, n * un_bytes          # per launch
             self.step = lambda: fl.unpack_widths(self.widths, self.offsets, self.src, output=self.dst, check=False)
         else:
             pl_bytes = 128 * width
             ib, ob = (un_bytes, pl_bytes) if op == "pack" else (pl_bytes, un_bytes)
-            self.src = rand_u8(n * ib, 1234 + rank, dev).view(tdt)
-            self.dst = torch.empty(n * ob // esz, dtype=tdt, device=dev)
+            src, aux, dst = buffers(n * ib, n * ob, n * 128 if op == "undelta_pack" else 0)
+            self.src, self.dst = src.view(tdt), dst.view(tdt)
             self.in_bytes, self.out_bytes = n * ib, n * ob
             if op == "undelta_pack":
-                self.bases = rand_u8(n * 128, 99 + rank, dev).view(tdt)
+                self.bases = aux.view(tdt)
                 self.in_bytes += n * 128
                 self.step = lambda: fl.Delta.undelta_pack(width, self.src, self.bases, output=self.dst)
             elif op == "unpack":
@@ -535,7 +570,7 @@ def live_pmc_traffic(args, workload=None):
                     continue
                 v = float(r["Counter_Value"]) * 1024.0
                 name = r["Kernel_Name"]
-                if "fl::k_" in name and "k_scan" not in name:
+                if "fl::k_" in name and "k_scan" not in name and "k_fill" not in name:
                     ker.append(v)
                 elif v > 0.25 * PMC_CAL_BYTES and ("copy" in name.lower() or "elementwise" in name.lower()) \
                         and "distribution" not in name:
@@ -588,7 +623,38 @@ def run_check(w, args, ctl):
     return flags, n_checked
 
 
-def config5_leg(args, world, rank, dev, ctl, w=None):
+PLACEMENT_TEXT = {
+    "zoned": "input and output carved from ONE allocation, the output 64 GiB after the input: different 64-GiB zones of the device "
+             "memory (fastlanes_amd/placement.py, DESIGN.md section 4); roofline.separate_allocations = the same kernel on "
+             "separately allocated buffers in the same run",
+    "separate": "one torch allocation per buffer, wherever the driver puts it",
+}
+
+
+def separate_allocations_leg(name, n, first, rank, dev, args):
+    """The same workload on separately allocated buffers (the lottery the zoned placement removes), a few untimed-by-the-contract
+    launches next to the headline, for the record: {"GBps", "frac", "kernel_ms_avg"}."""
+    import torch
+    try:
+        w = Workload(name, n, first, rank, dev, "separate")
+        for _ in range(2):
+            w.step()
+        torch.cuda.synchronize()
+        ms = []
+        for _ in range(max(5, args.steps // 2)):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); w.step(); b.record(); b.synchronize()
+            ms.append(a.elapsed_time(b))
+        avg = sum(ms) / len(ms)
+        gbps = w.bytes / (avg / 1e3) / 1e9
+        del w
+        torch.cuda.empty_cache()
+        return {"GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4), "kernel_ms_avg": round(avg, 4)}
+    except Exception as e:          # a comparison figure must never take the bench down
+        return {"error": repr(e)[:200]}
+
+
+def config5_leg(args, world, rank, dev, ctl, w=None, place="zoned"):
     """BASELINE.json configs[4], STRONG scaling: the 10 B-integer u32 column (9 765 625 blocks, width[b] = 1 + b mod 32)
     sharded by contiguous block range over the ranks (no collective on the data path).  `w` = this rank's slice, already
     resident in HBM (main() builds both legs' columns before anything is timed)."""
@@ -599,7 +665,7 @@ def config5_leg(args, world, rank, dev, ctl, w=None):
         return {"dry_run": True, "per_rank": [{"rank": r, "first_block": block_range(CONFIG5_BLOCKS, world, r)[0],
                                                "blocks": int(v[0])} for r, v in enumerate(per_rank)]}
     if w is None:
-        w = Workload("u32_mixed_unpack", n, first, rank, dev)
+        w = Workload("u32_mixed_unpack", n, first, rank, dev, place)
     elapsed, kern_ms = timed_region(w.step, args, ctl)
     avg_ms = sum(kern_ms) / len(kern_ms)
     per_rank = ctl.gather([float(n), avg_ms, float(w.bytes)])
@@ -607,10 +673,12 @@ def config5_leg(args, world, rank, dev, ctl, w=None):
     if rank != 0:
         return {"flags": flags}
     traffic = source = None
+    placed = w.placement
+    import torch
+    w.src = w.dst = w.slab = None            # measured and checked (the PMC child builds its own copy of the column)
+    torch.cuda.empty_cache()
+    separate = separate_allocations_leg("u32_mixed_unpack", n, first, rank, dev, args) if (world == 1 and placed == "zoned") else None
     if world == 1 and not args.no_pmc:
-        del w.src, w.dst                     # the PMC child builds its own copy of the column
-        import torch
-        torch.cuda.empty_cache()
         live = live_pmc_traffic(args, "u32_mixed_unpack")
         if live is not None:
             traffic = int(live["bytes"])
@@ -634,7 +702,8 @@ def config5_leg(args, world, rank, dev, ctl, w=None):
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "aggregate_GBps": round(sum(v[2] for v in per_rank) * args.steps / elapsed / 1e9, 1),
         "per_rank": ranks,
-        "roofline_rank0": roofline(w, kern_ms, traffic, source),
+        "roofline_rank0": dict(roofline(w, kern_ms, traffic, source), **({"separate_allocations": separate} if separate else {})),
+        "placement": PLACEMENT_TEXT[placed],
         "correctness": check_text(flags, n_checked),
         "flags": flags,
     }
@@ -702,21 +771,16 @@ def main():
     import fastlanes_amd as fl
     fl.load()  # fails loudly if the HIP extension is missing
 
-    w = Workload(args.workload, n, first, rank, dev)
-    # Both legs' columns are made resident BEFORE anything is timed (50 + 61 GB on one GPU): a column allocated into the holes a
-    # freed 50 GB column leaves behind streams up to 8 % slower than the same column on a fresh heap (config 5 as the second
-    # leg: 0.75-0.83 of the peak across runs when re-allocated after the first leg, vs 0.81-0.84 standalone).
-    w5 = None
-    if not args.no_config5 and not strong_main:
-        from fastlanes_amd.sharding import block_range as _br
-        f5, n5 = _br(CONFIG5_BLOCKS, world, rank)
-        w5 = Workload("u32_mixed_unpack", n5, f5, rank, dev)
+    place = "separate" if args.single_device else args.placement     # several ranks on one device: no room for a slab each
+    w = Workload(args.workload, n, first, rank, dev, place)
     elapsed, kern_ms = timed_region(w.step, args, ctl)
     avg_ms = sum(kern_ms) / len(kern_ms)
     per_rank = ctl.gather([float(n), avg_ms, float(w.bytes)])
     flags, n_checked = run_check(w, args, ctl)       # every rank, its own slice, outside the timed region
-    w.src = w.dst = w.bases = None                   # leg 1 is measured and checked: its column can go (the PMC child and
-    torch.cuda.empty_cache()                         # leg 2's own column, already resident, need the room)
+    placed = w.placement
+    w.src = w.dst = w.bases = w.slab = None          # leg 1 is measured and checked: its column can go
+    torch.cuda.empty_cache()
+    separate = separate_allocations_leg(args.workload, n, first, rank, dev, args) if (rank == 0 and world == 1 and placed == "zoned") else None
 
     # ---- rank 0, N=1: the cpu_baseline leg (with the checks, the only place bench.py touches oracle/)
     cpu = None
@@ -776,6 +840,9 @@ def main():
             "per_rank": ranks,
             "correctness": check_text(flags, n_checked),
         }
+        out["config"]["placement"] = PLACEMENT_TEXT[placed]
+        if separate is not None:
+            out["roofline"]["separate_allocations"] = separate
         out.update(control)
         if cpu is not None:
             out["cpu_baseline"] = cpu
@@ -783,7 +850,7 @@ def main():
     # ---- second leg: BASELINE.json configs[4] strong-scaled over the same ranks ------------------
     bad = not all(flags)
     if not args.no_config5 and not strong_main:
-        c5 = config5_leg(args, world, rank, dev, ctl, w5)
+        c5 = config5_leg(args, world, rank, dev, ctl, None, place)
         bad = bad or not all(c5.pop("flags"))
         if rank == 0:
             out["config5_strong"] = c5

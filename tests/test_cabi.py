@@ -203,3 +203,16 @@ def test_headers_are_plain_c_and_cxx17():
                            os.path.join(inc, "fastlanes_amd.h")])
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-fsyntax-only", "-x", "c++", "-I", inc,
                            os.path.join(inc, "fastlanes_amd.hpp")])
+
+
+def test_zone_aware_placement_helper_arithmetic():
+    """fastlanes_amd/placement.py: the output starts exactly one 64-GiB zone after the input; an input that would itself cross
+    the zone boundary is refused (no GPU needed for the arithmetic: torch.empty on the meta device)."""
+    import torch
+    from fastlanes_amd import placement as pl
+    assert pl.ZONE_BYTES == 64 << 30
+    slab, src, aux, dst = pl.column_pair(1000, 4096, torch.device("meta"), aux_bytes=128)
+    assert slab.numel() == pl.ZONE_BYTES + 4096 and src.numel() == 1000 and aux.numel() == 128 and dst.numel() == 4096
+    assert dst.storage_offset() - src.storage_offset() == pl.ZONE_BYTES and aux.storage_offset() == 1024
+    with pytest.raises(ValueError):
+        pl.column_pair(pl.ZONE_BYTES, 4096, torch.device("meta"))

@@ -48,5 +48,65 @@ int main(int argc, char** argv)
         for (int o = 0; o < P; ++o) printf(" %6.0f", time_pair(i, o));
         printf("\n");
     }
+    // is a slow output buffer slow everywhere, or in places?  8 consecutive eighths of every pair, each timed on its own
+    printf("GB/s per eighth of the column (1.25 M blocks each), pair by pair\n");
+    const size_t n8 = n / 8;
+    for (int p = 0; p < P; ++p) {
+        printf("pair %d  ", p);
+        for (int k = 0; k < 8; ++k) {
+            std::vector<float> ms;
+            for (int r = 0; r < rounds; ++r) {
+                CK(hipEventRecord(e0, nullptr));
+                if (fl_u32_unpack(7, in[p] + k * n8 * 224, out[p] + k * n8 * 1024, n8, nullptr) != FL_OK) exit(1);
+                CK(hipEventRecord(e1, nullptr));
+                CK(hipEventSynchronize(e1));
+                float t; CK(hipEventElapsedTime(&t, e0, e1));
+                ms.push_back(t);
+            }
+            std::sort(ms.begin(), ms.end());
+            printf(" %6.0f", (double)n8 * 4992 / ms[ms.size() / 2] / 1e6);
+        }
+        printf("\n");
+    }
+    // the same window (n/8 blocks) slid over the column in steps of n/32: where in the allocation is it fast?
+    printf("GB/s of a 1.25 M-block window starting at block s = j * 312 500, pairs 0 and 1\n");
+    for (int p = 0; p < 2 && p < P; ++p) {
+        printf("pair %d ", p);
+        for (int j = 0; j <= 28; ++j) {
+            const size_t s0 = (size_t)j * (n / 32);
+            std::vector<float> ms;
+            for (int r = 0; r < rounds; ++r) {
+                CK(hipEventRecord(e0, nullptr));
+                if (fl_u32_unpack(7, in[p] + s0 * 224, out[p] + s0 * 1024, n8, nullptr) != FL_OK) exit(1);
+                CK(hipEventRecord(e1, nullptr));
+                CK(hipEventSynchronize(e1));
+                float t; CK(hipEventElapsedTime(&t, e0, e1));
+                ms.push_back(t);
+            }
+            std::sort(ms.begin(), ms.end());
+            printf(" %5.0f", (double)n8 * 4992 / ms[ms.size() / 2] / 1e6);
+        }
+        printf("\n");
+    }
+    // is it the kernel or the memory?  a plain write-only stream (fl_fill_random) over the same output windows
+    printf("write-only GB/s (fl_fill_random) over the same output windows, pairs 0 and 1\n");
+    for (int p = 0; p < 2 && p < P; ++p) {
+        printf("pair %d ", p);
+        for (int j = 0; j <= 28; ++j) {
+            const size_t s0 = (size_t)j * (n / 32);
+            std::vector<float> ms;
+            for (int r = 0; r < rounds; ++r) {
+                CK(hipEventRecord(e0, nullptr));
+                if (fl_fill_random(out[p] + s0 * 1024, n8 * 4096, 7, nullptr) != FL_OK) exit(1);
+                CK(hipEventRecord(e1, nullptr));
+                CK(hipEventSynchronize(e1));
+                float t; CK(hipEventElapsedTime(&t, e0, e1));
+                ms.push_back(t);
+            }
+            std::sort(ms.begin(), ms.end());
+            printf(" %5.0f", (double)n8 * 4096 / ms[ms.size() / 2] / 1e6);
+        }
+        printf("\n");
+    }
     return 0;
 }
