@@ -13,6 +13,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fastlanes_amd as fl  # noqa: E402
 
+PLACEMENT = "separate" if "--placement" in sys.argv and sys.argv[sys.argv.index("--placement") + 1] == "separate" else "zoned"
 ESZ = {"u8": 1, "u16": 2, "u32": 4, "u64": 8}
 TDT = {"u8": torch.uint8, "u16": torch.uint16, "u32": torch.uint32, "u64": torch.uint64}
 dev = torch.device("cuda:0")
@@ -42,49 +43,67 @@ def bytes_per_block(op, ty, w):
 
 
 def run(op, ty, w, gb, reps):
+    """One op on one column.  The column's input and output are carved from ONE allocation, the input at offset 0, the output
+    straddling a 64-GiB multiple (fastlanes_amd/placement.py: reads stay inside one 64-GiB zone of the device memory, writes are
+    split over two -- separately allocated tensors share a zone or not at the driver's whim, which moved every row of rounds 1-2
+    by up to 8 %); --placement separate restores that."""
+    from fastlanes_amd import placement as pl
     T = ESZ[ty] * 8
+    esz = ESZ[ty]
     bpb = bytes_per_block(op, ty, w)
     n = max(32, int(gb * 1e9 / bpb))
-    un = lambda s: rnd(n * 128 * T, s).view(TDT[ty])
-    pk = lambda s: rnd(n * 128 * w, s).view(TDT[ty])
-    bases = rnd(n * 128, 3).view(TDT[ty])
-    refs = rnd(n * ESZ[ty], 4).view(TDT[ty])
+    packed_in = op in ("unpack", "unfor_pack", "undelta_pack", "unpack_block_sums", "unpack_compare", "undelta_pack_untranspose")
+    in_bytes = n * 128 * w if packed_in else n * 128 * T
+    if op in ("pack", "for_pack", "transpose_delta_pack"):
+        out_bytes = n * 128 * w
+    elif op == "unpack_block_sums":
+        out_bytes = n * 8
+    elif op == "unpack_compare":
+        out_bytes = n * 128
+    elif op == "block_min_max":
+        out_bytes = 2 * n * esz
+    else:
+        out_bytes = n * 128 * T
+    aux_bytes = n * 128 + n * esz          # Delta bases, then FoR references
+    lib = fl.load()
+    if PLACEMENT == "zoned" and pl.fits(in_bytes, out_bytes, dev, aux_bytes):
+        slab, src8, aux8, dst8 = pl.column_pair(in_bytes, out_bytes, dev, aux_bytes)
+    else:
+        slab = None
+        src8 = torch.empty(in_bytes, dtype=torch.uint8, device=dev)
+        aux8 = torch.empty(aux_bytes, dtype=torch.uint8, device=dev)
+        dst8 = torch.empty(out_bytes, dtype=torch.uint8, device=dev)
+    for t, seed in ((src8, 1), (aux8, 3)):
+        if t.numel() & ~7:
+            assert lib.fl_fill_random(t.data_ptr(), t.numel() & ~7, seed, None) == 0
+    src = src8.view(TDT[ty])
+    dst = dst8[:(out_bytes // esz) * esz].view(TDT[ty]) if op not in ("unpack_block_sums", "unpack_compare", "block_min_max") else None
+    bases = aux8[:n * 128].view(TDT[ty])
+    refs = aux8[n * 128:n * 128 + n * esz].view(TDT[ty])
     if op == "pack":
-        src, dst = un(1), torch.empty(n * 128 * w // ESZ[ty], dtype=TDT[ty], device=dev)
         f = lambda: fl.BitPacking.pack(w, src, output=dst)
     elif op == "unpack":
-        src, dst = pk(1), torch.empty(n * 1024, dtype=TDT[ty], device=dev)
         f = lambda: fl.BitPacking.unpack(w, src, output=dst)
     elif op == "for_pack":
-        src, dst = un(1), torch.empty(n * 128 * w // ESZ[ty], dtype=TDT[ty], device=dev)
         f = lambda: fl.FoR.for_pack(w, src, refs, output=dst)
     elif op == "unfor_pack":
-        src, dst = pk(1), torch.empty(n * 1024, dtype=TDT[ty], device=dev)
         f = lambda: fl.FoR.unfor_pack(w, src, refs, output=dst)
     elif op == "undelta_pack":
-        src, dst = pk(1), torch.empty(n * 1024, dtype=TDT[ty], device=dev)
         f = lambda: fl.Delta.undelta_pack(w, src, bases, output=dst)
     elif op == "unpack_block_sums":
-        src = pk(1)
-        f = lambda: fl.BitPacking.unpack_block_sums(w, src)
+        f = lambda: fl.BitPacking.unpack_block_sums(w, src)          # (allocates its own 8 B / block result)
     elif op == "unpack_compare":
-        src = pk(1)
         f = lambda: fl.BitPacking.unpack_compare(w, src, "<", (1 << w) // 2)
     elif op == "block_min_max":
-        src = un(1)
         f = lambda: fl.BitPacking.block_min_max(src)
     elif op == "undelta_pack_untranspose":
-        src, dst = pk(1), torch.empty(n * 1024, dtype=TDT[ty], device=dev)
         f = lambda: fl.Delta.undelta_pack_untranspose(w, src, bases, output=dst)
     elif op == "transpose_delta_pack":
-        src, dst = un(1), torch.empty(n * 128 * w // ESZ[ty], dtype=TDT[ty], device=dev)
         f = lambda: fl.Delta.transpose_delta_pack(w, src, bases, output=dst)
     elif op in ("delta", "undelta"):
-        src, dst = un(1), torch.empty(n * 1024, dtype=TDT[ty], device=dev)
         g = getattr(fl.Delta, op)
         f = lambda: g(src, bases, output=dst)
     else:
-        src, dst = un(1), torch.empty(n * 1024, dtype=TDT[ty], device=dev)
         g = getattr(fl.Transpose, op)
         f = lambda: g(src, output=dst)
     for _ in range(2):
@@ -120,6 +139,7 @@ def main():
     ap.add_argument("--reps", type=int, default=7)
     ap.add_argument("--cases", default="quick")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--placement", default="zoned", choices=("zoned", "separate"))
     args = ap.parse_args()
     cases = []
     if args.cases == "quick":
