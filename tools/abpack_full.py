@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B on the GPU box at BASELINE-like sizes: pack / unpack through the cell-column kernels vs the wave-per-block kernels at
-3/4/5/6/8 waves per SIMD, on the SAME torch-allocated buffers (the allocation pattern of bench.py), full-entropy inputs.
+3/4/5/6/8 waves per SIMD, on the SAME buffers, placed like bench.py places them (zone-aware: fastlanes_amd/placement.py),
+full-entropy inputs.
     FL_LIB=$PWD/fastlanes_amd/libfastlanes_amd_full.so python tools/abpack_full.py [--all] [--gb 64] [--rounds 3]
 Default: BASELINE's configs 2, 3 (and u32 W=12) at the full 10 M blocks.  --all: every (T, W) at min(10 M blocks, --gb GB per
 launch), printed in tools/abuniform's row format -- the input of tools/make_dispatch.py (which kernel and which occupancy
@@ -13,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 import fastlanes_amd as fl  # noqa: E402
-from bench import rand_u8  # noqa: E402
+from fastlanes_amd import placement as pl  # noqa: E402
 
 lib = fl.load()
 assert b"FULL build" in lib.fl_version(), "run against libfastlanes_amd_full.so (FL_LIB=...): policy 1 must mean the cell-column kernel"
@@ -26,20 +27,26 @@ TD = {"u8": (torch.uint8, 8), "u16": (torch.uint16, 16), "u32": (torch.uint32, 3
 cases = [("u32", 7), ("u64", 17), ("u32", 12)]
 if ALL:
     cases = [(ty, w) for ty in ("u32", "u64", "u16", "u8") for w in range(TD[ty][1] + 1)]
-print(f"GB/s (algorithmic bytes), median of {ROUNDS}, min(10 M blocks, {GB:.0f} GB) per launch, torch allocations; cc = cell-column kernel, "
+print(f"GB/s (algorithmic bytes), median of {ROUNDS}, min(10 M blocks, {GB:.0f} GB) per launch, zone-aware placement; cc = cell-column kernel, "
       "wpb = wave-per-block at 3 4 5 6 8 waves/SIMD")
-cur = None
+def fill(t, seed):
+    if t.numel() & ~7:
+        assert lib.fl_fill_random(t.data_ptr(), t.numel() & ~7, seed, None) == 0
+
+
 for ty, W in cases:
     tdt, T = TD[ty]
     esz = T // 8
     bpb = 128 * W + 1024 * esz
     n = min(10_000_000, int(GB * 1e9 / bpb))
-    if cur != (ty, n):           # the unpacked buffers are shared by every width of a type (same placement for all of them)
-        un = rand_u8(n * 1024 * esz, 1, dev).view(tdt)           # pack input: full-entropy values (pack truncates)
-        un_out = torch.empty(n * 1024, dtype=tdt, device=dev)
-        cur = (ty, n)
-    pk_in = rand_u8(n * 128 * W, 2, dev).view(tdt)
-    pk_out = torch.empty(n * 128 * W // esz, dtype=tdt, device=dev)
+    # zone-aware placement (fastlanes_amd/placement.py), one slab per direction: the input inside one 64-GiB zone, the output
+    # straddling two -- the layout bench.py uses, so that a row compares the two designs where the bench measures them
+    slab_u, pk8, _, un8 = pl.column_pair(n * 128 * W, n * 1024 * esz, dev)        # unpack: packed in, unpacked out
+    fill(pk8, 2)
+    pk_in, un_out = pk8.view(tdt), un8.view(tdt)
+    slab_p, uni8, _, pko8 = pl.column_pair(n * 1024 * esz, n * 128 * W, dev)      # pack: full-entropy values in (pack truncates)
+    fill(uni8, 1)
+    un, pk_out = uni8.view(tdt), pko8.view(tdt)
     row = {}
     for name, f in (("unpack", lambda: fl.BitPacking.unpack(W, pk_in, output=un_out, n_blocks=n)), ("pack", lambda: fl.BitPacking.pack(W, un, output=pk_out))):
         res = {}
@@ -56,4 +63,5 @@ for ty, W in cases:
     u, p = row["unpack"], row["pack"]
     print(f"u{T:<2d} W={W:<2d} | unpack cc {u[0]:6.0f}  wpb " + " ".join(f"{x:6.0f}" for x in u[1:]) +
           f" | pack cc {p[0]:6.0f}  wpb " + " ".join(f"{x:6.0f}" for x in p[1:]), flush=True)
-    del pk_in, pk_out
+    del pk_in, pk_out, un, un_out, slab_u, slab_p, pk8, un8, uni8, pko8
+    torch.cuda.empty_cache()
