@@ -158,6 +158,23 @@ def _out(src, output, ty, n_elems, what):
     return out
 
 
+def _consumer_out(src, output, dtype, n_elems, what):
+    """Output tensor of a fused consumer (sums / mask): the caller's CUDA tensor of exactly n_elems elements of `dtype`'s width on
+    the input's device, or a fresh one.  (Where a thin output stream lives relative to the packed input moves the rate by
+    10-15 %: DESIGN.md 4, fastlanes_amd/placement.py.)"""
+    import torch
+    if output is None:
+        return torch.empty(n_elems, dtype=dtype, device=src.x.device)
+    if not (_is_torch(output) and output.is_cuda and output.is_contiguous()):
+        raise TypeError(f"{what}: output must be a contiguous CUDA tensor")
+    if output.device != src.x.device:
+        raise ValueError(f"tensors live on different devices ({src.x.device} vs {output.device})")
+    if output.element_size() != torch.empty(0, dtype=dtype).element_size() or output.numel() != n_elems:
+        raise ValueError(f"{what}: output holds {output.numel()} x {output.element_size()}-byte elements, expected {n_elems} x "
+                         f"{torch.empty(0, dtype=dtype).element_size()}")
+    return output
+
+
 def _run(method, ty, width, src, out, n_blocks, aux=None, aux_stride=None, scalar=None):
     """Dispatch to fl_<ty>_<method>[_host]."""
     lib = _lib.load()
@@ -263,10 +280,10 @@ class BitPacking:
 
     # ---- extensions -------------------------------------------------------
     @staticmethod
-    def unpack_block_sums(width, packed, n_blocks=None):
+    def unpack_block_sums(width, packed, n_blocks=None, output=None):
         """sums[b] = sum(BitPacking.unpack(width, block b)) as wrapping uint64, without
         materialising the values.  Device tier only; returns a CUDA int64 tensor (bit pattern
-        of the uint64 sums)."""
+        of the uint64 sums) -- `output` (n_blocks 8-byte elements) if given."""
         import torch
         src = _Arg(packed)
         ty = src.ty
@@ -275,7 +292,7 @@ class BitPacking:
         n = _blocks(src.n, packed_len(ty, width), "unpack_block_sums input")
         if n is None:
             n = n_blocks or 0
-        out = torch.empty(n, dtype=torch.int64, device=src.x.device)
+        out = _consumer_out(src, output, torch.int64, n, "unpack_block_sums")
         with torch.cuda.device(src.x.device):
             _check(getattr(_lib.load(), f"fl_{ty}_unpack_block_sums")(width, src.ptr, n, out.data_ptr(), _stream(src)),
                    f"fl_{ty}_unpack_block_sums")
@@ -284,11 +301,11 @@ class BitPacking:
     CMP = {"==": 0, "!=": 1, "<": 2, "<=": 3, ">": 4, ">=": 5}
 
     @staticmethod
-    def unpack_compare(width, packed, op, constant, n_blocks=None):
+    def unpack_compare(width, packed, op, constant, n_blocks=None, output=None):
         """Selection mask straight from packed data: bit i of block b's 1024-bit mask =
         (BitPacking.unpack(width, block b)[i] <op> constant), op in '==','!=','<','<=','>','>='.
         Device tier only; returns a CUDA int32 tensor of 32 words per block (bit i of word i//32,
-        LSB first)."""
+        LSB first) -- `output` (32 * n_blocks 4-byte elements) if given."""
         import torch
         src = _Arg(packed)
         ty = src.ty
@@ -297,7 +314,7 @@ class BitPacking:
         n = _blocks(src.n, packed_len(ty, width), "unpack_compare input")
         if n is None:
             n = n_blocks or 0
-        out = torch.empty(n * 32, dtype=torch.int32, device=src.x.device)
+        out = _consumer_out(src, output, torch.int32, n * 32, "unpack_compare")
         k = _lib.CTYPE[ty](int(constant) & ((1 << _lib.BITS[ty]) - 1))
         with torch.cuda.device(src.x.device):
             _check(getattr(_lib.load(), f"fl_{ty}_unpack_compare")(width, src.ptr, BitPacking.CMP[op], k, n,

@@ -227,19 +227,6 @@ int dev_unpack_compare(unsigned w, const T* in, int op, T constant, size_t n, ui
         if (constant == 0) a.constant = MAXV; else { a.constant = (T)(constant - 1); a.invert = 1; }
         break;
     }
-    // u32 / u64 from mid widths up: the wave-per-block form (1 KiB-contiguous non-temporal reads); kernel policy 1 / 2 force
-    // one of the two (tests, A/B)
-    const int pol = g_kernel_policy.load(std::memory_order_relaxed);
-    int waves = compare_wave_policy(Elem<T>::BITS, w);
-    if ((pol & 0xff) == 1) waves = 0;
-    if ((pol & 0xff) == 2 && sizeof(T) >= 4 && w >= 1) waves = ((pol >> 8) & 0xff) ? ((pol >> 8) & 0xff) : (waves ? waves : 4);
-    if (waves) {
-        const compare_wave_launch_t fn = a.is_eq ? compare_wave_launcher<T, true>() : compare_wave_launcher<T, false>();
-        if (fn) {
-            hipError_t e = fn(a, w, waves, static_cast<hipStream_t>(s));
-            return e == hipSuccess ? FL_OK : hip_fail(e);
-        }
-    }
     hipError_t e = (a.is_eq ? compare_table_impl<T, true>() : compare_table_impl<T, false>()).fn[w](a, static_cast<hipStream_t>(s));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }

@@ -8,7 +8,6 @@
 //                          (bits(max - min)) before calling for_pack::<W> (ffor.rs:24-36).
 #pragma once
 #include "fl_kernels.hpp"
-#include "fl_widths.hpp"
 
 namespace fl {
 
@@ -168,8 +167,8 @@ __global__ __launch_bounds__(WG) void k_block_min_max(ReduceArgs a)
 // in, 128 bytes out per block.  Every predicate is reduced on the host to one of two primitives
 // (x == k, x <= k) plus a final complement.  Address-row j of a block is elements [j*LANES,
 // (j+1)*LANES) = mask bits [j*LANES, (j+1)*LANES); every column thread contributes PER_CELL contiguous bits
-// of each row.  The pieces are put together in a wave-private LDS image of the block's 128-byte mask
-// (u8/u16/u32) or with DPP OR-reductions (u64), and the mask leaves as one coalesced 16-byte store per thread.
+// of each row.  The pieces are put together in a wave-private LDS image of the block's 128-byte mask (u8 / u16) or by a
+// register butterfly between the 8 threads (u32 / u64), and the mask leaves as one coalesced 16-byte store per thread.
 // ---------------------------------------------------------------------------
 struct CompareArgs {
     const u32x4* in;
@@ -180,14 +179,6 @@ struct CompareArgs {
     uint64_t n_blocks;
     uint64_t tiles_per_xcd;
 };
-
-__device__ __forceinline__ uint32_t or_allreduce8(uint32_t x)
-{
-    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]: lane ^ 1
-    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]: lane ^ 2
-    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true);   // row_half_mirror: lane -> 7 - lane
-    return x;
-}
 
 // Per-row predicate bits of one cell column: bit e of the result = cmp(element e of the cell, k), e < PER_CELL.
 //   u64 / u32 : one compare per element.
@@ -281,37 +272,136 @@ __device__ __forceinline__ uint32_t row_predicate_bits_of_row(const Cell<T>* in,
     }
 }
 
-// u64: the 8 column threads OR their 2-bit pieces together with three DPP steps per 32-bit mask word.
-template <typename T, int W, bool IS_EQ>
-__device__ __forceinline__ void compare_block_dpp(const Cell<T>* in, T k, unsigned c, uint32_t (&keep)[4])
+// u32 / u64: the verdict bits never leave the registers.
+//   * One verdict costs two VALU operations: v_cmp writes the lane's verdict to VCC and v_addc_co (bits + bits + carry-in)
+//     shifts it into the low end of a 32-bit word (shift_in_verdicts).  hipcc has no pattern for that (it emits v_cmp, v_cndmask, v_or / v_lshl:
+//     2.75 per value), hence the two-instruction asm.
+//   * A column thread's 128 verdicts (T rows x N elements) fill 4 words; what it must store is the 128 mask bits of ITS
+//     T/8 address-rows over all 8 columns.  That is an 8 x 8 transpose of N*T/8-bit pieces between the 8 threads of a block,
+//     done as a 3-step butterfly on words laid out for it: a word's bit positions are [.. | J2 J1 J0 | e] where J = the
+//     address-row's owner (j / (T/8)) and e the element inside the cell; step i swaps "owner bit i" with "column bit i" --
+//     a thread keeps the groups whose J_i equals bit i of its own column, takes the partner's (column ^ (1 << i)) groups
+//     with the same J_i and puts them where the groups it gave away were (a rotate by the group size, one v_bfi).  After the
+//     three steps bit positions read [.. | c2 c1 c0 | e]: the mask's own layout.  3 operations per word and step.
+//     (Before: three DPP OR-steps per mask word for u64, a DPP exchange + ds_write_b8 per row and an LDS round trip for
+//     u32: 176 and 270 of the 660 / 850 VALU operations per wavefront at u32 W=7 / u64 W=17, now 36 + 9.)
+//   * DPP reaches lane ^ 1, lane ^ 2 and lane ^ 7 (row_half_mirror) of an 8-lane group in one operation, not lane ^ 4.  So
+//     lanes 4..7 of a group take the columns in reverse (column_of_lane): then lane ^ 7 IS column ^ 4.  The 8 lanes still read
+//     and write the same 128 contiguous bytes per row.
+__device__ __forceinline__ unsigned column_of_lane(unsigned lane8) { return lane8 ^ ((lane8 & 4u) ? 3u : 0u); }
+
+#define FL_CMP_ADDC(op, x) "v_cmp_" op " vcc, %[k], %[" x "]\n\tv_addc_co_u32 %[b], vcc, %[b], %[b], vcc\n\t"
+// verdicts of x3, x2, x1, x0 (u32: the four elements of a cell) in that order; one asm statement per cell because hipcc puts an
+// s_nop between two adjacent asm statements that touch VCC
+template <bool IS_EQ> __device__ __forceinline__ void shift_in_verdicts(uint32_t& bits, uint32_t x3, uint32_t x2, uint32_t x1, uint32_t x0, uint32_t k)
 {
-    constexpr int TB = Elem<T>::BITS;
-    constexpr int N = Elem<T>::PER_CELL;              // bits this thread contributes per row
-    constexpr int LANES = Elem<T>::LANES;             // bits per address-row
-    constexpr int PER_S = TB / 8;
-    static_assert(LANES <= 32, "one or more address-rows per mask word");
-    uint32_t piece[TB];
-    static_for<TB>([&](auto J) {
-        constexpr int j = decltype(J)::value;
-        constexpr int row = fl_order((j % PER_S) * (8 / PER_S)) * 8 + j / PER_S;
-        piece[j] = row_predicate_bits<T, W, IS_EQ>(unpack_row<T, W, row>(in), k);
-    });
-    static_for<32>([&](auto D) {
-        constexpr int d = decltype(D)::value;
-        constexpr int RPW = 32 / LANES;               // address-rows per mask word
-        uint32_t w = 0;
-        static_for<RPW>([&](auto Q) {
-            constexpr int q = decltype(Q)::value;
-            w |= piece[d * RPW + q] << (q * LANES + c * N);
-        });
-        w = or_allreduce8(w);
-        if (d / 4 == (int)c) keep[d % 4] = w;
-    });
+    if constexpr (IS_EQ)
+        asm(FL_CMP_ADDC("eq_u32", "x3") FL_CMP_ADDC("eq_u32", "x2") FL_CMP_ADDC("eq_u32", "x1") FL_CMP_ADDC("eq_u32", "x0")
+            : [b] "+&v"(bits) : [x3] "v"(x3), [x2] "v"(x2), [x1] "v"(x1), [x0] "v"(x0), [k] "s"(k) : "vcc");
+    else
+        asm(FL_CMP_ADDC("ge_u32", "x3") FL_CMP_ADDC("ge_u32", "x2") FL_CMP_ADDC("ge_u32", "x1") FL_CMP_ADDC("ge_u32", "x0")     // k >= x
+            : [b] "+&v"(bits) : [x3] "v"(x3), [x2] "v"(x2), [x1] "v"(x1), [x0] "v"(x0), [k] "s"(k) : "vcc");
+}
+template <bool IS_EQ> __device__ __forceinline__ void shift_in_verdicts(uint32_t& bits, uint32_t x1, uint32_t x0, uint32_t k)
+{
+    if constexpr (IS_EQ) asm(FL_CMP_ADDC("eq_u32", "x1") FL_CMP_ADDC("eq_u32", "x0") : [b] "+&v"(bits) : [x1] "v"(x1), [x0] "v"(x0), [k] "s"(k) : "vcc");
+    else asm(FL_CMP_ADDC("ge_u32", "x1") FL_CMP_ADDC("ge_u32", "x0") : [b] "+&v"(bits) : [x1] "v"(x1), [x0] "v"(x0), [k] "s"(k) : "vcc");
+}
+template <bool IS_EQ> __device__ __forceinline__ void shift_in_verdicts(uint32_t& bits, uint64_t x1, uint64_t x0, uint64_t k)
+{
+    if constexpr (IS_EQ) asm(FL_CMP_ADDC("eq_u64", "x1") FL_CMP_ADDC("eq_u64", "x0") : [b] "+&v"(bits) : [x1] "v"(x1), [x0] "v"(x0), [k] "s"(k) : "vcc");
+    else asm(FL_CMP_ADDC("ge_u64", "x1") FL_CMP_ADDC("ge_u64", "x0") : [b] "+&v"(bits) : [x1] "v"(x1), [x0] "v"(x0), [k] "s"(k) : "vcc");
+}
+#undef FL_CMP_ADDC
+
+// the partner's word: column ^ (1 << STEP) (see column_of_lane for STEP = 2)
+template <int STEP> __device__ __forceinline__ uint32_t butterfly_partner(uint32_t x)
+{
+    constexpr int ctrl = STEP == 0 ? 0xB1 /* quad_perm [1,0,3,2] */ : STEP == 1 ? 0x4E /* quad_perm [2,3,0,1] */ : 0x141 /* row_half_mirror */;
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, 0xF, 0xF, true);
 }
 
-// u8 / u16 / u32: the block's 128-byte mask is assembled in a wave-private LDS image -- address-row j is bits
-// [j*LANES, (j+1)*LANES) and thread c owns PER_CELL contiguous bits of it (16 bits: ds_write_b16, 8 bits: ds_write_b8,
-// 4 bits: one DPP exchange with the neighbour column makes a byte) -- and read back as one 16-byte cell per thread.
+// (address-row j, element e) whose verdict sits at bit b of pre-butterfly word m:  u32: word = j % 4, bit = (j / 4) * 4 + e;
+// u64: word = (j / 2) % 4, bit = (j % 2) * 16 + (j / 8) * 2 + e  -- the owner j / (T/8) in the three bits above e
+template <typename T> constexpr int butterfly_row(int m, int b) { return sizeof(T) == 4 ? 4 * (b >> 2) + m : 8 * ((b >> 1) & 7) + 2 * m + (b >> 4); }
+template <typename T> constexpr int butterfly_elem(int b) { return sizeof(T) == 4 ? (b & 3) : (b & 1); }
+
+// x <= k without extracting x: the field of logical row ROW, element ELEM, moved to the TOP of a 32-bit register -- one shift if it
+// lies inside a dword of the lane's stream, one v_alignbit_b32 if it crosses into the next -- with whatever lay below it left
+// in place.  [field | junk] <= [k | all ones] <=> field <= k, so the mask (v_and / v_bfe) of macros.rs:150-164 is not needed.
+// 1 <= W <= 32 (for u64: the two dwords of a word are consecutive dwords of the stream).
+template <typename T, int I, int ELEM> __device__ __forceinline__ uint32_t stream_dword(const Cell<T>* in)
+{
+    if constexpr (sizeof(T) == 4) return in[I].x[ELEM];
+    else return __builtin_bit_cast(u32x4, in[I / 2])[2 * ELEM + I % 2];   // (as registers: a 64-bit shift would be re-derived as v_alignbit + v_and)
+}
+template <typename T, int W, int ROW, int ELEM> __device__ __forceinline__ uint32_t top_aligned_field(const Cell<T>* in)
+{
+    static_assert(sizeof(T) >= 4 && W >= 1 && W <= 32, "");
+    constexpr int d = (ROW * W) / 32, s = (ROW * W) % 32;
+    if constexpr (s + W == 32) return stream_dword<T, d, ELEM>(in);
+    else if constexpr (s + W < 32) return stream_dword<T, d, ELEM>(in) << (32 - s - W);
+    else return __builtin_amdgcn_alignbit(stream_dword<T, d + 1, ELEM>(in), stream_dword<T, d, ELEM>(in), s + W - 32);
+}
+
+template <typename T, int W, bool IS_EQ>
+__device__ __forceinline__ void compare_block_butterfly(const Cell<T>* in, T k, unsigned c, uint32_t (&keep)[4])
+{
+    static_assert(sizeof(T) >= 4, "u8 / u16 compare SWAR-wise (compare_block_lds)");
+    constexpr int TB = Elem<T>::BITS;
+    constexpr int N = Elem<T>::PER_CELL;
+    constexpr int LOG_N = N == 4 ? 2 : 1;
+    constexpr int PER_S = TB / 8;
+    // every value is < 2^W: x <= k <=> x <= min(k, 2^W - 1), and x == k is false beyond 2^W - 1; for W <= 32 the compare is then
+    // a 32-bit one for u64 too
+    constexpr T FM = W >= TB ? (T) ~(T)0 : (T)(((T)1 << (W % TB)) - 1);
+    const bool beyond = k > FM;                                   // wave-uniform
+    const T kc = beyond ? FM : k;
+    constexpr int TOP = W >= 1 && W < 32 ? 32 - W : 0;
+    const uint32_t k_top = ((uint32_t)kc << TOP) | ((1u << TOP) - 1u);   // [k | all ones], see top_aligned_field
+    static_for<4>([&](auto M) {
+        constexpr int m = decltype(M)::value;
+        uint32_t bits = 0;
+        static_for<32 / N>([&](auto Q) {
+            constexpr int b0 = 32 - N * (decltype(Q)::value + 1);   // descending: the first verdict shifted in ends up on top
+            constexpr int j = butterfly_row<T>(m, b0);              // bits b0 .. b0 + N - 1 are the N elements of one address-row
+            static_assert(butterfly_elem<T>(b0) == 0 && butterfly_row<T>(m, b0 + N - 1) == j, "");
+            constexpr int row = fl_order((j % PER_S) * (8 / PER_S)) * 8 + j / PER_S;
+            if constexpr (!IS_EQ && W >= 1 && W <= 32) {
+                if constexpr (N == 4)
+                    shift_in_verdicts<false>(bits, top_aligned_field<T, W, row, 3>(in), top_aligned_field<T, W, row, 2>(in),
+                                             top_aligned_field<T, W, row, 1>(in), top_aligned_field<T, W, row, 0>(in), k_top);
+                else
+                    shift_in_verdicts<false>(bits, top_aligned_field<T, W, row, 1>(in), top_aligned_field<T, W, row, 0>(in), k_top);
+            } else {
+                const Cell<T> v = unpack_row<T, W, row>(in);
+                if constexpr (N == 4) shift_in_verdicts<IS_EQ>(bits, v.x[3], v.x[2], v.x[1], v.x[0], (uint32_t)kc);
+                else if constexpr (W <= 32) shift_in_verdicts<IS_EQ>(bits, (uint32_t)v.x[1], (uint32_t)v.x[0], (uint32_t)kc);
+                else shift_in_verdicts<IS_EQ>(bits, (uint64_t)v.x[1], (uint64_t)v.x[0], (uint64_t)kc);
+            }
+        });
+        keep[m] = bits;
+    });
+    static_for<3>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        constexpr int g = N << i;                                 // group size in bits at this step
+        constexpr uint32_t LOW = g == 2 ? 0x33333333u : g == 4 ? 0x0F0F0F0Fu : g == 8 ? 0x00FF00FFu : 0x0000FFFFu;   // position bit (LOG_N + i) clear
+        static_assert(LOG_N + i <= 4, "groups stay inside a word");
+        const bool up = (c >> i) & 1u;
+        const uint32_t mine = up ? (LOW << g) : LOW;              // the groups this thread keeps
+        const uint32_t rot = up ? (uint32_t)g : 32u - g;          // received groups move down (up: their J_i = 1 slot -> 0) or up
+        static_for<4>([&](auto M) {
+            constexpr int m = decltype(M)::value;
+            const uint32_t t = butterfly_partner<i>(keep[m]);
+            keep[m] = (keep[m] & mine) | (__builtin_amdgcn_alignbit(t, t, rot) & ~mine);
+        });
+    });
+    if (IS_EQ && beyond) keep[0] = keep[1] = keep[2] = keep[3] = 0u;
+}
+
+// u8 / u16: the block's 128-byte mask is assembled in a wave-private LDS image -- address-row j is bits
+// [j*LANES, (j+1)*LANES) and thread c owns PER_CELL contiguous bits of it (16 bits: ds_write_b16, 8 bits: ds_write_b8)
+// -- and read back as one 16-byte cell per thread.
 template <typename T, int W, bool IS_EQ>
 __device__ __forceinline__ void compare_block_lds(const Cell<T>* in, T k, unsigned c, char* lds_blk, uint32_t (&keep)[4])
 {
@@ -321,15 +411,8 @@ __device__ __forceinline__ void compare_block_lds(const Cell<T>* in, T k, unsign
         constexpr int j = decltype(J)::value;
         constexpr int row = fl_order((j % PER_S) * (8 / PER_S)) * 8 + j / PER_S;
         const uint32_t bits = row_predicate_bits_of_row<T, W, row, IS_EQ>(in, k);
-        if constexpr (sizeof(T) == 1) {
-            *reinterpret_cast<uint16_t*>(lds_blk + j * 16 + c * 2) = (uint16_t)bits;
-        } else if constexpr (sizeof(T) == 2) {
-            *reinterpret_cast<uint8_t*>(lds_blk + j * 8 + c) = (uint8_t)bits;
-        } else {
-            uint32_t w = bits << (4 * (c & 1u));
-            w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]: lane ^ 1
-            *reinterpret_cast<uint8_t*>(lds_blk + j * 4 + (c >> 1)) = (uint8_t)w;           // both columns of the pair write the same byte
-        }
+        if constexpr (sizeof(T) == 1) *reinterpret_cast<uint16_t*>(lds_blk + j * 16 + c * 2) = (uint16_t)bits;
+        else *reinterpret_cast<uint8_t*>(lds_blk + j * 8 + c) = (uint8_t)bits;
     });
     wave_lds_fence();
     const u32x4 m = *reinterpret_cast<const u32x4*>(lds_blk + c * 16);
@@ -344,14 +427,14 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, compare_m
     if (tile >= n_tiles) return;
     const unsigned tid = threadIdx.x;
     const uint64_t blk = tile * BLOCKS_PER_WG + (tid >> 3);
-    const unsigned c = tid & 7u;
+    const unsigned c = sizeof(T) >= 4 ? column_of_lane(tid & 7u) : (tid & 7u);
     if (blk >= a.n_blocks) return;     // whole 8-thread groups leave together (DPP / LDS exchange stays inside a group)
     Cell<T> in[W ? W : 1];
     const u32x4* pk = a.in + blk * (uint64_t)(8 * W) + c;
     static_for<W>([&](auto Wd) { in[decltype(Wd)::value] = load_cell<T, true>(pk + 8 * decltype(Wd)::value); });
     uint32_t keep[4] = {0, 0, 0, 0};
-    if constexpr (sizeof(T) == 8) {
-        compare_block_dpp<T, W, IS_EQ>(in, (T)a.constant, c, keep);
+    if constexpr (sizeof(T) >= 4) {
+        compare_block_butterfly<T, W, IS_EQ>(in, (T)a.constant, c, keep);
     } else {
         // 144-byte stride between the mask images of a wavefront's 8 blocks: at 128 bytes (= all 32 banks) the same byte
         // of every block falls into the same bank and each ds_write is an 8-way conflict (profiles/r03_pmc_sq_counters.csv:
@@ -361,8 +444,13 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, compare_m
         compare_block_lds<T, W, IS_EQ>(in, (T)a.constant, c, lds + (tid >> 3) * MASK_STRIDE, keep);
     }
     const uint32_t flip = a.invert ? ~0u : 0u;
-    u32x4 out = {keep[0] ^ flip, keep[1] ^ flip, keep[2] ^ flip, keep[3] ^ flip};
-    a.mask[blk * 8 + c] = out;
+    const u32x4 out = {keep[0] ^ flip, keep[1] ^ flip, keep[2] ^ flip, keep[3] ^ flip};
+    // The mask is 1/8 .. 1/56 of the bytes moved and still what bounds this kernel: with the store suppressed, or aimed at one
+    // L2-resident 4 KiB, the same loads run at 7.8-8.5 TB/s (counting the mask), with it at 5.8-6.0 -- a thin write stream inside a
+    // read stream costs the DRAM about 2.4x its bytes (profiles/abcompare_maskstore_r03.txt).  The streaming store policy of the
+    // unpack kernels (nt + sc1) recovers 3-6 % of that at the narrow widths; walking several tiles per workgroup does not.
+    const __amdgpu_buffer_rsrc_t mask_rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.mask) + blk * 128u, 0, 128u, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(out, mask_rs, c * 16u, 0, STORE_AUX);
 }
 
 typedef hipError_t (*compare_launch_t)(const CompareArgs&, hipStream_t);
@@ -383,98 +471,6 @@ constexpr CompareTable<T> make_compare_table(std::integer_sequence<int, Ws...>)
 }
 // the two primitives live in separate translation units (families 11 / 12) to build in parallel
 template <typename T, bool IS_EQ> const CompareTable<T>& compare_table_impl();
-
-// ---------------------------------------------------------------------------
-// unpack_compare on the wave-per-block mapping (u32 / u64, runtime width): the packed block arrives in the wave's LDS image by
-// non-temporal LDS-DMA (1 KiB-contiguous reads, fl_widths.hpp), lane (i, c) funnel-shifts the cell of address-row 8k+i,
-// column c of every 1-KiB group k -- N = 16/sizeof(T) elements with CONSECUTIVE element indices k*1024/sizeof(T) + lane*N --
-// so its N verdicts are N consecutive mask bits; the 8 lanes of a lane group (u64: 16 lanes) OR them into one 32-bit mask
-// word with DPP steps, and 32 lanes store the block's 32 words.  More VALU per value than the cell-column kernel (the
-// shift is a register, not a constant), but the wide widths are nowhere near VALU-bound there (0.26-0.38 of the issue
-// rate) and read 1 KiB contiguous here instead of 8 x 128 B.
-// ---------------------------------------------------------------------------
-template <typename T, bool IS_EQ>
-__global__ __launch_bounds__(WG) void k_compare_wave(CompareArgs a, unsigned w)
-{
-    static_assert(sizeof(T) >= 4, "SWAR types stay on the cell-column kernel");
-    using G = WaveBlock<T>;
-    constexpr int TB = G::TB;
-    constexpr int N = 16 / (int)sizeof(T);
-    extern __shared__ __attribute__((aligned(16))) char lds_all[];
-    const uint64_t n_tiles = (a.n_blocks + (WG / 64) - 1) / (WG / 64);
-    const uint64_t tile = (uint64_t)(blockIdx.x & 7u) * a.tiles_per_xcd + (blockIdx.x >> 3);
-    if (tile >= n_tiles) return;
-    const unsigned tid = threadIdx.x;
-    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
-    const uint64_t blk = tile * (WG / 64) + wave;
-    if (blk >= a.n_blocks) return;
-    char* lds = lds_all + wave * G::BLOCK_BYTES;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(a.in)) + blk * (uint64_t)(128u * w), 0, 128u * w, 0x00020000);
-    static_for<G::GROUPS>([&](auto Gi) {
-        constexpr int g = decltype(Gi)::value;
-        if (8u * g < w) dma_1k_to_lds<RD_DMA_NT, g * 1024>(rs, lds, lane);
-    });
-    wait_lds_dma();
-    wave_lds_fence();
-    const T k = (T)a.constant;
-    const unsigned i = lane >> 3, c = lane & 7u, c16 = c * 16u;
-    const typename G::word_t m = G::field_mask(w);
-    unsigned bit = G::row_base(i) * w;
-    const unsigned step = G::KSTEP * w;
-    const unsigned last = (w - 1u) * 128u;
-    uint32_t mine = 0;
-    static_for<G::GROUPS>([&](auto K) {
-        constexpr unsigned kk = decltype(K)::value;
-        const unsigned word = bit >> G::LOG_TB, sh = bit & (TB - 1u);
-        const unsigned a0 = word * 128u;
-        const unsigned a1 = a0 + 128u < last ? a0 + 128u : last;            // macros.rs:156
-        const Cell<T> cur = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(lds + a0 + c16));
-        const Cell<T> nxt = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(lds + a1 + c16));
-        const Cell<T> v = G::funnel(cur, nxt, sh, m);
-        uint32_t bits = 0;
-        static_for<N>([&](auto E) {
-            const T x = (T)cell_get<T>(v, decltype(E)::value);
-            const uint32_t p = IS_EQ ? (x == k) : (x <= k);
-            bits |= p << decltype(E)::value;
-        });
-        // this cell's N elements are mask bits [kk*(1024/sizeof(T))... ] = element index kk*64*N + lane*N
-        if constexpr (sizeof(T) == 4) {
-            uint32_t wd = or_allreduce8(bits << (4u * c));                  // 8 lanes x 4 bits = mask word kk*8 + i
-            if (c == kk) mine = wd;                                          // GROUPS = 4: lanes c < 4 keep a word each
-        } else {
-            uint32_t wd = or_allreduce8(bits << (2u * c + 16u * (i & 1u)));  // 8 lanes x 2 bits in the lane group's half ...
-            wd |= (uint32_t)__shfl_xor((int)wd, 8, 64);                      // ... + the neighbouring group = mask word kk*4 + i/2
-            if (c == kk) mine = wd;                                          // GROUPS = 8: lanes (i even, c) keep a word each
-        }
-        bit += step;
-    });
-    const uint32_t flip = a.invert ? ~0u : 0u;
-    uint32_t* out = reinterpret_cast<uint32_t*>(a.mask) + blk * 32u;
-    if constexpr (sizeof(T) == 4) {
-        if (c < 4u) out[c * 8u + i] = mine ^ flip;
-    } else {
-        if ((i & 1u) == 0u) out[c * 4u + (i >> 1)] = mine ^ flip;
-    }
-}
-
-typedef hipError_t (*compare_wave_launch_t)(const CompareArgs&, unsigned w, int waves, hipStream_t);
-template <typename T, bool IS_EQ> hipError_t launch_compare_wave(const CompareArgs& a0, unsigned w, int waves, hipStream_t s)
-{
-    if (a0.n_blocks == 0) return hipSuccess;
-    if constexpr (sizeof(T) >= 4) {
-        CompareArgs a = a0;
-        const uint64_t n_tiles = (a.n_blocks + (WG / 64) - 1) / (WG / 64);
-        a.tiles_per_xcd = (n_tiles + 7) / 8;
-        if (a.tiles_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((k_compare_wave<T, IS_EQ>), dim3((unsigned)(a.tiles_per_xcd * 8)), dim3(WG), widths_lds_bytes<T>(waves), s, a, w);
-        return hipGetLastError();
-    } else {
-        return hipErrorInvalidValue;
-    }
-}
-// nullptr for the SWAR types (u8 / u16)
-template <typename T, bool IS_EQ> compare_wave_launch_t compare_wave_launcher();
 
 typedef hipError_t (*reduce_launch_t)(const ReduceArgs&, hipStream_t);
 

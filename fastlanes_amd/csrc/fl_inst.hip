@@ -80,17 +80,9 @@ template <> reduce_launch_t min_max_launcher<T>() { return &launch_block_min_max
 #elif FL_FAMILY == 11
 static constexpr CompareTable<T> t_compare_le = make_compare_table<T, false>(Ws{});
 template <> const CompareTable<T>& compare_table_impl<T, false>() { return t_compare_le; }
-template <> compare_wave_launch_t compare_wave_launcher<T, false>()
-{
-    if constexpr (sizeof(T) >= 4) return &launch_compare_wave<T, false>; else return nullptr;
-}
 #elif FL_FAMILY == 12
 static constexpr CompareTable<T> t_compare_eq = make_compare_table<T, true>(Ws{});
 template <> const CompareTable<T>& compare_table_impl<T, true>() { return t_compare_eq; }
-template <> compare_wave_launch_t compare_wave_launcher<T, true>()
-{
-    if constexpr (sizeof(T) >= 4) return &launch_compare_wave<T, true>; else return nullptr;
-}
 #else
 #error "FL_FAMILY must be 0..6 or 8..12"
 #endif

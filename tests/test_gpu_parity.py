@@ -1021,25 +1021,50 @@ def test_random_shapes_fuzz(fl, oracle, kernel_policy, policy):
         assert np.array_equal(to_np(got, ty), want), (ty, w, op, n, seed)
 
 
-@pytest.mark.parametrize("policy", [0, 1, 2])
-def test_unpack_compare_both_designs(fl, oracle, kernel_policy, policy):
-    """unpack_compare has two designs for u32 / u64 as well: the cell-column kernels and the wave-per-block form
-    (k_compare_wave).  Every width and all six predicates under the automatic choice and with each design forced."""
+def test_unpack_compare_u32_u64_every_width(fl, oracle):
+    """unpack_compare of u32 / u64 keeps the verdict bits in registers (v_cmp + v_addc_co per value, then an 8 x 8 butterfly between the
+    column threads of a block: fl_consume.hpp compare_block_butterfly): every width -- the per-(W, row) code differs -- and all six
+    predicates, constants inside, at and beyond the field's range; 13 blocks = one full and one partly filled wavefront, 1 block."""
     import operator
-    kernel_policy(policy)
     ops = {"==": operator.eq, "!=": operator.ne, "<": operator.lt, "<=": operator.le, ">": operator.gt, ">=": operator.ge}
     for ty in ("u32", "u64"):
         T = tbits(ty)
-        n = 13
         for w in range(T + 1):
-            pk = values(ty, n * packed_len(ty, w), 16000 + 64 * T + w)
-            un = oracle.batch("unpack", ty, w, pk, n_blocks=n)
-            dpk = to_dev(pk)
-            maxv = (1 << w) - 1 if w else 0
-            for k in sorted({0, maxv // 3, maxv, int(un[7]), (1 << T) - 1}):
-                for name, f in ops.items():
-                    got = fl.BitPacking.unpack_compare(w, dpk, name, k, n_blocks=n).cpu().numpy().view(np.uint8)
-                    assert np.array_equal(got, np.packbits(f(un, TYPES[ty][0](k)), bitorder="little")), (ty, w, name, k, policy)
+            for n in ((13, 1) if w in (0, 7, 17, T) else (13,)):
+                pk = values(ty, n * packed_len(ty, w), 16000 + 64 * T + w)
+                un = oracle.batch("unpack", ty, w, pk, n_blocks=n)
+                dpk = to_dev(pk)
+                maxv = (1 << w) - 1 if w else 0
+                for k in sorted({0, maxv // 3, maxv, min(maxv + 1, (1 << T) - 1), int(un[7]), (1 << T) - 1}):
+                    for name, f in ops.items():
+                        got = fl.BitPacking.unpack_compare(w, dpk, name, k, n_blocks=n).cpu().numpy().view(np.uint8)
+                        assert np.array_equal(got, np.packbits(f(un, TYPES[ty][0](k)), bitorder="little")), (ty, w, name, k, n)
+
+
+def test_consumers_write_into_the_callers_output(fl, oracle):
+    """unpack_compare / unpack_block_sums with output=: the caller's tensor is what gets written (and returned), guard elements on
+    both sides stay, and a tensor of the wrong size / element width / tier is refused before any launch."""
+    import torch
+    n, w = 21, 11
+    pk = values("u32", n * packed_len("u32", w), 4242)
+    un = oracle.batch("unpack", "u32", w, pk, n_blocks=n)
+    dpk = to_dev(pk)
+    big = torch.full((n * 32 + 64,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+    mask = big[32:32 + n * 32]
+    got = fl.BitPacking.unpack_compare(w, dpk, "<=", 700, output=mask)
+    assert got.data_ptr() == mask.data_ptr()
+    assert np.array_equal(mask.cpu().numpy().view(np.uint8), np.packbits(un <= 700, bitorder="little"))
+    assert bool((big[:32] == 0x5A5A5A5A).all()) and bool((big[32 + n * 32:] == 0x5A5A5A5A).all())
+    sums = torch.full((n + 2,), -1, dtype=torch.int64, device="cuda")
+    fl.BitPacking.unpack_block_sums(w, dpk, output=sums[1:1 + n])
+    assert np.array_equal(sums[1:1 + n].cpu().numpy().view(np.uint64), un.reshape(n, 1024).astype(np.uint64).sum(axis=1))
+    assert int(sums[0]) == -1 and int(sums[-1]) == -1
+    for bad in (torch.empty(n * 32 - 1, dtype=torch.int32, device="cuda"), torch.empty(n * 32, dtype=torch.int64, device="cuda"),
+                torch.empty(n * 32, dtype=torch.int32), torch.empty(2 * n * 32, dtype=torch.int32, device="cuda")[::2]):
+        with pytest.raises((ValueError, TypeError)):
+            fl.BitPacking.unpack_compare(w, dpk, "<=", 700, output=bad)
+    with pytest.raises(ValueError):
+        fl.BitPacking.unpack_block_sums(w, dpk, output=torch.empty(n + 1, dtype=torch.int64, device="cuda"))
 
 
 @pytest.mark.parametrize("ty", TYS)

@@ -91,9 +91,13 @@ def run(op, ty, w, gb, reps):
     elif op == "undelta_pack":
         f = lambda: fl.Delta.undelta_pack(w, src, bases, output=dst)
     elif op == "unpack_block_sums":
-        f = lambda: fl.BitPacking.unpack_block_sums(w, src)          # (allocates its own 8 B / block result)
+        sums = dst8[:n * 8].view(torch.int64)
+        f = lambda: fl.BitPacking.unpack_block_sums(w, src, output=sums)
     elif op == "unpack_compare":
-        f = lambda: fl.BitPacking.unpack_compare(w, src, "<", (1 << w) // 2)
+        # the mask is a thin WRITE stream inside a read stream: sharing a region of the device memory with the packed input costs
+        # it 10-15 % (profiles/exp_thin_stream_r03.txt); placed like every other output (fastlanes_amd/placement.py)
+        mask = dst8[:n * 128].view(torch.int32)
+        f = lambda: fl.BitPacking.unpack_compare(w, src, "<", (1 << w) // 2, output=mask)
     elif op == "block_min_max":
         f = lambda: fl.BitPacking.block_min_max(src)
     elif op == "undelta_pack_untranspose":
