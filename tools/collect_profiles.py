@@ -44,6 +44,14 @@ for log, dst in (("bench_under_rocprof.log", f"{RD}_bench_u32w7_under_rocprof.js
     if os.path.exists(src):
         with open(src) as f, open(os.path.join(P, dst), "w") as o:
             o.writelines(l for l in f if l.startswith('{"metric"'))
+# SQ / LDS counter passes (bash tools/gpu/sq_counters.sh tools/pmc_probe_r03.py gpurun_out/<round>), when the run made them
+if os.path.exists(os.path.join(G, "sq_counters.csv")):
+    cp(os.path.join(G, "sq_counters.csv"), f"{RD}_pmc_sq_counters.csv")
+    with open(os.path.join(G, "sq_derived.txt")) as f, open(os.path.join(P, f"{RD}_pmc_sq_derived.txt"), "w") as o:
+        o.write(f"# from profiles/{RD}_pmc_sq_counters.csv + the kernel trace of the same rocprofv3 pass (tools/gpu/sq_counters.sh "
+                "tools/pmc_probe_r03.py), the round's final kernels\n")
+        o.write(f.read())
+    print("copied", f"{RD}_pmc_sq_derived.txt")
 try:
     d = json.load(open(os.path.join(G, "bench_u32w7.json")))
     print("HEADLINE", d["value"], d["roofline"]["achieved"], d["roofline"]["frac"], "traffic", d["roofline"]["traffic"],

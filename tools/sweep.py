@@ -218,6 +218,13 @@ def main():
             t = sorted(ms)[len(ms) // 2]
             want = fl.BitPacking.unpack(w, pk_all)
             same = torch.equal(want.view(torch.int32), out_all.view(torch.int32))
+            # the yardstick: the same 640 000 blocks as ONE contiguous column through fl_u32_unpack, same buffers
+            ms_c = []
+            for _ in range(args.reps + 2):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); fl.BitPacking.unpack(w, pk_all, output=out_all); b.record(); b.synchronize()
+                ms_c.append(a.elapsed_time(b))
+            tc = sorted(ms_c[2:])[len(ms_c[2:]) // 2]
             nbytes = n_arr * nb * (128 * w + 4096)
             # the same arrays as one call each (what a chunk-at-a-time caller does today), through the raw C ABI
             lib = fl.load()
@@ -232,7 +239,7 @@ def main():
             t1 = a.elapsed_time(b)
             print(f"unpack_batch u32 W={w}: {n_arr} arrays x {nb} blocks in one launch {t:8.4f} ms  {n_arr * nb * 1024 / t / 1e6:7.1f} Gint/s  "
                   f"{nbytes / t / 1e6:7.1f} GB/s ({nbytes / t / 8e9:.3f} of peak)  {'== one big unpack' if same else 'MISMATCH'} | "
-                  f"one call per array: {t1:8.3f} ms  {n_arr * nb * 1024 / t1 / 1e6:7.1f} Gint/s  (x{t1 / t:.1f})", flush=True)
+                  f"the same blocks as one contiguous column, one call: {tc:8.4f} ms | one call per array: {t1:8.3f} ms  {n_arr * nb * 1024 / t1 / 1e6:7.1f} Gint/s  (x{t1 / t:.1f})", flush=True)
             del batch, pk_all, out_all, want
         return
     if args.cases == "refbench":
