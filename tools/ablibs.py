@@ -3,7 +3,7 @@
 before / after a kernel change, or with an experiment macro set differently (round 3: waves-per-SIMD caps of the fused
 consumers, occupancy of the narrow types' cell-column kernels).
     python tools/ablibs.py <rounds> <ops> <cases> lib_a.so lib_b.so ...
-      ops    comma list of: unpack pack undelta_pack compare sums
+      ops    comma list of: unpack pack undelta_pack undelta_pack_untranspose undelta compare sums   (undelta ignores the width)
       cases  comma list of type:width, e.g. u8:3,u8:6,u16:3   (or "consumers" = round 3's consumer sweep)
 GB/s of algorithmic bytes, median."""
 import ctypes
@@ -32,11 +32,12 @@ for ty, W in cases:
     tdt, T = TD[ty]
     esz = T // 8
     for op in OPS:
-        bpb = {"compare": 128 * W + 128, "sums": 128 * W + 8, "undelta_pack": 128 * W + 128 + 128 * T}.get(op, 128 * W + 128 * T)
+        bpb = {"compare": 128 * W + 128, "sums": 128 * W + 8, "undelta_pack": 128 * W + 128 + 128 * T,
+               "undelta_pack_untranspose": 128 * W + 128 + 128 * T, "undelta": 2 * 128 * T + 128}.get(op, 128 * W + 128 * T)
         n = int(8e9 / bpb)
         pk = rand_u8(n * 128 * W, 2, dev).view(tdt)
-        un = rand_u8(n * 128 * T, 3, dev).view(tdt) if op == "pack" else None
-        bases = rand_u8(n * 128, 4, dev).view(tdt) if op == "undelta_pack" else None
+        un = rand_u8(n * 128 * T, 3, dev).view(tdt) if op in ("pack", "undelta") else None
+        bases = rand_u8(n * 128, 4, dev).view(tdt) if op.startswith("undelta") else None
         out_bytes = {"compare": n * 128, "sums": n * 8, "pack": n * 128 * W}.get(op, n * 128 * T)
         out = torch.empty(max(out_bytes, 16) // 4, dtype=torch.int32, device=dev)
         fns = []
@@ -53,8 +54,11 @@ for ty, W in cases:
             elif op == "pack":
                 f = getattr(lib, f"fl_{ty}_pack"); f.argtypes = [U, P, P, Z, P]
                 fns.append(lambda f=f: f(W, un.data_ptr(), out.data_ptr(), n, None))
+            elif op == "undelta":
+                f = getattr(lib, f"fl_{ty}_undelta"); f.argtypes = [P, P, P, Z, P]
+                fns.append(lambda f=f: f(un.data_ptr(), bases.data_ptr(), out.data_ptr(), n, None))
             else:
-                f = getattr(lib, f"fl_{ty}_undelta_pack"); f.argtypes = [U, P, P, P, Z, P]
+                f = getattr(lib, f"fl_{ty}_{op}"); f.argtypes = [U, P, P, P, Z, P]
                 fns.append(lambda f=f: f(W, pk.data_ptr(), bases.data_ptr(), out.data_ptr(), n, None))
         ref, same = None, True
         for f in fns:
