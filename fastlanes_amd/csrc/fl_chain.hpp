@@ -17,8 +17,8 @@
 //
 // Between the stages a lane holds R = T/8 CONSECUTIVE logical rows of one cell column: lane (i = lane/8, c = lane%8)
 // owns rows R*i .. R*i+R-1 of column c (16/sizeof(T) FL lanes).  The per-FL-lane chain over the T rows (row order
-// matters: macros.rs:119, delta.rs:56-61) is then a local running value plus a scan of the 8 segment totals across lane
-// groups (undelta: scan_lane_groups, DPP + v_permlane*_swap), or the previous group's last row (delta).
+// matters: macros.rs:119, delta.rs:56-61) is then a local running value plus a 3-step exclusive scan of the 8 segment
+// totals across lane groups (undelta), or the previous group's last row (delta).
 //
 // The transposes need no shuffle network either: along an FL lane's row order the original positions
 // are consecutive, tau(index(r, l)) = lane_base(l) + r.  For the 32- and 64-bit types a 16-byte cell holds n = 4 / 2
@@ -123,51 +123,6 @@ template <typename T> __device__ __forceinline__ Cell<T> cell_from_group_below(c
         r[k] = src < 0 ? 0u : got;
     }
     return __builtin_bit_cast(Cell<T>, r);
-}
-
-// Inclusive scan (wrapping element-wise add) of one cell per lane GROUP over the 8 groups of a wavefront -- lane (i, c) holds group
-// i's value for column c and ends up with groups 0..i summed -- without the LDS: three levels, each one "the upper half takes
-// the lower half's last total":
-//   A  inside a 16-lane row (2 groups):      DPP row_shr:8                     -> group 2k+1 += group 2k
-//   B  inside a 32-lane half (2 rows):       v_permlane16_swap (row 0 -> row 1, row 2 -> row 3; gfx950)
-//   C  between the halves:                   v_permlane16_swap + v_permlane32_swap (lanes 0..31 -> 32..63; gfx950)
-// where "the lower half's last total" sits in the upper group of a row and is first copied to both groups of its row (DPP
-// row_shl:8 with the old value kept where the shift runs out of the row).  ~10 VALU operations per dword and no ds_bpermute
-// round trips (the Hillis-Steele form over ds_bpermute needed 4 dependent LDS exchanges per dword).
-template <typename T> __device__ __forceinline__ Cell<T> scan_lane_groups(Cell<T> v, unsigned lane)
-{
-    const bool odd_row = lane & 16u, upper_half = lane & 32u;
-    auto upper_group_to_both = [](const Cell<T>& x) {
-        u32x4 w = __builtin_bit_cast(u32x4, x), r;
-        for (int k = 0; k < 4; ++k) r[k] = (uint32_t)__builtin_amdgcn_update_dpp((int)w[k], (int)w[k], 0x108 /* row_shl:8 */, 0xF, 0xF, false);
-        return r;
-    };
-    {   // A
-        const u32x4 w = __builtin_bit_cast(u32x4, v);
-        u32x4 below;
-        for (int k = 0; k < 4; ++k) below[k] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[k], 0x118 /* row_shr:8 */, 0xF, 0xF, true);
-        v = v.add(__builtin_bit_cast(Cell<T>, below));
-    }
-    {   // B
-        const u32x4 t = upper_group_to_both(v);
-        u32x4 below;
-        for (int k = 0; k < 4; ++k) {
-            const auto sw = __builtin_amdgcn_permlane16_swap(t[k], t[k], false, false);   // [0]: rows (t0, t0, t2, t2)
-            below[k] = odd_row ? (uint32_t)sw[0] : 0u;
-        }
-        v = v.add(__builtin_bit_cast(Cell<T>, below));
-    }
-    {   // C
-        const u32x4 t = upper_group_to_both(v);
-        u32x4 below;
-        for (int k = 0; k < 4; ++k) {
-            const auto sw = __builtin_amdgcn_permlane16_swap(t[k], t[k], false, false);   // [1]: rows (t1, t1, t3, t3)
-            const auto hf = __builtin_amdgcn_permlane32_swap(sw[1], sw[1], false, false);  // [0]: halves (lower, lower)
-            below[k] = upper_half ? (uint32_t)hf[0] : 0u;
-        }
-        v = v.add(__builtin_bit_cast(Cell<T>, below));
-    }
-    return v;
 }
 
 // n x n element tile: in[j] = cell of row j (n lanes), out[e] = cell of lane e (n rows)  -- and back (the map is an involution)
@@ -283,12 +238,16 @@ __global__ __launch_bounds__(WG) void k_chain(ChainArgs a)
             prev = cur;
         });
     } else if constexpr (BODY == CHAIN_UNDELTA) {
-        // next = elem + prev; out[idx] = next; prev = next  (delta.rs:40-42,58-60): local running sum, then what the segments
-        // before this one add up to -- the inclusive scan of the segment totals over the 8 lane groups minus the own total (the
-        // arithmetic wraps, so the difference is exact) -- base entering at segment 0
+        // next = elem + prev; out[idx] = next; prev = next  (delta.rs:40-42,58-60): local running sum, then the exclusive
+        // scan of the segment totals over the 8 lane groups (Hillis-Steele, 3 steps), base entering at segment 0
         if (i == 0) x[0] = x[0].add(base);
         static_for<R - 1>([&](auto J) { x[decltype(J)::value + 1] = x[decltype(J)::value + 1].add(x[decltype(J)::value]); });
-        const Cell<T> excl = scan_lane_groups<T>(x[R - 1], lane).sub(x[R - 1]);
+        Cell<T> incl = x[R - 1];
+        static_for<3>([&](auto S) {
+            constexpr unsigned d = 1u << decltype(S)::value;
+            incl = incl.add(cell_from_group_below<T>(incl, lane, d));
+        });
+        const Cell<T> excl = cell_from_group_below<T>(incl, lane, 1);
         static_for<R>([&](auto J) { x[decltype(J)::value] = x[decltype(J)::value].add(excl); });
     }
     // the source image is dead once every lane has taken its rows (lanes re-use other lanes' cells below, except ROWS -> ROWS)
