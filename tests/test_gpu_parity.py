@@ -1379,3 +1379,90 @@ def test_bench_two_ranks_on_this_gpu(fl, backend):
         assert d["control_backend"] in ("gloo", "nccl")
         if d["control_backend"] == "gloo":
             assert d["control_fallback_reason"]
+
+
+# ---------------------------------------------------------------------------
+# Under load.  The per-(T, W) tests above run tens of blocks: a handful of wavefronts on an idle chip.  A kernel can be right
+# there and wrong with every CU busy (round 3: a register-only form of Delta's lane-group scan passed all of them and produced
+# 3 % wrong blocks, differently on every run, at 735 000 blocks).  So: every kernel family at a column size that fills the chip
+# many times over -- the result must be the same on two runs, and right (against the oracle) on the first / last blocks and a
+# seeded sample of the rest.
+# ---------------------------------------------------------------------------
+UNDER_LOAD_WIDTHS = {"u8": (3, 8), "u16": (9,), "u32": (7, 12, 20), "u64": (17, 20)}
+
+
+def _sample_blocks(n, k, seed):
+    rng = np.random.default_rng(seed)
+    return np.unique(np.concatenate([np.arange(4), np.arange(n - 4, n), rng.integers(0, n, size=k)]))
+
+
+def _gather(t, idx, per_block):
+    """blocks idx of a flat device tensor -> one contiguous numpy array"""
+    import torch
+    i = torch.from_numpy(idx).to(t.device)
+    return t.view(torch.uint8).view(-1, per_block * t.element_size())[i].contiguous().cpu().numpy().reshape(-1)      # (torch indexes uint8, not uint16/32/64)
+
+
+@pytest.mark.parametrize("ty", TYS)
+def test_every_kernel_family_under_load(fl, oracle, ty):
+    import torch
+    T = tbits(ty)
+    L = lanes(ty)
+    dt = TYPES[ty][0]
+    tdt = getattr(torch, str(np.dtype(dt)))
+    n = 600_000 if T <= 16 else 300_000
+    lib = fl.load()
+    idx = _sample_blocks(n, 120, 99 + T)
+
+    def filled(n_elems, seed):
+        t = torch.empty(n_elems, dtype=tdt, device="cuda:0")
+        assert lib.fl_fill_random(t.data_ptr(), (n_elems * (T // 8)) & ~7, seed, None) == 0
+        return t
+
+    def twice(f):
+        a = f().clone()
+        b = f()
+        torch.cuda.synchronize()
+        assert torch.equal(a.view(torch.uint8), b.view(torch.uint8)), "two runs of the same call differ"
+        return a
+
+    un = filled(n * 1024, 5)
+    bases = filled(n * L, 6)
+    refs = filled(n, 7)
+    un_s = _gather(un, idx, 1024).view(dt)
+    bases_s = _gather(bases, idx, L).view(dt)
+    refs_s = _gather(refs, idx, 1).view(dt)
+    k = len(idx)
+    # the width-free kernels
+    for name, call in (("delta", lambda: fl.Delta.delta(un, bases)), ("undelta", lambda: fl.Delta.undelta(un, bases)),
+                       ("transpose", lambda: fl.Transpose.transpose(un)), ("untranspose", lambda: fl.Transpose.untranspose(un))):
+        got = _gather(twice(call), idx, 1024).view(dt)
+        want = oracle.batch(name, ty, None, un_s, aux=bases_s) if "delta" in name else oracle.batch(name, ty, None, un_s)
+        assert np.array_equal(got, want), (ty, name)
+    mins, maxs = fl.BitPacking.block_min_max(un)
+    assert np.array_equal(to_np(mins, ty)[idx], un_s.reshape(k, 1024).min(axis=1)) and np.array_equal(to_np(maxs, ty)[idx], un_s.reshape(k, 1024).max(axis=1))
+    for w in UNDER_LOAD_WIDTHS[ty]:
+        pl = packed_len(ty, w)
+        pk = filled(n * pl, 11 + w)
+        pk_s = _gather(pk, idx, pl).view(dt)
+        unpacked_s = oracle.batch("unpack", ty, w, pk_s, n_blocks=k)
+        checks = (
+            ("unpack", lambda: fl.BitPacking.unpack(w, pk), 1024, lambda: unpacked_s),
+            ("pack", lambda: fl.BitPacking.pack(w, un), pl, lambda: oracle.batch("pack", ty, w, un_s)),
+            ("unfor_pack", lambda: fl.FoR.unfor_pack(w, pk, refs), 1024, lambda: oracle.batch("unfor_pack", ty, w, pk_s, aux=refs_s, n_blocks=k)),
+            ("for_pack", lambda: fl.FoR.for_pack(w, un, refs), pl, lambda: oracle.batch("for_pack", ty, w, un_s, aux=refs_s)),
+            ("undelta_pack", lambda: fl.Delta.undelta_pack(w, pk, bases), 1024, lambda: oracle.batch("undelta_pack", ty, w, pk_s, aux=bases_s, n_blocks=k)),
+            ("undelta_pack_untranspose", lambda: fl.Delta.undelta_pack_untranspose(w, pk, bases), 1024,
+             lambda: oracle.batch("untranspose", ty, None, oracle.batch("undelta_pack", ty, w, pk_s, aux=bases_s, n_blocks=k))),
+            ("transpose_delta_pack", lambda: fl.Delta.transpose_delta_pack(w, un, bases), pl,
+             lambda: oracle.batch("pack", ty, w, oracle.batch("delta", ty, None, oracle.batch("transpose", ty, None, un_s), aux=bases_s))),
+        )
+        for name, call, per_block, want in checks:
+            got = _gather(twice(call), idx, per_block).view(dt)
+            assert np.array_equal(got, want()), (ty, w, name)
+        kc = (1 << w) // 3
+        mask = twice(lambda: fl.BitPacking.unpack_compare(w, pk, "<=", kc))
+        assert np.array_equal(_gather(mask, idx, 32), np.packbits(unpacked_s <= dt(kc), bitorder="little")), (ty, w, "unpack_compare")
+        sums = twice(lambda: fl.BitPacking.unpack_block_sums(w, pk))
+        assert np.array_equal(sums.cpu().numpy().view(np.uint64)[idx], unpacked_s.reshape(k, 1024).astype(np.uint64).sum(axis=1)), (ty, w, "sums")
+        del pk
