@@ -323,14 +323,16 @@ class BitPacking:
         return out
 
     @staticmethod
-    def block_min_max(values):
-        """(mins, maxs) per 1024-value block of an unpacked column.  Device tier only."""
+    def block_min_max(values, output=None):
+        """(mins, maxs) per 1024-value block of an unpacked column -- written into `output` = (mins, maxs), two CUDA tensors of
+        n_blocks elements of the column's type, if given.  Device tier only."""
         import torch
         src = _Arg(values)
         ty = src.ty
         n = _blocks(src.n, 1024, "block_min_max input")
-        mins = torch.empty(n, dtype=src.x.dtype, device=src.x.device)
-        maxs = torch.empty(n, dtype=src.x.dtype, device=src.x.device)
+        mins, maxs = output if output is not None else (None, None)
+        mins = _consumer_out(src, mins, src.x.dtype, n, "block_min_max mins")
+        maxs = _consumer_out(src, maxs, src.x.dtype, n, "block_min_max maxs")
         with torch.cuda.device(src.x.device):
             _check(getattr(_lib.load(), f"fl_{ty}_block_min_max")(src.ptr, n, mins.data_ptr(), maxs.data_ptr(), _stream(src)),
                    f"fl_{ty}_block_min_max")

@@ -1065,6 +1065,39 @@ def test_consumers_write_into_the_callers_output(fl, oracle):
             fl.BitPacking.unpack_compare(w, dpk, "<=", 700, output=bad)
     with pytest.raises(ValueError):
         fl.BitPacking.unpack_block_sums(w, dpk, output=torch.empty(n + 1, dtype=torch.int64, device="cuda"))
+    dun = to_dev(un)
+    mm = torch.zeros(2 * n + 2, dtype=torch.uint32, device="cuda")
+    mins, maxs = fl.BitPacking.block_min_max(dun, output=(mm[1:1 + n], mm[1 + n:1 + 2 * n]))
+    assert mins.data_ptr() == mm[1:].data_ptr() and int(mm[0]) == 0 and int(mm[-1]) == 0
+    assert np.array_equal(to_np(mins, "u32"), un.reshape(n, 1024).min(axis=1)) and np.array_equal(to_np(maxs, "u32"), un.reshape(n, 1024).max(axis=1))
+    with pytest.raises(ValueError):
+        fl.BitPacking.block_min_max(dun, output=(mm[:n], mm[n:2 * n + 1]))
+
+
+def test_consumer_pair_places_the_output_by_probe(fl, oracle):
+    """placement.consumer_pair: one allocation; the input inside a run of 8-GiB granules of one class of memory, the output in a
+    granule of another class, classes found by the probe kernel (a small unpack_compare); the buffers it returns are usable as
+    they are."""
+    import torch
+    from fastlanes_amd import placement as pl
+    n, w = 1000, 9
+    in_bytes, out_bytes = n * 128 * w, n * 128
+    slab, src8, dst8, info = pl.consumer_pair(in_bytes, out_bytes, torch.device("cuda:0"), slab_bytes=64 << 30)
+    assert slab.numel() == 64 << 30 and src8.numel() == in_bytes and dst8.numel() == out_bytes
+    gi, go, classes = info["input_granule"], info["output_granule"], info["classes"]
+    assert len(classes) == 8 and set(classes) <= set("ABC.") and classes[0] == "A"
+    assert src8.data_ptr() == slab.data_ptr() + gi * pl.GRANULE_BYTES and dst8.data_ptr() == slab.data_ptr() + go * pl.GRANULE_BYTES and gi != go
+    if "B" in classes:                       # two classes inside 64 GiB: the usual case, not a law
+        assert info["input_one_class"] and classes[go] != classes[gi] and classes[go] != "."
+    pk = values("u32", n * packed_len("u32", w), 321)
+    src8.copy_(torch.from_numpy(pk.view(np.uint8)).to("cuda:0"))
+    got = fl.BitPacking.unpack_compare(w, src8.view(torch.uint32), ">", 100, output=dst8.view(torch.int32))
+    un = oracle.batch("unpack", "u32", w, pk, n_blocks=n)
+    assert np.array_equal(got.cpu().numpy().view(np.uint8), np.packbits(un > 100, bitorder="little"))
+    # an output too large for one granule: the zone layout of column_pair
+    slab2, s2, d2, info2 = pl.consumer_pair(1 << 20, 9 << 30, torch.device("cuda:0"))
+    assert info2["output_granule"] is None and d2.numel() == 9 << 30
+    del slab, slab2, s2, d2
 
 
 @pytest.mark.parametrize("ty", TYS)

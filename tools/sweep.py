@@ -66,7 +66,15 @@ def run(op, ty, w, gb, reps):
         out_bytes = n * 128 * T
     aux_bytes = n * 128 + n * esz          # Delta bases, then FoR references
     lib = fl.load()
-    if PLACEMENT == "zoned" and pl.fits(in_bytes, out_bytes, dev, aux_bytes):
+    placed = ""
+    if PLACEMENT == "zoned" and op in ("unpack_block_sums", "unpack_compare", "block_min_max"):
+        # a thin write stream: put it where a probe kernel says it does not share a memory class with the input
+        slab, src8, dst8, info = pl.consumer_pair(in_bytes, out_bytes, dev)
+        aux8 = torch.empty(0, dtype=torch.uint8, device=dev)
+        if info["output_granule"] is not None:
+            placed = (f"granules {info['classes']}: input from {info['input_granule']}"
+                      f"{'' if info['input_one_class'] else ' (SPANS classes)'}, output in {info['output_granule']}")
+    elif PLACEMENT == "zoned" and pl.fits(in_bytes, out_bytes, dev, aux_bytes):
         slab, src8, aux8, dst8 = pl.column_pair(in_bytes, out_bytes, dev, aux_bytes)
     else:
         slab = None
@@ -78,8 +86,8 @@ def run(op, ty, w, gb, reps):
             assert lib.fl_fill_random(t.data_ptr(), t.numel() & ~7, seed, None) == 0
     src = src8.view(TDT[ty])
     dst = dst8[:(out_bytes // esz) * esz].view(TDT[ty]) if op not in ("unpack_block_sums", "unpack_compare", "block_min_max") else None
-    bases = aux8[:n * 128].view(TDT[ty])
-    refs = aux8[n * 128:n * 128 + n * esz].view(TDT[ty])
+    bases = aux8[:n * 128].view(TDT[ty]) if aux8.numel() else None
+    refs = aux8[n * 128:n * 128 + n * esz].view(TDT[ty]) if aux8.numel() else None
     if op == "pack":
         f = lambda: fl.BitPacking.pack(w, src, output=dst)
     elif op == "unpack":
@@ -99,7 +107,8 @@ def run(op, ty, w, gb, reps):
         mask = dst8[:n * 128].view(torch.int32)
         f = lambda: fl.BitPacking.unpack_compare(w, src, "<", (1 << w) // 2, output=mask)
     elif op == "block_min_max":
-        f = lambda: fl.BitPacking.block_min_max(src)
+        mm = (dst8[:n * esz].view(TDT[ty]), dst8[n * esz:2 * n * esz].view(TDT[ty]))
+        f = lambda: fl.BitPacking.block_min_max(src, output=mm)
     elif op == "undelta_pack_untranspose":
         f = lambda: fl.Delta.undelta_pack_untranspose(w, src, bases, output=dst)
     elif op == "transpose_delta_pack":
@@ -122,7 +131,7 @@ def run(op, ty, w, gb, reps):
     med = ms[len(ms) // 2]
     gbps = n * bpb / med / 1e6
     return {"op": op, "ty": ty, "w": w, "n_blocks": n, "ms": round(med, 4), "GBps": round(gbps, 1),
-            "frac": round(gbps / 8000, 4), "Gints": round(n * 1024 / med / 1e6, 1)}
+            "frac": round(gbps / 8000, 4), "Gints": round(n * 1024 / med / 1e6, 1), "placed": placed}
 
 
 def host_tier(reps=3):
@@ -332,7 +341,7 @@ def main():
     for op, ty, w in cases:
         r = run(op, ty, w, args.gb, args.reps)
         out.append(r)
-        print(f"{op:13s} {ty:4s} W={w:<3d} n={r['n_blocks']:>9d} {r['ms']:9.4f} ms {r['GBps']:8.1f} GB/s {r['frac']:.3f} {r['Gints']:8.1f} Gint/s", flush=True)
+        print(f"{op:13s} {ty:4s} W={w:<3d} n={r['n_blocks']:>9d} {r['ms']:9.4f} ms {r['GBps']:8.1f} GB/s {r['frac']:.3f} {r['Gints']:8.1f} Gint/s" + (f"   [{r['placed']}]" if r.get("placed") else ""), flush=True)
         torch.cuda.empty_cache()
     if args.json:
         json.dump(out, open(args.json, "w"), indent=1)
