@@ -1424,7 +1424,7 @@ def test_bench_two_ranks_on_this_gpu(fl, backend):
 UNDER_LOAD_WIDTHS = {"u8": (3, 8), "u16": (9,), "u32": (7, 12, 20), "u64": (17, 20)}
 
 
-def _sample_blocks(n, k, seed):
+def _sampled_block_indices(n, k, seed):
     rng = np.random.default_rng(seed)
     return np.unique(np.concatenate([np.arange(4), np.arange(n - 4, n), rng.integers(0, n, size=k)]))
 
@@ -1445,7 +1445,7 @@ def test_every_kernel_family_under_load(fl, oracle, ty):
     tdt = getattr(torch, str(np.dtype(dt)))
     n = 600_000 if T <= 16 else 300_000
     lib = fl.load()
-    idx = _sample_blocks(n, 120, 99 + T)
+    idx = _sampled_block_indices(n, 120, 99 + T)
 
     def filled(n_elems, seed):
         t = torch.empty(n_elems, dtype=tdt, device="cuda:0")
