@@ -138,6 +138,22 @@ def granule_classes(slab, lib=None):
     return cls, rates
 
 
+def choose_granules(cls, rates, k):
+    """(first input granule, output granule, input_one_class) from granule_classes()' answer, for an input of k granules: the
+    first run of k granules of one class and a granule of another class; without such a run, offset 0 and the granule that probed
+    fastest against granule 0."""
+    n = len(cls)
+    start = next((i for i in range(n - k + 1) if cls[i] is not None and all(cls[j] == cls[i] for j in range(i, i + k))), None)
+    one_class = start is not None
+    start = start or 0
+    outside = [g for g in range(n) if not start <= g < start + k]
+    clean = [g for g in outside if cls[g] is not None and cls[g] != cls[start]] if one_class else []
+    # any granule of another class will do; prefer one whose rate against the input's class was measured, highest first
+    known = rates.get(cls[start] if clean else 0, {})
+    best = max(clean or outside, key=lambda g: known.get(g, 0.0))
+    return start, best, one_class
+
+
 def consumer_pair(in_bytes, out_bytes, device, slab_bytes=128 << 30):
     """(slab, input, output, info) for a read-dominated consumer, both carved from one torch allocation of at least `slab_bytes`:
     the input in the first run of 8-GiB granules that are all of ONE class of memory, the output at the start of a granule of
@@ -151,25 +167,13 @@ def consumer_pair(in_bytes, out_bytes, device, slab_bytes=128 << 30):
     k = max(1, (pad(in_bytes) + GRANULE_BYTES - 1) // GRANULE_BYTES)
     total = max(int(slab_bytes), (k + 2) * GRANULE_BYTES)
     total = (total + GRANULE_BYTES - 1) // GRANULE_BYTES * GRANULE_BYTES
-    n = total // GRANULE_BYTES
     if pad(out_bytes) > GRANULE_BYTES - (1 << 30):
         slab, src, _, dst = column_pair(in_bytes, out_bytes, device)
         return slab, src, dst, {"classes": "", "input_granule": 0, "output_granule": None, "input_one_class": None}
     with torch.cuda.device(device):
         slab = torch.empty(total, dtype=torch.uint8, device=device)
     cls, rates = granule_classes(slab, _lib.load())
-    start = next((i for i in range(n - k + 1) if cls[i] is not None and all(cls[j] == cls[i] for j in range(i, i + k))), None)
-    one_class = start is not None
-    start = start or 0
-    outside = [g for g in range(n) if not start <= g < start + k]
-    clean = [g for g in outside if cls[g] is not None and cls[g] != cls[start]] if one_class else []
-    if clean:
-        # any granule of another class will do; prefer one whose rate against the input's class was measured, highest first
-        known = rates.get(cls[start], {})
-        best = max(clean, key=lambda g: known.get(g, 0.0))
-    else:
-        known = rates.get(0, {})
-        best = max(outside, key=lambda g: known.get(g, 0.0))
+    start, best, one_class = choose_granules(cls, rates, k)
     i_off, o_off = start * GRANULE_BYTES, best * GRANULE_BYTES
     return slab, slab[i_off:i_off + in_bytes], slab[o_off:o_off + out_bytes], {
         "classes": "".join("." if c is None else "ABC"[c] for c in cls), "input_granule": start, "output_granule": best,

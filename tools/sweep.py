@@ -42,11 +42,37 @@ def bytes_per_block(op, ty, w):
     return 2 * 128 * T  # transpose / untranspose
 
 
+SLAB = {"t": None, "classes": None, "map": ""}
+
+
+def the_slab(nbytes):
+    """ONE allocation for the whole sweep, made before anything else and never freed: freeing and re-allocating per case hands the
+    cases alternately a fresh and a fragmented piece of the device memory (the class maps of profiles/r03_sweep_consume.txt
+    alternated between AAAABBBBBBBBACCC and ABBCAABCAACCCBCC), which showed up as every second row of a sweep being 5-8 % low --
+    undelta against delta, untranspose against transpose.  The memory classes of its 8-GiB granules are measured once."""
+    from fastlanes_amd import placement as pl
+    if SLAB["t"] is None or SLAB["t"].numel() < nbytes:
+        SLAB["t"] = None
+        torch.cuda.empty_cache()
+        free, _ = torch.cuda.mem_get_info(dev)
+        want = max(nbytes, 160 << 30)
+        size = min(want, free - (24 << 30)) // pl.GRANULE_BYTES * pl.GRANULE_BYTES
+        if size < nbytes:
+            return None
+        SLAB["t"] = torch.empty(size, dtype=torch.uint8, device=dev)
+        SLAB["classes"] = pl.granule_classes(SLAB["t"])
+        SLAB["map"] = "".join("." if c is None else "ABC"[c] for c in SLAB["classes"][0])
+        print(f"# one {size >> 30}-GiB allocation for every row; memory class of its 8-GiB granules: {SLAB['map']}", flush=True)
+    return SLAB["t"]
+
+
 def run(op, ty, w, gb, reps):
-    """One op on one column.  The column's input and output are carved from ONE allocation, the input at offset 0, the output
-    straddling a 64-GiB multiple (fastlanes_amd/placement.py: reads stay inside one 64-GiB zone of the device memory, writes are
-    split over two -- separately allocated tensors share a zone or not at the driver's whim, which moved every row of rounds 1-2
-    by up to 8 %); --placement separate restores that."""
+    """One op on one column.  The column's input and output are carved from the sweep's ONE allocation (the_slab): for the
+    materialising kernels the input at offset 0 and the output centred on the first 64-GiB multiple behind it (where a fresh
+    allocation's first boundary between memory classes lies: fastlanes_amd/placement.py); for the fused consumers the input in a
+    run of 8-GiB granules of one class and the thin output in a granule of another, by the measured class map.  Separately
+    allocated tensors share a class or not at the driver's whim, which moved every row of rounds 1-2 by up to 8 %;
+    --placement separate restores that."""
     from fastlanes_amd import placement as pl
     T = ESZ[ty] * 8
     esz = ESZ[ty]
@@ -67,17 +93,27 @@ def run(op, ty, w, gb, reps):
     aux_bytes = n * 128 + n * esz          # Delta bases, then FoR references
     lib = fl.load()
     placed = ""
-    if PLACEMENT == "zoned" and op in ("unpack_block_sums", "unpack_compare", "block_min_max"):
-        # a thin write stream: put it where a probe kernel says it does not share a memory class with the input
-        slab, src8, dst8, info = pl.consumer_pair(in_bytes, out_bytes, dev)
-        aux8 = torch.empty(0, dtype=torch.uint8, device=dev)
-        if info["output_granule"] is not None:
-            placed = (f"granules {info['classes']}: input from {info['input_granule']}"
-                      f"{'' if info['input_one_class'] else ' (SPANS classes)'}, output in {info['output_granule']}")
-    elif PLACEMENT == "zoned" and pl.fits(in_bytes, out_bytes, dev, aux_bytes):
-        slab, src8, aux8, dst8 = pl.column_pair(in_bytes, out_bytes, dev, aux_bytes)
+    consumer = op in ("unpack_block_sums", "unpack_compare", "block_min_max")
+    total = None
+    if PLACEMENT == "zoned":
+        try:
+            i_off, a_off, o_off, total = pl._layout(in_bytes, out_bytes, aux_bytes)
+        except ValueError:
+            total = None
+    slab = the_slab(max(total, (in_bytes // pl.GRANULE_BYTES + 3) * pl.GRANULE_BYTES)) if total is not None else None
+    if slab is not None and consumer and out_bytes <= pl.GRANULE_BYTES - (1 << 30):
+        # a thin write stream: input in a run of granules of one memory class, output in a granule of another (classes measured once
+        # on the sweep's slab: fastlanes_amd/placement.py)
+        cls, rates = SLAB["classes"]
+        k = max(1, (in_bytes + pl.GRANULE_BYTES - 1) // pl.GRANULE_BYTES)
+        start, best, one_class = pl.choose_granules(cls, rates, k)
+        src8 = slab[start * pl.GRANULE_BYTES:][:in_bytes]
+        dst8 = slab[best * pl.GRANULE_BYTES:][:out_bytes]
+        aux8 = slab[:0]
+        placed = f"input from granule {start}{'' if one_class else ' (SPANS classes)'}, output in {best} of {SLAB['map']}"
+    elif slab is not None:
+        src8, aux8, dst8 = slab[i_off:i_off + in_bytes], slab[a_off:a_off + aux_bytes], slab[o_off:o_off + out_bytes]
     else:
-        slab = None
         src8 = torch.empty(in_bytes, dtype=torch.uint8, device=dev)
         aux8 = torch.empty(aux_bytes, dtype=torch.uint8, device=dev)
         dst8 = torch.empty(out_bytes, dtype=torch.uint8, device=dev)
