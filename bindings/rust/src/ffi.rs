@@ -78,6 +78,10 @@ extern "C" {
     /// offsets[b] = sum_{i<b} 128 * widths[i] on the device (three small launches, no scratch memory)
     pub fn fl_widths_to_offsets(type_bits: u32, d_widths: *const u8, n_blocks: usize, d_offsets: *mut u64,
                                 d_total_bytes: *mut u64, d_err_flag: *mut u32, stream: *mut c_void) -> i32;
+    /// classes[g] = memory class (0, 1, 2; -1 = no clean answer) of every 8-GiB granule of a device allocation: decode outputs
+    /// are fastest across a class boundary, a mask or per-block sums fastest in another class than the packed input
+    /// (fastlanes_amd.h; synchronous and destructive: call it on a pool before the pool holds data)
+    pub fn fl_probe_memory_classes(slab: *mut c_void, slab_bytes: usize, classes: *mut i32, stream: *mut c_void) -> i32;
     /// frees the calling thread's cached host-tier context (stream, pinned + device staging buffers)
     pub fn fl_host_release();
     pub fn fl_status_string(status: i32) -> *const c_char;

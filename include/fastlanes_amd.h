@@ -105,6 +105,20 @@ void fl_host_release(void);
  * (FL_ERR_ALIGN otherwise).  Asynchronous on `stream`. */
 int fl_fill_random(void *dst, size_t n_bytes, uint64_t seed, void *stream);
 
+/* Where buffers live in HBM matters (not a reference function; DESIGN.md section 4, profiles/exp_region_map_r03.txt): every
+ * 8-GiB granule of a device allocation belongs to one of three CLASSES of memory (most likely the ranks of the HBM stacks), in
+ * an order the driver chooses; a thin write stream (a selection mask, per-block sums) next to a bulk read stream runs at 7.0 TB/s
+ * when the two lie in different classes and at 6.05 TB/s when they share one, and a decode kernel's output is fastest across a
+ * class boundary.  Nothing in an address tells the class; this measures it: classes[g] (HOST array, slab_bytes /
+ * FL_GRANULE_BYTES entries) = 0, 1 or 2, or -1 where the probe has no clean answer, for granule g of `slab` -- a small
+ * fl_u32_unpack_compare reads the start of a representative granule and writes its mask into the last GiB of every other one;
+ * the slow ones are of the representative's class.  SYNCHRONOUS (kernels are timed with events on `stream`; ~100 ms for a
+ * 128-GiB allocation) and DESTRUCTIVE (the first 5.2 GB of up to three granules and the last GiB of every granule are
+ * overwritten): call it on a pool before the pool holds data.  slab 16-byte aligned.  fastlanes_amd/placement.py is the same in
+ * Python, with the layout helpers on top. */
+#define FL_GRANULE_BYTES ((size_t)8 << 30)
+int fl_probe_memory_classes(void *slab, size_t slab_bytes, int *classes, void *stream);
+
 /*
  * Mixed-width columns (BASELINE.json config 5): block b has its own width widths[b].
  * The reference has no multi-block API; this is its caller loop

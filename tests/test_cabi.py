@@ -33,7 +33,7 @@ def _header_symbols():
 def test_every_declared_symbol_is_exported(lib):
     import fastlanes_amd
     syms = _header_symbols()
-    assert len(syms) == 4 * 34 + 15
+    assert len(syms) == 4 * 34 + 16
     assert sorted(fastlanes_amd.exported_symbols()) == syms
     for s in syms:
         assert hasattr(lib, s), s
@@ -87,6 +87,16 @@ def test_fill_random_validation_needs_no_gpu(lib):
     assert lib.fl_fill_random(p + 4, 64, 1, None) == 4          # FL_ERR_ALIGN: 8-byte words
     assert lib.fl_fill_random(p, 60, 1, None) == 4
     assert lib.fl_status_string(6) == b"block outside the packed column"
+
+
+def test_probe_memory_classes_validation_needs_no_gpu(lib):
+    import ctypes
+    out = (ctypes.c_int * 4)(7, 7, 7, 7)
+    assert lib.fl_probe_memory_classes(None, 0, out, None) == 0 and list(out) == [7, 7, 7, 7]          # no whole granule: nothing to say
+    assert lib.fl_probe_memory_classes(None, (8 << 30) - 1, out, None) == 0
+    assert lib.fl_probe_memory_classes(None, 16 << 30, out, None) == 3                                     # FL_ERR_NULL
+    assert lib.fl_probe_memory_classes(ctypes.c_void_p(0x1000), 16 << 30, None, None) == 3
+    assert lib.fl_probe_memory_classes(ctypes.c_void_p(0x1008), 16 << 30, out, None) == 4                # FL_ERR_ALIGN
 
 
 def test_python_mirror_raises_like_the_reference():
