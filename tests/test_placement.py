@@ -40,3 +40,12 @@ def test_consumer_granules_fragmented_memory():
     # granules the probe could not classify never count as "another class"
     start, best, one = pl.choose_granules(classes("AA..B."), {0: {2: 6900.0, 3: 6900.0, 4: 6900.0, 5: 6900.0}}, 2)
     assert (start, best, one) == (0, 4, True)
+
+
+def test_granule_size_is_the_c_abis():
+    """include/fastlanes_amd.h: FL_GRANULE_BYTES is what fl_probe_memory_classes counts its classes[] in"""
+    import os
+    import re
+    h = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "fastlanes_amd.h")).read()
+    m = re.search(r"#define FL_GRANULE_BYTES \(\(size_t\)(\d+) << (\d+)\)", h)
+    assert m and int(m.group(1)) << int(m.group(2)) == pl.GRANULE_BYTES == 8 * GiB
