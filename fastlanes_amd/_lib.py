@@ -66,12 +66,17 @@ def _signatures(ty):
     return dev
 
 
+# include/fastlanes_amd_internal.h: test / measurement hooks, not part of the stable ABI
+INTERNAL_SYMBOLS = ["fl_internal_set_kernel_policy", "fl_internal_get_kernel_policy", "fl_internal_probe_memory_classes"]
+
+
 def exported_symbols():
-    """Every symbol include/fastlanes_amd.h declares."""
+    """Every symbol include/fastlanes_amd.h and include/fastlanes_amd_internal.h declare."""
     names = ["fl_version", "fl_status_string", "fl_last_hip_error", "fl_packed_len",
              "fl_mixed_plan_create", "fl_mixed_plan_destroy", "fl_mixed_plan_n_blocks",
              "fl_mixed_plan_packed_bytes", "fl_mixed_plan_offsets", "fl_mixed_plan_widths",
-             "fl_widths_to_offsets", "fl_fill_random", "fl_probe_memory_classes", "fl_host_release", "fl_internal_set_kernel_policy", "fl_internal_get_kernel_policy"]
+             "fl_widths_to_offsets", "fl_fill_random", "fl_host_release"]
+    names += INTERNAL_SYMBOLS
     for ty in TYPES:
         names += [f"fl_{ty}_{m}" for m in _signatures(ty)]
     return names
@@ -116,8 +121,8 @@ def load():
     lib.fl_host_release.argtypes = []
     lib.fl_fill_random.restype = ctypes.c_int
     lib.fl_fill_random.argtypes = [_P, _Z, _Q, _P]
-    lib.fl_probe_memory_classes.restype = ctypes.c_int
-    lib.fl_probe_memory_classes.argtypes = [_P, _Z, ctypes.POINTER(ctypes.c_int), _P]
+    lib.fl_internal_probe_memory_classes.restype = ctypes.c_int
+    lib.fl_internal_probe_memory_classes.argtypes = [_P, _Z, ctypes.POINTER(ctypes.c_int), _P]
     lib.fl_widths_to_offsets.restype = ctypes.c_int
     lib.fl_widths_to_offsets.argtypes = [_U, _P, _Z, _P, _P, _P, _P]
     for ty in TYPES:

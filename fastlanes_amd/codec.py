@@ -605,6 +605,11 @@ class Batch:
                 raise ValueError(f"array {a}: the unpacked array must hold 1024 elements per block")
             if p.n != (u.n // 1024) * packed_len(self.ty, int(w[a])):
                 raise ValueError(f"array {a}: packed length {p.n} does not match {u.n // 1024} blocks of width {int(w[a])}")
+            # the kernel can only SKIP a misaligned array and raise FL_DEVERR_ALIGN (the pointers reach it through HBM), which a
+            # caller running with check=False would never see: here, where the pointers are still on the host, it is an error like
+            # at every other entry point (FL_ERR_ALIGN).  A width-0 array has no packed bytes: any pointer, or none, will do.
+            if u.ptr % 16 or (int(w[a]) != 0 and u.n and p.ptr % 16):
+                raise FastLanesError(4, f"fl_{self.ty}_unpack_batch (array {a}: device pointers must be 16-byte aligned)")
             nb.append(u.n // 1024)
         self.device = args_u[0].x.device
         self._keep = (list(packed), list(unpacked))                     # the pointer arrays below refer to these

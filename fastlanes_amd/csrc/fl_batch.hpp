@@ -4,9 +4,10 @@
 // (bitpacking.rs:109-129 inside the loop shape of benches/bitpacking.rs:80-97).  One device-tier call per chunk is
 // launch-bound (3 us per launch = 20 G ints/s at 64 blocks); fl_<ty>_unpack_widths needs the chunks in one allocation.  Here
 // the chunks are given as DEVICE ARRAYS OF POINTERS: array a has n_blocks[a] blocks of width widths[a] at packed[a] and
-// decodes to out[a].  Mapping: one wavefront per block, workgroup (array, 4 consecutive blocks of it); the grid is sized
-// from the caller's bound max_blocks >= n_blocks[a], workgroups past an array's end leave at once.  The block kernel is
-// the runtime-width wave-per-block one (fl_widths.hpp), fed a per-array argument block.
+// decodes to out[a].  Mapping: one wavefront per block (or per `bpw` consecutive blocks, all requested up front), workgroup
+// (array, 4 * bpw consecutive blocks of it); the grid is sized from the caller's bound max_blocks >= n_blocks[a], workgroups
+// past an array's end leave at once.  The block kernel is the runtime-width wave-per-block one (fl_widths.hpp), fed a
+// per-array argument block.
 #pragma once
 #include "fl_widths.hpp"
 
@@ -21,9 +22,31 @@ struct BatchArgs {
     const void* refs;            // FoR: references[a], one per ARRAY (ffor.rs:24-50); nullptr = plain BitPacking
     uint64_t n_arrays;
     uint64_t tiles_per_xcd;
-    unsigned tiles_per_array;    // ceil(max_blocks / 4)
+    unsigned tiles_per_array;    // ceil(max_blocks / (4 * bpw))
     unsigned max_blocks;         // the caller's bound on n_blocks[a]
+    unsigned bpw;                // consecutive blocks of the array per wavefront (>= 1); a workgroup takes 4 * bpw
+    unsigned prefetch;           // bpw > 1: all of a wavefront's blocks are requested up front by LDS-DMA (one image per block)
 };
+
+// Array `arr`'s descriptor -- block count, width, the two pointers -- as four INDEPENDENT loads through the vector memory
+// path, in flight together, ONE wait, then broadcast to SGPRs.  (Round 3 read n_blocks[arr] first, tested it, and only then
+// fetched the pointers and the width with scalar loads: three dependent memory round trips in front of a workgroup whose
+// whole job is 4 blocks; the batch ran 16 % behind the same blocks as one contiguous column, profiles/r03_sweep_batch.txt.)
+struct ArrayDesc { unsigned n_blocks, width; uint64_t packed, unpacked; };
+__device__ __forceinline__ ArrayDesc array_desc(const BatchArgs& b, unsigned arr)
+{
+    const unsigned i = arr + opaque_zero();
+    const unsigned nb = b.n_blocks[i];
+    const unsigned w = b.widths[i];
+    const uint64_t pk = reinterpret_cast<const uint64_t*>(b.packed)[i];
+    const uint64_t un = reinterpret_cast<const uint64_t*>(b.unpacked)[i];
+    ArrayDesc d;
+    d.n_blocks = (unsigned)__builtin_amdgcn_readfirstlane(nb);
+    d.width = (unsigned)__builtin_amdgcn_readfirstlane(w);
+    d.packed = wave_uniform_u64(pk);
+    d.unpacked = wave_uniform_u64(un);
+    return d;
+}
 
 template <typename T, bool PACK>
 __global__ __launch_bounds__(WG) void k_batch(BatchArgs b)
@@ -33,39 +56,49 @@ __global__ __launch_bounds__(WG) void k_batch(BatchArgs b)
     const uint64_t n_tiles = b.n_arrays * b.tiles_per_array;
     const uint64_t tile = (uint64_t)(blockIdx.x & 7u) * b.tiles_per_xcd + (blockIdx.x >> 3);
     if (tile >= n_tiles) return;
-    const uint64_t arr = tile / b.tiles_per_array;
+    // the launcher keeps the grid below 2^31 workgroups: 32-bit division (a 64-bit one is ~3x the scalar instructions)
+    const unsigned arr = (unsigned)tile / b.tiles_per_array;
+    const unsigned tile_in_arr = (unsigned)tile - arr * b.tiles_per_array;
     const unsigned tid = threadIdx.x;
     const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
-    const uint64_t blk = (tile - arr * b.tiles_per_array) * (WG / 64) + wave;
-    const unsigned nb = b.n_blocks[arr];
-    if (blk >= nb) return;
+    const unsigned first = (tile_in_arr * (WG / 64) + wave) * b.bpw;
+    const ArrayDesc d = array_desc(b, arr);
+    if (first >= d.n_blocks) return;
     // a bound that is too small would leave the array's tail undecoded without a trace: flag it (once per array)
-    if (blk == 0 && nb > b.max_blocks) raise_device_error(b.err_flag, DEVERR_BOUNDS, lane);
+    if (first == 0 && d.n_blocks > b.max_blocks) raise_device_error(b.err_flag, DEVERR_BOUNDS, lane);
     WidthsArgs a;
-    a.packed = b.packed[arr];
-    a.unpacked = b.unpacked[arr];
+    a.packed = reinterpret_cast<const char*>(d.packed);
+    a.unpacked = reinterpret_cast<char*>(d.unpacked);
     a.widths = nullptr;
     a.offsets = nullptr;
     a.err_flag = b.err_flag;
-    a.refs = b.refs ? static_cast<const char*>(b.refs) + arr * sizeof(T) : nullptr;   // every block of the array shares it
+    a.refs = b.refs ? static_cast<const char*>(b.refs) + (uint64_t)arr * sizeof(T) : nullptr;   // every block of the array shares it
     a.ref_stride = 0;
-    a.n_blocks = nb;
+    a.n_blocks = d.n_blocks;
     a.tiles_per_xcd = 0;
-    a.uniform_width = b.widths[arr];
-    a.bpw = 1;
+    a.uniform_width = d.width;
+    a.bpw = b.bpw;
     a.packed_bytes = 0;
-    a.prefetch = 0;
+    a.prefetch = b.prefetch;
     a.linear_map = 0;
     // per-array preconditions the host cannot check (the pointers live in HBM): 16-byte alignment; the width check
     // (bitpacking.rs:93,126) is the block kernel's
-    if (((reinterpret_cast<uintptr_t>(a.packed) | reinterpret_cast<uintptr_t>(a.unpacked)) & 15u) != 0 ||
-        !a.unpacked || (!a.packed && a.uniform_width != 0)) {
+    if (((d.packed | d.unpacked) & 15u) != 0 || !d.unpacked || (!d.packed && d.width != 0)) {
         raise_device_error(b.err_flag, DEVERR_ALIGN, lane);
         return;
     }
-    char* lds = lds_all + wave * G::BLOCK_BYTES;
-    if constexpr (PACK) pack_block_wave<T, RD_VGPR>(a, blk, lds, lane);
-    else unpack_block_wave<T, RD_AUTO>(a, blk, lds, lane);
+    const unsigned left = d.n_blocks - first;
+    const unsigned count = left < b.bpw ? left : b.bpw;
+    char* lds = lds_all + wave * G::BLOCK_BYTES * (b.prefetch ? b.bpw : 1u);
+    if (b.prefetch && count > 1 && !(PACK && a.refs)) {
+        if constexpr (PACK) pack_blocks_wave_prefetched<T>(a, first, count, lds, lane);
+        else unpack_blocks_wave_prefetched<T>(a, first, count, lds, lane);
+        return;
+    }
+    for (unsigned j = 0; j < count; ++j) {
+        if constexpr (PACK) pack_block_wave<T, RD_VGPR>(a, first + j, lds, lane);
+        else unpack_block_wave<T, RD_AUTO>(a, first + j, lds, lane);
+    }
 }
 
 typedef hipError_t (*batch_launch_t)(const BatchArgs&, uint32_t max_blocks, int waves, hipStream_t);
@@ -75,12 +108,18 @@ hipError_t launch_batch(const BatchArgs& b0, uint32_t max_blocks, int waves, hip
 {
     if (b0.n_arrays == 0 || max_blocks == 0) return hipSuccess;
     BatchArgs b = b0;
-    b.tiles_per_array = (max_blocks + (WG / 64) - 1) / (WG / 64);
+    if (b.bpw == 0) b.bpw = 1;
+    if (b.bpw < 2 || b.bpw > 16) b.prefetch = 0;
+    if (b.prefetch && (WG / 64) * b.bpw * WaveBlock<T>::BLOCK_BYTES > 64u * 1024u) b.prefetch = 0;   // images would not fit a workgroup's LDS
+    const uint64_t tile_blocks = (uint64_t)b.bpw * (WG / 64);
+    b.tiles_per_array = (unsigned)(((uint64_t)max_blocks + tile_blocks - 1) / tile_blocks);            // 64-bit: no wrap near 2^32
     b.max_blocks = max_blocks;
     const uint64_t n_tiles = b.n_arrays * b.tiles_per_array;
     b.tiles_per_xcd = (n_tiles + 7) / 8;
-    if (b.tiles_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_batch<T, PACK>), dim3((unsigned)(b.tiles_per_xcd * 8)), dim3(WG), widths_lds_bytes<T>(waves), s, b);
+    if (b.tiles_per_array == 0 || b.tiles_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;
+    const unsigned lds = widths_lds_bytes<T>(waves, b.prefetch ? b.bpw : 1u);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_batch<T, PACK>), dim3((unsigned)(b.tiles_per_xcd * 8)), dim3(WG), lds, s, b);
     return hipGetLastError();
 }
 

@@ -14,7 +14,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <new>
 #include <vector>
 
@@ -52,6 +54,37 @@ inline int hip_fail(hipError_t e)
 
 inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 
+// FL_CHECK_DEVICE=1 (fastlanes_amd.h "Threading and device selection"): before a device-tier launch, every pointer must be
+// memory the calling thread's CURRENT device can use -- its own HBM, managed memory, or pinned host memory -- and `stream` a
+// stream of that device; FL_ERR_DEVICE otherwise.  Off by default (one relaxed load per call): a raw kernel launch does not
+// check either, and hipPointerGetAttributes costs microseconds.
+inline bool device_check_enabled()
+{
+    static const bool on = [] { const char* e = getenv("FL_CHECK_DEVICE"); return e && e[0] && strcmp(e, "0") != 0; }();
+    return on;
+}
+int device_check(void* stream, std::initializer_list<const void*> ptrs)
+{
+    if (!device_check_enabled()) return FL_OK;
+    int cur = -1;
+    if (hipError_t e = hipGetDevice(&cur); e != hipSuccess) return hip_fail(e);
+    if (stream) {
+        int sdev = -1;
+        if (hipStreamGetDevice(static_cast<hipStream_t>(stream), &sdev) != hipSuccess) { (void)hipGetLastError(); return FL_ERR_DEVICE; }
+        if (sdev != cur) return FL_ERR_DEVICE;
+    }
+    for (const void* p : ptrs) {
+        if (!p) continue;                                   // NULL is judged (FL_ERR_NULL or allowed) by the entry point itself
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return FL_ERR_DEVICE; }   // plain host memory
+        const bool device_mem = at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged || at.type == hipMemoryTypeArray;
+        if (device_mem && at.type != hipMemoryTypeManaged && at.device != cur) return FL_ERR_DEVICE;
+        if (!device_mem && at.type != hipMemoryTypeHost) return FL_ERR_DEVICE;   // unregistered host memory
+    }
+    return FL_OK;
+}
+#define FL_DEVICE_TIER(stream, ...) do { if (const int rc_ = device_check(stream, {__VA_ARGS__})) return rc_; } while (0)
+
 template <typename T>
 int run_stream(stream_launch_t fn, const T* in, T* out, const void* aux, size_t aux_stride,
                size_t n_blocks, bool need_in, bool need_out, bool need_aux, void* stream)
@@ -59,6 +92,9 @@ int run_stream(stream_launch_t fn, const T* in, T* out, const void* aux, size_t 
     if (n_blocks == 0) return FL_OK;
     if ((need_in && !in) || (need_out && !out) || (need_aux && !aux)) return FL_ERR_NULL;
     if (misaligned(in) || misaligned(out)) return FL_ERR_ALIGN;
+    // a cell-column instance exists only where the dispatch table sends calls to it (fl_kernels.hpp: unpack_entry / pack_entry);
+    // chosen_waves() never selects a missing one, but a table / build mismatch must be an error, not a call through nullptr
+    if (!fn) return hip_fail(hipErrorInvalidDeviceFunction);
     StreamArgs a;
     a.in = reinterpret_cast<const u32x4*>(in);
     a.out = reinterpret_cast<u32x4*>(out);
@@ -162,8 +198,10 @@ int dev_undelta_pack(unsigned w, const T* in, const T* bases, T* out, size_t n, 
 {
     if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
     if (n && misaligned(bases)) return FL_ERR_ALIGN;
-    if (const int waves = chosen_waves(Elem<T>::BITS, w, WAVE_UNDELTA_PACK))
-        return run_chain<T>(OP_UNDELTA_PACK, waves, w, in, bases, out, n, s);
+    if (const int waves = chosen_waves(Elem<T>::BITS, w, WAVE_UNDELTA_PACK)) {
+        const int rc = run_chain<T>(OP_UNDELTA_PACK, waves, w, in, bases, out, n, s);
+        if (rc >= 0) return rc;                  // -1: no pipeline form of this op (cannot happen today): the cell-column kernel
+    }
     return run_stream<T>(unpack_table_impl<T, BODY_UNDELTA>().fn[w], in, out, bases, 0, n, w != 0, true, true, s);
 }
 template <typename T>
@@ -245,8 +283,10 @@ int dev_block_min_max(const T* in, size_t n, T* mins, T* maxs, void* s)
 template <typename T> int dev_delta(bool inverse, const T* in, const T* bases, T* out, size_t n, void* s)
 {
     if (n && misaligned(bases)) return FL_ERR_ALIGN;
-    if (const int waves = chosen_waves(Elem<T>::BITS, Elem<T>::BITS, inverse ? WAVE_UNDELTA : WAVE_DELTA))
-        return run_chain<T>(inverse ? OP_UNDELTA : OP_DELTA, waves, Elem<T>::BITS, in, bases, out, n, s);
+    if (const int waves = chosen_waves(Elem<T>::BITS, Elem<T>::BITS, inverse ? WAVE_UNDELTA : WAVE_DELTA)) {
+        const int rc = run_chain<T>(inverse ? OP_UNDELTA : OP_DELTA, waves, Elem<T>::BITS, in, bases, out, n, s);
+        if (rc >= 0) return rc;
+    }
     return run_stream<T>(delta_launcher<T>(inverse), in, out, bases, 0, n, true, true, true, s);
 }
 template <typename T> int dev_transpose(bool inverse, const T* in, T* out, size_t n, void* s)
@@ -489,6 +529,7 @@ int run_batch(bool pack, const void* const* packed, void* const* unpacked, const
 {
     if (n_arrays == 0 || max_blocks == 0) return FL_OK;
     if (!packed || !unpacked || !widths || !n_blocks || (with_refs && !refs)) return FL_ERR_NULL;
+    if (max_blocks > BATCH_MAX_BLOCKS) return FL_ERR_INDEX;       // 2^30 blocks = 2^40 values in ONE array: a bound nobody means
     BatchArgs b;
     b.packed = reinterpret_cast<const char* const*>(packed);
     b.unpacked = reinterpret_cast<char* const*>(unpacked);
@@ -500,7 +541,13 @@ int run_batch(bool pack, const void* const* packed, void* const* unpacked, const
     b.tiles_per_xcd = 0;
     b.tiles_per_array = 0;
     b.max_blocks = max_blocks;
-    hipError_t e = batch_launcher<T>(pack)(b, max_blocks, mixed_waves(Elem<T>::BITS, pack), static_cast<hipStream_t>(stream));
+    b.bpw = batch_blocks_per_wave(Elem<T>::BITS, pack);
+    b.prefetch = b.bpw > 1;
+    int waves = batch_waves(Elem<T>::BITS, pack);
+    const int pol = g_kernel_policy.load(std::memory_order_relaxed);       // A/B tools: as for the mixed-width kernels (run_widths)
+    if ((pol & 0xff) == 2 && ((pol >> 8) & 0xff)) waves = (pol >> 8) & 0xff;
+    if ((pol & 0xff) == 2 && ((pol >> 16) & 0xff)) { b.bpw = (pol >> 16) & 0xff; b.prefetch = (pol >> 24) & 1; }
+    hipError_t e = batch_launcher<T>(pack)(b, max_blocks, waves, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
 
@@ -524,6 +571,7 @@ int fl_widths_to_offsets(unsigned type_bits, const uint8_t* widths, size_t n_blo
 {
     if (type_bits != 8 && type_bits != 16 && type_bits != 32 && type_bits != 64) return FL_ERR_WIDTH;
     if (n_blocks && (!widths || !offsets)) return FL_ERR_NULL;
+    FL_DEVICE_TIER(stream, widths, offsets, total_bytes, err_flag);
     ScanArgs a{widths, offsets, total_bytes, err_flag, n_blocks, type_bits};
     hipError_t e = launch_widths_to_offsets(a, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? FL_OK : hip_fail(e);
@@ -567,13 +615,14 @@ int fl_fill_random(void* dst, size_t n_bytes, uint64_t seed, void* stream)
     if (n_bytes == 0) return FL_OK;
     if (!dst) return FL_ERR_NULL;
     if ((reinterpret_cast<uintptr_t>(dst) & 7u) || (n_bytes & 7u)) return FL_ERR_ALIGN;
+    FL_DEVICE_TIER(stream, dst);
     hipError_t e = launch_fill_random(static_cast<uint64_t*>(dst), n_bytes / 8, seed, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
 
-int fl_probe_memory_classes(void* slab, size_t slab_bytes, int* classes, void* stream)
+int fl_internal_probe_memory_classes(void* slab, size_t slab_bytes, int* classes, void* stream)
 {
-    const size_t n_granules = slab_bytes / FL_GRANULE_BYTES;
+    const size_t n_granules = slab_bytes / FL_INTERNAL_GRANULE_BYTES;
     if (n_granules == 0) return FL_OK;
     if (!slab || !classes) return FL_ERR_NULL;
     if (misaligned(slab)) return FL_ERR_ALIGN;
@@ -590,8 +639,8 @@ int fl_probe_memory_classes(void* slab, size_t slab_bytes, int* classes, void* s
     int rc = e == hipSuccess ? FL_OK : hip_fail(e);
     // milliseconds of the probe reading granule gi and writing into granule gm: median of 3 after one untimed launch
     auto probe_ms = [&](size_t gi, size_t gm, float& ms) -> int {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(base + gi * FL_GRANULE_BYTES);
-        uint32_t* mask = reinterpret_cast<uint32_t*>(base + gm * FL_GRANULE_BYTES + FL_GRANULE_BYTES - ((size_t)1 << 30));
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(base + gi * FL_INTERNAL_GRANULE_BYTES);
+        uint32_t* mask = reinterpret_cast<uint32_t*>(base + gm * FL_INTERNAL_GRANULE_BYTES + FL_INTERNAL_GRANULE_BYTES - ((size_t)1 << 30));
         float t[3] = {0.f, 0.f, 0.f};
         for (int i = -1; i < 3; ++i) {
             hipError_t h = hipEventRecord(t0, s);
@@ -616,7 +665,7 @@ int fl_probe_memory_classes(void* slab, size_t slab_bytes, int* classes, void* s
         while (rep < n_granules && classes[rep] != -1) ++rep;
         if (rep == n_granules) break;
         classes[rep] = c;
-        rc = fl_fill_random(base + rep * FL_GRANULE_BYTES, PROBE_BLOCKS * 128 * PROBE_WIDTH, 17 + rep, s);   // full-entropy probe input
+        rc = fl_fill_random(base + rep * FL_INTERNAL_GRANULE_BYTES, PROBE_BLOCKS * 128 * PROBE_WIDTH, 17 + rep, s);   // full-entropy probe input
         float slowest = 0.f, fastest = 1e30f;
         size_t others = 0;
         for (size_t g = 0; g < n_granules && rc == FL_OK; ++g) {
@@ -662,9 +711,9 @@ void fl_internal_set_kernel_policy(int policy)
 int fl_internal_get_kernel_policy(void) { return g_kernel_policy.load(std::memory_order_relaxed); }
 
 #ifdef FL_ALL_CELL_COLUMN
-const char* fl_version(void) { return "fastlanes_amd 0.3.0 (gfx950; wire format of spiraldb/fastlanes 0.1.8; FULL build: every cell-column instance, for A/B sweeps)"; }
+const char* fl_version(void) { return "fastlanes_amd 0.4.0 (gfx950; wire format of spiraldb/fastlanes 0.1.8; FULL build: every cell-column instance, for A/B sweeps)"; }
 #else
-const char* fl_version(void) { return "fastlanes_amd 0.3.0 (gfx950; wire format of spiraldb/fastlanes 0.1.8)"; }
+const char* fl_version(void) { return "fastlanes_amd 0.4.0 (gfx950; wire format of spiraldb/fastlanes 0.1.8)"; }
 #endif
 
 const char* fl_status_string(int status)
@@ -677,6 +726,7 @@ const char* fl_status_string(int status)
     case FL_ERR_ALIGN: return "device pointer (or offset / size) not aligned as required";
     case FL_ERR_HIP: return "HIP runtime error";
     case FL_ERR_BOUNDS: return "block outside the packed column";
+    case FL_ERR_DEVICE: return "pointer or stream does not belong to the current device (FL_CHECK_DEVICE)";
     default: return "unknown status";
     }
 }
@@ -691,52 +741,52 @@ size_t fl_packed_len(unsigned type_bits, unsigned width)
 }
 
 #define FL_DEFINE_TYPE(T, S)                                                                              \
-    int fl_##S##_pack(unsigned w, const T* in, T* out, size_t n, void* s) { return dev_pack<T>(w, in, out, n, s); } \
-    int fl_##S##_unpack(unsigned w, const T* in, T* out, size_t n, void* s) { return dev_unpack<T>(w, in, out, n, s); } \
+    int fl_##S##_pack(unsigned w, const T* in, T* out, size_t n, void* s) { FL_DEVICE_TIER(s, in, out); return dev_pack<T>(w, in, out, n, s); } \
+    int fl_##S##_unpack(unsigned w, const T* in, T* out, size_t n, void* s) { FL_DEVICE_TIER(s, in, out); return dev_unpack<T>(w, in, out, n, s); } \
     int fl_##S##_unpack_single(unsigned w, const T* pk, size_t n, const uint64_t* idx, size_t ni, T* out,  \
                                uint32_t* ef, void* s)                                                     \
-    { return dev_unpack_single<T>(w, pk, n, idx, ni, out, ef, s); }                                       \
+    { FL_DEVICE_TIER(s, pk, idx, out, ef); return dev_unpack_single<T>(w, pk, n, idx, ni, out, ef, s); }                                       \
     int fl_##S##_for_pack(unsigned w, const T* in, const T* r, size_t rs, T* out, size_t n, void* s)      \
-    { return dev_for_pack<T>(w, in, r, rs, out, n, s); }                                                  \
+    { FL_DEVICE_TIER(s, in, r, out); return dev_for_pack<T>(w, in, r, rs, out, n, s); }                                                  \
     int fl_##S##_unfor_pack(unsigned w, const T* in, const T* r, size_t rs, T* out, size_t n, void* s)    \
-    { return dev_unfor_pack<T>(w, in, r, rs, out, n, s); }                                                \
-    int fl_##S##_delta(const T* in, const T* b, T* out, size_t n, void* s) { return dev_delta<T>(false, in, b, out, n, s); } \
-    int fl_##S##_undelta(const T* in, const T* b, T* out, size_t n, void* s) { return dev_delta<T>(true, in, b, out, n, s); } \
+    { FL_DEVICE_TIER(s, in, r, out); return dev_unfor_pack<T>(w, in, r, rs, out, n, s); }                                                \
+    int fl_##S##_delta(const T* in, const T* b, T* out, size_t n, void* s) { FL_DEVICE_TIER(s, in, b, out); return dev_delta<T>(false, in, b, out, n, s); } \
+    int fl_##S##_undelta(const T* in, const T* b, T* out, size_t n, void* s) { FL_DEVICE_TIER(s, in, b, out); return dev_delta<T>(true, in, b, out, n, s); } \
     int fl_##S##_undelta_pack(unsigned w, const T* in, const T* b, T* out, size_t n, void* s)             \
-    { return dev_undelta_pack<T>(w, in, b, out, n, s); }                                                  \
+    { FL_DEVICE_TIER(s, in, b, out); return dev_undelta_pack<T>(w, in, b, out, n, s); }                                                  \
     int fl_##S##_undelta_pack_untranspose(unsigned w, const T* in, const T* b, T* out, size_t n, void* s) \
-    { return dev_undelta_pack_untranspose<T>(w, in, b, out, n, s); }                                      \
+    { FL_DEVICE_TIER(s, in, b, out); return dev_undelta_pack_untranspose<T>(w, in, b, out, n, s); }                                      \
     int fl_##S##_transpose_delta_pack(unsigned w, const T* in, const T* b, T* out, size_t n, void* s)     \
-    { return dev_transpose_delta_pack<T>(w, in, b, out, n, s); }                                          \
+    { FL_DEVICE_TIER(s, in, b, out); return dev_transpose_delta_pack<T>(w, in, b, out, n, s); }                                          \
     int fl_##S##_unpack_block_sums(unsigned w, const T* in, size_t n, uint64_t* sums, void* s)           \
-    { return dev_unpack_block_sums<T>(w, in, n, sums, s); }                                               \
+    { FL_DEVICE_TIER(s, in, sums); return dev_unpack_block_sums<T>(w, in, n, sums, s); }                                               \
     int fl_##S##_unpack_compare(unsigned w, const T* in, int op, T k, size_t n, uint32_t* mask, void* s)  \
-    { return dev_unpack_compare<T>(w, in, op, k, n, mask, s); }                                           \
+    { FL_DEVICE_TIER(s, in, mask); return dev_unpack_compare<T>(w, in, op, k, n, mask, s); }                                           \
     int fl_##S##_block_min_max(const T* in, size_t n, T* mins, T* maxs, void* s)                          \
-    { return dev_block_min_max<T>(in, n, mins, maxs, s); }                                                \
-    int fl_##S##_transpose(const T* in, T* out, size_t n, void* s) { return dev_transpose<T>(false, in, out, n, s); } \
-    int fl_##S##_untranspose(const T* in, T* out, size_t n, void* s) { return dev_transpose<T>(true, in, out, n, s); } \
-    int fl_##S##_unpack_mixed(const fl_mixed_plan* p, const T* pk, T* out, void* s) { return run_mixed<T>(false, p, pk, out, s); } \
-    int fl_##S##_pack_mixed(const fl_mixed_plan* p, const T* in, T* pk, void* s) { return run_mixed<T>(true, p, pk, const_cast<T*>(in), s); } \
+    { FL_DEVICE_TIER(s, in, mins, maxs); return dev_block_min_max<T>(in, n, mins, maxs, s); }                                                \
+    int fl_##S##_transpose(const T* in, T* out, size_t n, void* s) { FL_DEVICE_TIER(s, in, out); return dev_transpose<T>(false, in, out, n, s); } \
+    int fl_##S##_untranspose(const T* in, T* out, size_t n, void* s) { FL_DEVICE_TIER(s, in, out); return dev_transpose<T>(true, in, out, n, s); } \
+    int fl_##S##_unpack_mixed(const fl_mixed_plan* p, const T* pk, T* out, void* s) { FL_DEVICE_TIER(s, pk, out); return run_mixed<T>(false, p, pk, out, s); } \
+    int fl_##S##_pack_mixed(const fl_mixed_plan* p, const T* in, T* pk, void* s) { FL_DEVICE_TIER(s, in, pk); return run_mixed<T>(true, p, pk, const_cast<T*>(in), s); } \
     int fl_##S##_unpack_widths(const uint8_t* w, const uint64_t* o, const T* pk, size_t pb, T* out, size_t n, uint32_t* ef, void* s) \
-    { return run_widths<T>(false, w, o, pk, pb, out, n, ef, s); }                                         \
+    { FL_DEVICE_TIER(s, w, o, pk, out, ef); return run_widths<T>(false, w, o, pk, pb, out, n, ef, s); }                                         \
     int fl_##S##_pack_widths(const uint8_t* w, const uint64_t* o, const T* in, T* pk, size_t pb, size_t n, uint32_t* ef, void* s) \
-    { return run_widths<T>(true, w, o, pk, pb, const_cast<T*>(in), n, ef, s); }                           \
+    { FL_DEVICE_TIER(s, w, o, in, pk, ef); return run_widths<T>(true, w, o, pk, pb, const_cast<T*>(in), n, ef, s); }                           \
     int fl_##S##_unpack_batch(const T* const* pk, T* const* out, const uint8_t* w, const uint32_t* nb, size_t na, uint32_t mb, \
                               uint32_t* ef, void* s)                                                      \
-    { return run_batch<T>(false, reinterpret_cast<const void* const*>(pk), reinterpret_cast<void* const*>(out), w, nullptr, false, nb, na, mb, ef, s); } \
+    { FL_DEVICE_TIER(s, pk, out, w, nb, ef); return run_batch<T>(false, reinterpret_cast<const void* const*>(pk), reinterpret_cast<void* const*>(out), w, nullptr, false, nb, na, mb, ef, s); } \
     int fl_##S##_unfor_pack_batch(const T* const* pk, T* const* out, const uint8_t* w, const T* refs, const uint32_t* nb, size_t na, \
                                   uint32_t mb, uint32_t* ef, void* s)                                     \
-    { return run_batch<T>(false, reinterpret_cast<const void* const*>(pk), reinterpret_cast<void* const*>(out), w, refs, true, nb, na, mb, ef, s); } \
+    { FL_DEVICE_TIER(s, pk, out, w, refs, nb, ef); return run_batch<T>(false, reinterpret_cast<const void* const*>(pk), reinterpret_cast<void* const*>(out), w, refs, true, nb, na, mb, ef, s); } \
     int fl_##S##_for_pack_batch(const T* const* in, T* const* pk, const uint8_t* w, const T* refs, const uint32_t* nb, size_t na, \
                                 uint32_t mb, uint32_t* ef, void* s)                                       \
-    { return run_batch<T>(true, reinterpret_cast<const void* const*>(pk), (void* const*)in, w, refs, true, nb, na, mb, ef, s); } \
+    { FL_DEVICE_TIER(s, pk, in, w, refs, nb, ef); return run_batch<T>(true, reinterpret_cast<const void* const*>(pk), (void* const*)in, w, refs, true, nb, na, mb, ef, s); } \
     int fl_##S##_pack_batch(const T* const* in, T* const* pk, const uint8_t* w, const uint32_t* nb, size_t na, uint32_t mb, \
                             uint32_t* ef, void* s)                                                        \
-    { return run_batch<T>(true, reinterpret_cast<const void* const*>(pk), (void* const*)in, w, nullptr, false, nb, na, mb, ef, s); } \
+    { FL_DEVICE_TIER(s, pk, in, w, nb, ef); return run_batch<T>(true, reinterpret_cast<const void* const*>(pk), (void* const*)in, w, nullptr, false, nb, na, mb, ef, s); } \
     int fl_##S##_unpack_single_widths(const uint8_t* w, const uint64_t* o, const T* pk, size_t pb, size_t n, const uint64_t* idx, \
                                       size_t ni, T* out, uint32_t* ef, void* s)                           \
-    { return dev_unpack_single_widths<T>(w, o, pk, pb, n, idx, ni, out, ef, s); }                         \
+    { FL_DEVICE_TIER(s, w, o, pk, idx, out, ef); return dev_unpack_single_widths<T>(w, o, pk, pb, n, idx, ni, out, ef, s); }                         \
     int fl_##S##_pack_host(unsigned w, const T* in, T* out, size_t n)                                     \
     {                                                                                                     \
         if (w > sizeof(T) * 8) return FL_ERR_WIDTH;                                                       \

@@ -180,12 +180,42 @@ struct CompareArgs {
     uint64_t tiles_per_xcd;
 };
 
+// u8 / u16 compare SWAR-wise: all elements of a 32-bit word at once, the verdict of an element landing in ONE bit of its
+// field (bit G of every T-bit element).  squeeze_bit<T, G> gathers those bits of the cell's four words into PER_CELL
+// contiguous bits, element e's verdict at bit e.  Round 4: these kernels are VALU-bound at the narrow widths
+// (profiles/r03_pmc_sq_derived.txt: 1.06 of the nominal issue rate at u16 W=3) and a third of their instructions squeezed
+// verdict bits together with shifts, ORs and (u8) a quarter-rate 32-bit multiply.  v_dot4_u32_u8 does it instead: a byte that
+// is (1 << g) or 0 times a weight 2^e, four bytes per instruction, accumulating -- sum = (the verdict bits) << g.
+//   u16: one v_perm_b32 picks the byte holding bit G of each of four elements (two words), one v_and isolates the bit, one
+//        dot4 per four elements, one shift per row: 7 operations per row of 8 elements (before: ~10, plus a v_and per word)
+//   u8 : one v_and + one dot4 per word, two accumulators (the weights are bytes: 2^0 .. 2^7), shift + v_lshl_or: 10 per row of
+//        16 elements (before: 16, four of them quarter-rate multiplies)
+// Whatever else the words hold is ignored.
+template <typename T, int G>
+__device__ __forceinline__ uint32_t squeeze_bit(const uint32_t (&t)[4])
+{
+    static_assert(sizeof(T) <= 2 && G >= 0 && G < (int)(sizeof(T) * 8), "");
+    constexpr int b = G & 7;
+    constexpr uint32_t m = 0x01010101u << b;
+    if constexpr (sizeof(T) == 2) {
+        constexpr uint32_t sel = G >= 8 ? 0x07050301u : 0x06040200u;    // bytes 1 / 3 or 0 / 2 of the two words
+        const uint32_t lo4 = __builtin_amdgcn_perm(t[1], t[0], sel) & m;   // elements 0, 1, 2, 3
+        const uint32_t hi4 = __builtin_amdgcn_perm(t[3], t[2], sel) & m;   // elements 4, 5, 6, 7
+        uint32_t acc = __builtin_amdgcn_udot4(lo4, 0x08040201u, 0u, false);
+        acc = __builtin_amdgcn_udot4(hi4, 0x80402010u, acc, false);
+        return b ? acc >> b : acc;
+    } else {
+        uint32_t lo = __builtin_amdgcn_udot4(t[0] & m, 0x08040201u, 0u, false);
+        lo = __builtin_amdgcn_udot4(t[1] & m, 0x80402010u, lo, false);
+        uint32_t hi = __builtin_amdgcn_udot4(t[2] & m, 0x08040201u, 0u, false);
+        hi = __builtin_amdgcn_udot4(t[3] & m, 0x80402010u, hi, false);
+        return (b ? lo >> b : lo) | (hi << (8 - b));
+    }
+}
+
 // Per-row predicate bits of one cell column: bit e of the result = cmp(element e of the cell, k), e < PER_CELL.
-//   u64 / u32 : one compare per element.
-//   u16 / u8  : SWAR -- all elements of a 32-bit word are compared at once, the verdicts land in the top bit of
-//               each element field (H), and the H bits of the cell's four words are squeezed together
-//               (per-element extraction cost ~4.5 VALU operations per value and capped these kernels at 0.47 of the
-//               HBM peak; this is ~2.5).
+//   u64 / u32 : one compare per element (only used by the W = 0 form; compare_block_butterfly is their kernel).
+//   u16 / u8  : SWAR -- the verdicts land in the top bit of each element and are squeezed together.
 template <typename T, int W, bool IS_EQ>
 __device__ __forceinline__ uint32_t row_predicate_bits(const Cell<T>& v, T k)
 {
@@ -207,70 +237,64 @@ __device__ __forceinline__ uint32_t row_predicate_bits(const Cell<T>& v, T k)
             const uint32_t x = v.x[i];
             if constexpr (IS_EQ) {
                 const uint32_t y = x ^ kr;
-                p[i] = ~(((y & L) + L) | y) & H;                           // field == 0
+                p[i] = ~(((y & L) + L) | y);                               // top bit: field == 0
             } else if constexpr (W < (int)(sizeof(T) * 8)) {
                 // elements are < 2^W <= 2^(T-1): their top bit is clear, so x <= k  <=>  k's top bit | low(k) >= x
-                p[i] = (((kr | H) - x) | kr) & H;
+                p[i] = ((kr | H) - x) | kr;
             } else {
                 const uint32_t ge_low = (kr | H) - (x & L);                // H bit: low(k) >= low(x), no borrow across fields
-                p[i] = ((~x & kr) | (~(x ^ kr) & ge_low)) & H;
+                p[i] = (~x & kr) | (~(x ^ kr) & ge_low);
             }
         }
-        if constexpr (sizeof(T) == 2) {
-            // H bits 15 / 31 of word i -> bits 2i / 16 + 2i, then fold the upper halfword in between
-            const uint32_t q = (p[0] >> 15) | (p[1] >> 13) | (p[2] >> 11) | (p[3] >> 9);
-            return (q & 0x55u) | ((q >> 15) & 0xAAu);
-        } else {
-            // H bits 7/15/23/31 of a word -> one nibble: (x * 0x01020408) >> 24 moves bit 8b to bit 24 + b (no two
-            // partial products share a bit position, so there are no carries)
-            uint32_t bits = 0;
-            for (int i = 0; i < 4; ++i) bits |= (((p[i] >> 7) * 0x01020408u) >> 24) << (4 * i);
-            return bits;
-        }
+        return squeeze_bit<T, (int)(sizeof(T) * 8) - 1>(p);
     }
 }
 
-// The same verdict bits for one logical row straight from the PACKED words where that is cheaper: for u8 / u16, a field that
-// lies inside one packed word below its top bit ((row*W) % T + W <= T - 1) is compared IN PLACE -- masked where it sits
-// (one v_and instead of shift + and) against the constant shifted to the same position, the element's top bit serving as
-// the SWAR guard (2 operations instead of 3).  k is clamped to the field's range first (x <= k is true for every W-bit x once
-// k >= 2^W - 1; x == k is false for k >= 2^W), so the shifted constant always fits.  ~20 instead of ~32 VALU operations per
-// row of a u16 column at the narrow widths, which are VALU-bound (profiles/r03_pmc_sq_derived.txt).
-template <typename T, int W, int ROW, bool IS_EQ>
-__device__ __forceinline__ uint32_t row_predicate_bits_of_row(const Cell<T>* in, T k)
-{
-    constexpr int TB = Elem<T>::BITS;
-    constexpr int sh = W ? (ROW * W) % TB : 0;
-    if constexpr (sizeof(T) <= 2 && W >= 1 && W < TB && sh + W <= TB - 1) {
-        constexpr int word = (ROW * W) / TB;
-        constexpr uint32_t H = sizeof(T) == 2 ? 0x80008000u : 0x80808080u;
-        constexpr uint32_t L = ~H;
-        constexpr T FM = (T)((1u << W) - 1u);
-        constexpr uint32_t M = Cell<T>::rep(W) << sh;                     // the field where it sits, in every element
-        const bool beyond = k > FM;                                       // wave-uniform
-        const uint32_t ks = Cell<T>::splat((T)((beyond ? FM : k) << sh)).x[0];
-        uint32_t p[4];
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t x = in[word].x[i] & M;
-            if constexpr (IS_EQ) {
-                const uint32_t y = x ^ ks;                                // bits of the field only (top bit clear)
-                p[i] = beyond ? 0u : (~((y + L) | y) & H);                // field == 0
-            } else {
-                p[i] = ((ks | H) - x) & H;                                // no borrow across elements: x, ks < 2^(T-1)
-            }
-        }
-        if constexpr (sizeof(T) == 2) {
-            const uint32_t q = (p[0] >> 15) | (p[1] >> 13) | (p[2] >> 11) | (p[3] >> 9);
-            return (q & 0x55u) | ((q >> 15) & 0xAAu);
-        } else {
-            uint32_t bits = 0;
-            for (int i = 0; i < 4; ++i) bits |= (((p[i] >> 7) * 0x01020408u) >> 24) << (4 * i);
-            return bits;
-        }
-    } else {
-        return row_predicate_bits<T, W, IS_EQ>(unpack_row<T, W, ROW>(in), k);
+// Which rows of a u8 / u16 column are compared IN PLACE, i.e. in the packed domain, and how (round 4).
+// A field that lies inside one packed word below the word's top bit ((row*W) % T + W <= T - 1) needs no extraction: masked
+// where it sits and subtracted from [guard bit | k at the same position], the guard bit -- the bit just above the field --
+// survives iff field <= k (a borrow-free SWAR compare; for ==: guard - (field ^ k) keeps the guard iff the fields are equal).
+// The fields of consecutive rows are adjacent in a word, so every OTHER in-place field of a word can share one subtraction: the
+// fields of the rows in between are masked away and their lowest bits serve as the guards.  A word's in-place rows therefore
+// fall into two classes (even / odd rank inside the word), and one class costs 2 operations per 32-bit register (== : 3) for ALL
+// its rows -- at u16 W=3 six classes cover 13 of the 16 rows: 48 operations where round 3 spent 104 (one v_and + one v_sub per
+// row and register) -- then each row's verdict bits are squeezed out of the class's registers (squeeze_bit at the row's guard).
+template <typename T, int W> struct InPlaceRows {
+    static constexpr int TB = Elem<T>::BITS;
+    static constexpr bool in_place(int r) { return W >= 1 && W < TB && (r * W) % TB + W <= TB - 1; }
+    static constexpr int word(int r) { return (r * W) / TB; }
+    static constexpr int shift(int r) { return (r * W) % TB; }
+    // class of an in-place row: parity of its rank among the in-place rows of its word
+    static constexpr int cls(int r)
+    {
+        int n = 0;
+        for (int q = 0; q < r; ++q) n += (in_place(q) && word(q) == word(r)) ? 1 : 0;
+        return n & 1;
     }
-}
+    static constexpr bool member(int r, int wd, int c) { return in_place(r) && word(r) == wd && cls(r) == c; }
+    static constexpr bool any(int wd, int c)
+    {
+        for (int r = 0; r < TB; ++r) if (member(r, wd, c)) return true;
+        return false;
+    }
+    // per element: the class's field bits / the lowest bit of every field / the guard bits; `rep` spreads over the elements of a word
+    static constexpr uint32_t rep(uint32_t e) { return e * (sizeof(T) == 2 ? 0x00010001u : 0x01010101u); }
+    static constexpr uint32_t fields(int wd, int c)
+    {
+        uint32_t m = 0;
+        for (int r = 0; r < TB; ++r) if (member(r, wd, c)) m |= ((1u << W) - 1u) << shift(r);
+        return rep(m);
+    }
+    static constexpr uint32_t ones(int wd, int c)
+    {
+        uint32_t m = 0;
+        for (int r = 0; r < TB; ++r) if (member(r, wd, c)) m |= 1u << shift(r);
+        return rep(m);
+    }
+    static constexpr uint32_t guards(int wd, int c) { return ones(wd, c) << W; }
+    // address-row of logical row r (the inverse of WaveRowStore<T>::row_at; FL_ORDER is its own inverse, lib.rs:53-59)
+    static constexpr int address_row(int r) { return (r % 8) * (TB / 8) + fl_order(r / 8) * (TB / 8) / 8; }
+};
 
 // u32 / u64: the verdict bits never leave the registers.
 //   * One verdict costs two VALU operations: v_cmp writes the lane's verdict to VCC and v_addc_co (bits + bits + carry-in)
@@ -401,22 +425,54 @@ __device__ __forceinline__ void compare_block_butterfly(const Cell<T>* in, T k, 
 
 // u8 / u16: the block's 128-byte mask is assembled in a wave-private LDS image -- address-row j is bits
 // [j*LANES, (j+1)*LANES) and thread c owns PER_CELL contiguous bits of it (16 bits: ds_write_b16, 8 bits: ds_write_b8)
-// -- and read back as one 16-byte cell per thread.
+// -- and read back as one 16-byte cell per thread.  Rows whose field lies inside one packed word are compared in place, a
+// class of them per subtraction (InPlaceRows); the others (straddling fields, fields touching a word's top bit, W = 0, W = T)
+// are extracted first (unpack_row, macros.rs:144-164).
 template <typename T, int W, bool IS_EQ>
 __device__ __forceinline__ void compare_block_lds(const Cell<T>* in, T k, unsigned c, char* lds_blk, uint32_t (&keep)[4])
 {
+    using P = InPlaceRows<T, W>;
     constexpr int TB = Elem<T>::BITS;
-    constexpr int PER_S = TB / 8;
-    static_for<TB>([&](auto J) {
+    auto put = [&](auto J, uint32_t bits) {
         constexpr int j = decltype(J)::value;
-        constexpr int row = fl_order((j % PER_S) * (8 / PER_S)) * 8 + j / PER_S;
-        const uint32_t bits = row_predicate_bits_of_row<T, W, row, IS_EQ>(in, k);
+        static_assert(j >= 0 && j < TB, "");
         if constexpr (sizeof(T) == 1) *reinterpret_cast<uint16_t*>(lds_blk + j * 16 + c * 2) = (uint16_t)bits;
         else *reinterpret_cast<uint8_t*>(lds_blk + j * 8 + c) = (uint8_t)bits;
+    };
+    // every value is < 2^W: x <= k <=> x <= min(k, 2^W - 1); x == k is false beyond 2^W - 1 (the kernel clears the mask then)
+    constexpr T FM = W >= TB ? (T) ~(T)0 : (T)(((uint32_t)1 << (W % TB)) - 1u);
+    const uint32_t kc = k > FM ? FM : k;                              // wave-uniform (scalar)
+    static_for<(W ? W : 1)>([&](auto WD) {
+        constexpr int wd = decltype(WD)::value;
+        static_for<2>([&](auto C) {
+            constexpr int cl = decltype(C)::value;
+            if constexpr (P::any(wd, cl)) {
+                // (constexpr variables: a constexpr function called in a runtime expression is compiled as a runtime loop)
+                constexpr uint32_t M = P::fields(wd, cl), G = P::guards(wd, cl), ONES = P::ones(wd, cl);
+                const uint32_t ks = kc * ONES;                            // k at every field of the class (scalar; no carries: k < 2^W)
+                uint32_t t[4];
+                for (int i = 0; i < 4; ++i) {
+                    if constexpr (IS_EQ) t[i] = G - ((in[wd].x[i] ^ ks) & M);      // guard survives iff field ^ k == 0
+                    else t[i] = (ks | G) - (in[wd].x[i] & M);                      // guard survives iff field <= k
+                }
+                static_for<TB>([&](auto R) {
+                    constexpr int r = decltype(R)::value;
+                    static_assert(WaveRowStore<T>::row_at(P::address_row(r)) == r, "address_row inverts row_at");
+                    if constexpr (P::member(r, wd, cl))
+                        put(std::integral_constant<int, P::address_row(r)>{}, squeeze_bit<T, P::shift(r) + W>(t));
+                });
+            }
+        });
+    });
+    static_for<TB>([&](auto R) {
+        constexpr int r = decltype(R)::value;
+        if constexpr (!P::in_place(r))
+            put(std::integral_constant<int, P::address_row(r)>{}, row_predicate_bits<T, W, IS_EQ>(unpack_row<T, W, r>(in), (T)kc));
     });
     wave_lds_fence();
     const u32x4 m = *reinterpret_cast<const u32x4*>(lds_blk + c * 16);
     keep[0] = m[0]; keep[1] = m[1]; keep[2] = m[2]; keep[3] = m[3];
+    if (IS_EQ && k > FM) keep[0] = keep[1] = keep[2] = keep[3] = 0u;   // wave-uniform
 }
 
 template <typename T, int W, bool IS_EQ>
@@ -449,8 +505,15 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, compare_m
     // L2-resident 4 KiB, the same loads run at 7.8-8.5 TB/s (counting the mask), with it at 5.8-6.0 -- a thin write stream inside a
     // read stream costs the DRAM about 2.4x its bytes (profiles/abcompare_maskstore_r03.txt).  The streaming store policy of the
     // unpack kernels (nt + sc1) recovers 3-6 % of that at the narrow widths; walking several tiles per workgroup does not.
-    const __amdgpu_buffer_rsrc_t mask_rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.mask) + blk * 128u, 0, 128u, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b128(out, mask_rs, c * 16u, 0, STORE_AUX);
+    // ONE descriptor per wavefront (its 8 blocks' masks are 1 KiB contiguous), built from readfirstlane'd values: a per-block
+    // descriptor differs between the 8 lane groups and hipcc wraps the store in a waterfall loop that runs 8 times (~80
+    // instructions of the ~430 of the u16 W=3 kernel, round 3; cdna_hip_programming.md T20)
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint64_t wave_first = tile * BLOCKS_PER_WG + wave * 8u;
+    const uint64_t left = a.n_blocks - wave_first;                     // >= 1: this lane's block exists
+    const __amdgpu_buffer_rsrc_t mask_rs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(a.mask) + wave_first * 128u, 0, (unsigned)(left < 8 ? left : 8) * 128u, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(out, mask_rs, ((tid >> 3) & 7u) * 128u + c * 16u, 0, STORE_AUX);
 }
 
 typedef hipError_t (*compare_launch_t)(const CompareArgs&, hipStream_t);

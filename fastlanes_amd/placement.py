@@ -89,7 +89,10 @@ def _probe_rate(lib, slab, in_granule, mask_granule, reps=3):
     oo = mask_granule * GRANULE_BYTES + GRANULE_BYTES - (1 << 30)
     src, dst = slab[io:io + ib], slab[oo:oo + ob]
     k = ctypes.c_uint32((1 << w) // 2)
-    run = lambda: lib.fl_u32_unpack_compare(w, src.data_ptr(), 2, k, n, dst.data_ptr(), None)
+    # on torch's CURRENT stream -- the one the torch events below are recorded on (the NULL stream would not be bracketed by
+    # events of a non-blocking side stream)
+    st = ctypes.c_void_p(torch.cuda.current_stream(slab.device).cuda_stream)
+    run = lambda: lib.fl_u32_unpack_compare(w, src.data_ptr(), 2, k, n, dst.data_ptr(), st)
     ms = []
     for i in range(reps + 1):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -109,6 +112,7 @@ def granule_classes(slab, lib=None):
     into the last GiB of every other one; the slow ones are of the representative's class (profiles/exp_region_map_r03.txt: 7.0 vs
     6.05 TB/s, nothing in between).  Overwrites parts of the slab.  Returns (classes, {class: {granule: GB/s against its
     representative}})."""
+    import ctypes
     import torch
     from . import _lib
     lib = lib or _lib.load()
@@ -124,7 +128,8 @@ def granule_classes(slab, lib=None):
             if not others:
                 break
             # full-entropy probe input (constant data would raise the clocks)
-            if lib.fl_fill_random(slab[rep * GRANULE_BYTES:].data_ptr(), _PROBE_BLOCKS * 128 * _PROBE_WIDTH, 17 + rep, None) != 0:
+            st = ctypes.c_void_p(torch.cuda.current_stream(slab.device).cuda_stream)
+            if lib.fl_fill_random(slab[rep * GRANULE_BYTES:].data_ptr(), _PROBE_BLOCKS * 128 * _PROBE_WIDTH, 17 + rep, st) != 0:
                 raise RuntimeError("placement probe: fl_fill_random failed")
             rates[c] = {g: _probe_rate(lib, slab, rep, g) for g in others}
             hi, lo = max(rates[c].values()), min(rates[c].values())

@@ -45,9 +45,19 @@
  * fl_status; a binding maps nonzero to panic! to match.
  * Nothing throws or aborts across the ABI.
  *
- * Threading.  Re-entrant and thread-safe; no global state besides HIP's own.
- * Kernels run on the device that is current for the calling thread (the
- * device `stream` belongs to).
+ * Threading and device selection.  Re-entrant and thread-safe; no global state
+ * besides HIP's own, and no entry point ever calls hipSetDevice.  The device is
+ * selected the way HIP selects it: kernels run on the device that is CURRENT for
+ * the calling thread, so `stream` (when not NULL) must be a stream of that device
+ * and every device pointer must be memory that device can use (its own HBM,
+ * managed memory, or pinned host memory).  One host thread per device, each after
+ * its own hipSetDevice, is the intended multi-GPU shape (examples/multi_gpu_decode.c).
+ * A mismatch -- device 0 current, buffers or stream of device 1 -- is undefined
+ * behaviour by default, exactly as for a raw kernel launch; with the environment
+ * variable FL_CHECK_DEVICE=1 (read once, at the first device-tier call) every
+ * device-tier entry point verifies it with hipPointerGetAttributes /
+ * hipStreamGetDevice before launching and returns FL_ERR_DEVICE instead: a debug
+ * aid that costs a few microseconds per call.
  */
 #ifndef FASTLANES_AMD_H
 #define FASTLANES_AMD_H
@@ -66,7 +76,10 @@ typedef enum fl_status {
     FL_ERR_NULL = 3,    /* required pointer is NULL                                */
     FL_ERR_ALIGN = 4,   /* device pointer not 16-byte aligned (fl_fill_random: 8)  */
     FL_ERR_HIP = 5,     /* HIP runtime error; see fl_last_hip_error()              */
-    FL_ERR_BOUNDS = 6   /* a block's bytes lie outside the packed column           */
+    FL_ERR_BOUNDS = 6,  /* a block's bytes lie outside the packed column           */
+    FL_ERR_DEVICE = 7   /* FL_CHECK_DEVICE=1 only: a device-tier pointer is not memory the
+                           calling thread's current device can use, or `stream` belongs to
+                           another device (see "Threading")                        */
 } fl_status;
 
 /* Device-side error bits.  The device tier never synchronises, so what the reference reports by panicking in the middle
@@ -104,20 +117,6 @@ void fl_host_release(void);
  * output number i+1 of splitmix64 seeded with seed * 0x9E3779B97F4A7C15.  dst 8-byte aligned, n_bytes a multiple of 8
  * (FL_ERR_ALIGN otherwise).  Asynchronous on `stream`. */
 int fl_fill_random(void *dst, size_t n_bytes, uint64_t seed, void *stream);
-
-/* Where buffers live in HBM matters (not a reference function; DESIGN.md section 4, profiles/exp_region_map_r03.txt): every
- * 8-GiB granule of a device allocation belongs to one of three CLASSES of memory (most likely the ranks of the HBM stacks), in
- * an order the driver chooses; a thin write stream (a selection mask, per-block sums) next to a bulk read stream runs at 7.0 TB/s
- * when the two lie in different classes and at 6.05 TB/s when they share one, and a decode kernel's output is fastest across a
- * class boundary.  Nothing in an address tells the class; this measures it: classes[g] (HOST array, slab_bytes /
- * FL_GRANULE_BYTES entries) = 0, 1 or 2, or -1 where the probe has no clean answer, for granule g of `slab` -- a small
- * fl_u32_unpack_compare reads the start of a representative granule and writes its mask into the last GiB of every other one;
- * the slow ones are of the representative's class.  SYNCHRONOUS (kernels are timed with events on `stream`; ~100 ms for a
- * 128-GiB allocation) and DESTRUCTIVE (the first 5.2 GB of up to three granules and the last GiB of every granule are
- * overwritten): call it on a pool before the pool holds data.  slab 16-byte aligned.  fastlanes_amd/placement.py is the same in
- * Python, with the layout helpers on top. */
-#define FL_GRANULE_BYTES ((size_t)8 << 30)
-int fl_probe_memory_classes(void *slab, size_t slab_bytes, int *classes, void *stream);
 
 /*
  * Mixed-width columns (BASELINE.json config 5): block b has its own width widths[b].
@@ -239,7 +238,8 @@ const uint8_t *fl_mixed_plan_widths(const fl_mixed_plan *plan);
      * (16-byte aligned) to array a's packed and unpacked blocks, widths[a] its width, n_blocks[a] its block count;          \
      * max_blocks (host) >= every n_blocks[a] sizes the grid.  An array with a width > T or a misaligned / NULL pointer is    \
      * skipped and FL_DEVERR_WIDTH / FL_DEVERR_ALIGN is ORed into *err_flag; an array with n_blocks[a] > max_blocks has only  \
-     * its first max_blocks (rounded up to 4) blocks processed and raises FL_DEVERR_BOUNDS. */                                \
+     * its first max_blocks (rounded up to a workgroup's share, 4 to 64 blocks) blocks processed and raises FL_DEVERR_BOUNDS;     \
+     * max_blocks itself may not exceed 2^30 (FL_ERR_INDEX). */                                \
     int fl_##S##_unpack_batch(const T *const *packed, T *const *out, const uint8_t *widths,       \
                               const uint32_t *n_blocks, size_t n_arrays, uint32_t max_blocks,     \
                               uint32_t *err_flag, void *stream);                                  \

@@ -87,16 +87,17 @@ def test_fill_random_validation_needs_no_gpu(lib):
     assert lib.fl_fill_random(p + 4, 64, 1, None) == 4          # FL_ERR_ALIGN: 8-byte words
     assert lib.fl_fill_random(p, 60, 1, None) == 4
     assert lib.fl_status_string(6) == b"block outside the packed column"
+    assert b"FL_CHECK_DEVICE" in lib.fl_status_string(7) and b"current device" in lib.fl_status_string(7)      # FL_ERR_DEVICE
 
 
 def test_probe_memory_classes_validation_needs_no_gpu(lib):
     import ctypes
     out = (ctypes.c_int * 4)(7, 7, 7, 7)
-    assert lib.fl_probe_memory_classes(None, 0, out, None) == 0 and list(out) == [7, 7, 7, 7]          # no whole granule: nothing to say
-    assert lib.fl_probe_memory_classes(None, (8 << 30) - 1, out, None) == 0
-    assert lib.fl_probe_memory_classes(None, 16 << 30, out, None) == 3                                     # FL_ERR_NULL
-    assert lib.fl_probe_memory_classes(ctypes.c_void_p(0x1000), 16 << 30, None, None) == 3
-    assert lib.fl_probe_memory_classes(ctypes.c_void_p(0x1008), 16 << 30, out, None) == 4                # FL_ERR_ALIGN
+    assert lib.fl_internal_probe_memory_classes(None, 0, out, None) == 0 and list(out) == [7, 7, 7, 7]          # no whole granule: nothing to say
+    assert lib.fl_internal_probe_memory_classes(None, (8 << 30) - 1, out, None) == 0
+    assert lib.fl_internal_probe_memory_classes(None, 16 << 30, out, None) == 3                                     # FL_ERR_NULL
+    assert lib.fl_internal_probe_memory_classes(ctypes.c_void_p(0x1000), 16 << 30, None, None) == 3
+    assert lib.fl_internal_probe_memory_classes(ctypes.c_void_p(0x1008), 16 << 30, out, None) == 4                # FL_ERR_ALIGN
 
 
 def test_python_mirror_raises_like_the_reference():

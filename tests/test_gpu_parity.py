@@ -1094,11 +1094,11 @@ def test_consumer_pair_places_the_output_by_probe(fl, oracle):
     got = fl.BitPacking.unpack_compare(w, src8.view(torch.uint32), ">", 100, output=dst8.view(torch.int32))
     un = oracle.batch("unpack", "u32", w, pk, n_blocks=n)
     assert np.array_equal(got.cpu().numpy().view(np.uint8), np.packbits(un > 100, bitorder="little"))
-    # the C ABI's probe (fl_probe_memory_classes) draws the same map of the same allocation
+    # the C ABI's probe (fl_internal_probe_memory_classes) draws the same map of the same allocation
     import ctypes
     n_granules = slab.numel() // pl.GRANULE_BYTES
     out = (ctypes.c_int * n_granules)()
-    assert fl.load().fl_probe_memory_classes(slab.data_ptr(), slab.numel(), out, None) == 0
+    assert fl.load().fl_internal_probe_memory_classes(slab.data_ptr(), slab.numel(), out, None) == 0
     assert "".join("." if c < 0 else "ABC"[c] for c in out) == classes
     # an output too large for one granule: the zone layout of column_pair
     slab2, s2, d2, info2 = pl.consumer_pair(1 << 20, 9 << 30, torch.device("cuda:0"))

@@ -43,9 +43,9 @@ def test_consumer_granules_fragmented_memory():
 
 
 def test_granule_size_is_the_c_abis():
-    """include/fastlanes_amd.h: FL_GRANULE_BYTES is what fl_probe_memory_classes counts its classes[] in"""
+    """include/fastlanes_amd_internal.h: FL_INTERNAL_GRANULE_BYTES is what fl_internal_probe_memory_classes counts its classes[] in"""
     import os
     import re
-    h = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "fastlanes_amd.h")).read()
-    m = re.search(r"#define FL_GRANULE_BYTES \(\(size_t\)(\d+) << (\d+)\)", h)
+    h = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "fastlanes_amd_internal.h")).read()
+    m = re.search(r"#define FL_INTERNAL_GRANULE_BYTES \(\(size_t\)(\d+) << (\d+)\)", h)
     assert m and int(m.group(1)) << int(m.group(2)) == pl.GRANULE_BYTES == 8 * GiB

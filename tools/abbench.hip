@@ -1,7 +1,13 @@
 // abbench.hip -- within-process interleaved A/B of launch-shape / cache-policy variants
 // of the u32 W=7 unpack kernel, next to plain read / write / copy streams of the same
 // byte mix (the in-situ ceilings).  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17
-// -I fastlanes_amd/csrc tools/abbench.hip -o tools/abbench ; run on the GPU box.
+// -I fastlanes_amd/csrc -I include tools/abbench.hip -L fastlanes_amd -lfastlanes_amd
+// -Wl,-rpath,'$ORIGIN/../fastlanes_amd' -o tools/abbench ; run on the GPU box.
+//   tools/abbench [n_blocks] [rounds]         round 1's u32 W=7 unpack experiments
+//   tools/abbench pack64 [n_blocks] [rounds]  round 4: BASELINE config 3's pack leg (fl_u64_pack, W=17) against bare
+//                                             64:17 read:write streams of exactly its bytes, same buffers, interleaved
+//   tools/abbench thin <type bits> <W> [n_blocks] [rounds]   round 4: fl_<ty>_unpack_compare against a bare stream of its
+//                                             bytes (W cells read : 1 cell written per thread), u16 / u8 W=3 and u32 W=7
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -10,6 +16,8 @@
 #include <string>
 #include <vector>
 #include "fl_device.hpp"
+#include "fastlanes_amd.h"
+#include "fastlanes_amd_internal.h"
 
 using namespace fl;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -329,8 +337,243 @@ void k_stream_tuned(const u32x4* in, u32x4* out, uint64_t n_tiles, uint64_t tile
 
 struct Variant { std::string name; double bytes; std::function<void()> launch; std::vector<float> ms; };
 
+// ---------------------------------------------------------------------------------------------------------------
+// mode "pack64" (round 4): is fl_u64_pack(17) at 10 M blocks (81.92 GB read, 21.76 GB written)
+// at what the memory gives a bare stream of the same bytes at the same addresses?
+// k_bare_wave has the product kernel's access shape and nothing else: one wavefront per 1024-value block, IN_G loads of
+// 1 KiB contiguous (all in flight), OUT_G stores of 1 KiB contiguous through a descriptor that ends at the block's
+// out_bytes (u64 W=17: 2 x 1 KiB + 128 B), XCD-contiguous tiles of 4 blocks, `sc1 nt` stores, occupancy set by the
+// dynamic-LDS request -- no LDS traffic, no shifts.
+// ---------------------------------------------------------------------------------------------------------------
+template <int IN_G, int OUT_G, int LAUX>
+__global__ __launch_bounds__(256) void k_bare_wave(const char* in, char* out, uint64_t n_blocks, uint64_t tiles_per_xcd, unsigned out_bytes)
+{
+    const uint64_t n_tiles = (n_blocks + 3) / 4;
+    const uint64_t tile = (uint64_t)(blockIdx.x & 7u) * tiles_per_xcd + (blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint64_t blk = tile * 4 + wave;
+    if (blk >= n_blocks) return;
+    const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in) + blk * (uint64_t)(IN_G * 1024), 0, IN_G * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(out + blk * (uint64_t)out_bytes, 0, out_bytes, 0x00020000);
+    u32x4 v[IN_G];
+    static_for<IN_G>([&](auto G) { v[decltype(G)::value] = __builtin_amdgcn_raw_buffer_load_b128(in_rs, lane * 16u + decltype(G)::value * 1024u, 0, LAUX); });
+    u32x4 acc = {0, 0, 0, 0};
+    static_for<IN_G>([&](auto G) { acc ^= v[decltype(G)::value]; });
+    static_for<OUT_G>([&](auto G) { __builtin_amdgcn_raw_buffer_store_b128(acc + (unsigned)decltype(G)::value, out_rs, lane * 16u + decltype(G)::value * 1024u, 0, 18); });
+    if (OUT_G == 0 && acc.x == 0x12345678u && acc.y == 0x9abcdef0u) *reinterpret_cast<u32x4*>(out) = acc;   // keeps the loads of the read-only form alive
+}
+
+static unsigned lds_for_waves(int waves) { return (160u * 1024u / (unsigned)(waves < 3 ? 3 : waves)) & ~1023u; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// mode "thin" (round 4): fl_<ty>_unpack_compare -- 128*W bytes read, 128 bytes of mask written per
+// block -- against a bare stream of exactly those bytes in the kernel's own access shape: thread (block g of the wave,
+// column c) loads W cells at a stride of 8 cells and stores ONE cell, the wave's 8 masks 1 KiB contiguous; XCD-contiguous
+// tiles of 32 blocks, nt loads, `sc1 nt` store.  WR = 0: the same loads with nothing stored.
+// ---------------------------------------------------------------------------------------------------------------
+template <int RD, int WR, int MAXW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, MAXW)))
+void k_bare_cells(const u32x4* in, u32x4* out, uint64_t n_blocks, uint64_t tiles_per_xcd)
+{
+    const uint64_t n_tiles = (n_blocks + 31) / 32;
+    const uint64_t tile = (uint64_t)(blockIdx.x & 7u) * tiles_per_xcd + (blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
+    const unsigned tid = threadIdx.x;
+    const uint64_t blk = tile * 32 + (tid >> 3);
+    const unsigned c = tid & 7u;
+    if (blk >= n_blocks) return;
+    u32x4 v[RD];
+    const u32x4* pk = in + blk * (uint64_t)(8 * RD) + c;
+    static_for<RD>([&](auto I) { v[decltype(I)::value] = __builtin_nontemporal_load(pk + 8 * decltype(I)::value); });
+    u32x4 acc = {0, 0, 0, 0};
+    static_for<RD>([&](auto I) { acc ^= v[decltype(I)::value]; });
+    if constexpr (WR > 0) {
+        const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const uint64_t wave_first = tile * 32 + wave * 8u;
+        const uint64_t left = n_blocks - wave_first;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(out) + wave_first * 128u, 0,
+                                                                            (unsigned)(left < 8 ? left : 8) * 128u, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(acc, rs, ((tid >> 3) & 7u) * 128u + c * 16u, 0, 18);
+    } else if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u) {
+        out[0] = acc;
+    }
+}
+
+template <int W>
+static int run_thin_w(unsigned type_bits, uint64_t n, int rounds)
+{
+    const uint64_t in_b = n * 128ull * W, out_b = n * 128ull;
+    char *in, *out;
+    CK(hipMalloc(&in, in_b));
+    CK(hipMalloc(&out, out_b + 256));
+    if (fl_fill_random(in, in_b, 42, nullptr) != 0) { printf("fl_fill_random failed\n"); return 1; }
+    CK(hipDeviceSynchronize());
+    printf("# %s\n# unpack_compare u%u W=%d, %llu blocks: %.2f GB read + %.2f GB of mask written per launch (two hipMalloc's)\n", fl_version(),
+           type_bits, W, (unsigned long long)n, in_b / 1e9, out_b / 1e9);
+    std::vector<Variant> vs;
+    const double bytes = (double)(in_b + out_b);
+    auto cmp = [&](const char* name, int op) {
+        vs.push_back({name, bytes, [=]() {
+            int rc = type_bits == 16 ? fl_u16_unpack_compare(W, (const uint16_t*)in, op, (uint16_t)((1u << W) / 2), n, (uint32_t*)out, nullptr)
+                   : type_bits == 8  ? fl_u8_unpack_compare(W, (const uint8_t*)in, op, (uint8_t)((1u << W) / 2), n, (uint32_t*)out, nullptr)
+                                     : fl_u32_unpack_compare(W, (const uint32_t*)in, op, (1u << W) / 2, n, (uint32_t*)out, nullptr);
+            if (rc != 0) { printf("unpack_compare failed %d\n", rc); exit(1); }
+        }, {}});
+    };
+    cmp("fl_unpack_compare  x < k", FL_CMP_LT);
+    cmp("fl_unpack_compare  x == k", FL_CMP_EQ);
+    vs.push_back({"fl_unpack_block_sums (8 B written per block)", (double)(in_b + n * 8), [=]() {
+        int rc = type_bits == 16 ? fl_u16_unpack_block_sums(W, (const uint16_t*)in, n, (uint64_t*)out, nullptr)
+               : type_bits == 8  ? fl_u8_unpack_block_sums(W, (const uint8_t*)in, n, (uint64_t*)out, nullptr)
+                                 : fl_u32_unpack_block_sums(W, (const uint32_t*)in, n, (uint64_t*)out, nullptr);
+        if (rc != 0) { printf("unpack_block_sums failed %d\n", rc); exit(1); }
+    }, {}});
+    const uint64_t tpx = ((n + 31) / 32 + 7) / 8;
+    auto bare = [&](const char* name, auto kern, double by) {
+        vs.push_back({name, by, [=]() { hipLaunchKernelGGL(kern, dim3((unsigned)(tpx * 8)), dim3(256), 0, 0, (const u32x4*)in, (u32x4*)out, n, tpx); }, {}});
+    };
+    bare("bare stream W cells rd : 1 cell wr, 8 waves", (k_bare_cells<W, 1, 8>), bytes);
+    bare("bare stream W cells rd : 1 cell wr, 4 waves", (k_bare_cells<W, 1, 4>), bytes);
+    bare("bare stream W cells rd : 1 cell wr, 2 waves", (k_bare_cells<W, 1, 2>), bytes);
+    bare("bare stream W cells rd, nothing stored, 8 waves", (k_bare_cells<W, 0, 8>), (double)in_b);
+    cmp("fl_unpack_compare  x < k (again)", FL_CMP_LT);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (auto& v : vs) v.launch();
+    CK(hipDeviceSynchronize());
+    for (int r = 0; r < rounds; ++r)
+        for (auto& v : vs) {
+            CK(hipEventRecord(e0, 0));
+            v.launch();
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            v.ms.push_back(ms);
+        }
+    CK(hipGetLastError());
+    printf("%-56s %9s %9s %9s %9s %7s\n", "variant", "med_ms", "min_ms", "GB/s_med", "GB/s_max", "frac");
+    for (auto& v : vs) {
+        std::sort(v.ms.begin(), v.ms.end());
+        float med = v.ms[v.ms.size() / 2], mn = v.ms[0];
+        printf("%-56s %9.4f %9.4f %9.1f %9.1f %7.3f\n", v.name.c_str(), med, mn, v.bytes / med / 1e6, v.bytes / mn / 1e6, v.bytes / med / 1e6 / 8000.0);
+    }
+    CK(hipFree(in)); CK(hipFree(out));
+    return 0;
+}
+
+static int run_thin(int argc, char** argv)
+{
+    const unsigned type_bits = argc > 2 ? (unsigned)atoi(argv[2]) : 16;
+    const int w = argc > 3 ? atoi(argv[3]) : 3;
+    const uint64_t n = argc > 4 ? strtoull(argv[4], 0, 10) : 40000000ull;
+    const int rounds = argc > 5 ? atoi(argv[5]) : 7;
+    if (w == 3 && (type_bits == 16 || type_bits == 8)) return run_thin_w<3>(type_bits, n, rounds);
+    if (w == 7 && type_bits == 32) return run_thin_w<7>(type_bits, n, rounds);
+    printf("thin: built for u16 / u8 W=3 and u32 W=7\n");
+    return 2;
+}
+
+static int run_pack64(int argc, char** argv)
+{
+    const uint64_t n = argc > 2 ? strtoull(argv[2], 0, 10) : 10000000ull;
+    const int rounds = argc > 3 ? atoi(argv[3]) : 5;
+    const unsigned W = 17;
+    const uint64_t in_b = n * 8192ull, out_b = n * 128ull * W;
+    char *in, *out;
+    CK(hipMalloc(&in, in_b));
+    CK(hipMalloc(&out, out_b));
+    if (fl_fill_random(in, in_b, 42, nullptr) != 0) { printf("fl_fill_random failed\n"); return 1; }
+    CK(hipDeviceSynchronize());
+    printf("# %s\n# pack u64 W=17, %llu blocks: %.2f GB read + %.2f GB written per launch; in %p out %p (two hipMalloc's)\n", fl_version(),
+           (unsigned long long)n, in_b / 1e9, out_b / 1e9, (void*)in, (void*)out);
+    hipStream_t s1, s2;
+    CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    std::vector<Variant> vs;
+    const double bytes = (double)(in_b + out_b);
+    auto lib = [&](const char* name, int policy, uint64_t first, uint64_t count) {
+        vs.push_back({name, (double)count * (8192 + 128 * W), [=]() {
+            fl_internal_set_kernel_policy(policy);
+            if (fl_u64_pack(W, (const uint64_t*)(in + first * 8192), (uint64_t*)(out + first * 128 * W), count, nullptr) != 0) { printf("fl_u64_pack failed\n"); exit(1); }
+            fl_internal_set_kernel_policy(0);
+        }, {}});
+    };
+    lib("fl_u64_pack(17) as shipped", 0, 0, n);
+    for (int w : {3, 4, 5, 6, 8}) {
+        static char names[9][64];
+        snprintf(names[w], 64, "fl_u64_pack(17) wave-per-block, %d waves/SIMD", w);
+        lib(names[w], 2 + 256 * w, 0, n);
+    }
+    // size / position dependence inside the same buffers
+    lib("fl_u64_pack(17) first half only", 0, 0, n / 2);
+    lib("fl_u64_pack(17) second half only", 0, n / 2, n - n / 2);
+    lib("fl_u64_pack(17) first quarter only", 0, 0, n / 4);
+    lib("fl_u64_pack(17) last quarter only", 0, n - n / 4, n / 4);
+    // the two halves at once, on two streams (each input inside fewer memory classes)
+    hipEvent_t fork, join;
+    CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+    vs.push_back({"fl_u64_pack(17) two half-column launches, two streams", bytes, [=]() {
+        CK(hipEventRecord(fork, 0));
+        CK(hipStreamWaitEvent(s1, fork, 0));
+        CK(hipStreamWaitEvent(s2, fork, 0));
+        fl_u64_pack(W, (const uint64_t*)in, (uint64_t*)out, n / 2, s1);
+        fl_u64_pack(W, (const uint64_t*)(in + (n / 2) * 8192), (uint64_t*)(out + (n / 2) * 128 * W), n - n / 2, s2);
+        CK(hipEventRecord(join, s1)); CK(hipStreamWaitEvent(0, join, 0));
+        CK(hipEventRecord(join, s2)); CK(hipStreamWaitEvent(0, join, 0));
+    }, {}});
+    const uint64_t tpx = ((n + 3) / 4 + 7) / 8;
+    auto bare = [&](const char* name, auto kern, int waves) {
+        const unsigned lds = lds_for_waves(waves);
+        vs.push_back({name, bytes, [=]() { hipLaunchKernelGGL(kern, dim3((unsigned)(tpx * 8)), dim3(256), lds, 0, (const char*)in, out, n, tpx, 128u * W); }, {}});
+    };
+    bare("bare wave stream 8 KiB rd : 2176 B wr, nt loads, 3 waves", (k_bare_wave<8, 3, 2>), 3);
+    bare("bare wave stream 8 KiB rd : 2176 B wr, nt loads, 4 waves", (k_bare_wave<8, 3, 2>), 4);
+    bare("bare wave stream 8 KiB rd : 2176 B wr, nt loads, 5 waves", (k_bare_wave<8, 3, 2>), 5);
+    bare("bare wave stream 8 KiB rd : 2176 B wr, nt loads, 6 waves", (k_bare_wave<8, 3, 2>), 6);
+    bare("bare wave stream 8 KiB rd : 2176 B wr, nt loads, 8 waves", (k_bare_wave<8, 3, 2>), 8);
+    bare("bare wave stream 8 KiB rd : 2176 B wr, default loads, 5 waves", (k_bare_wave<8, 3, 0>), 5);
+    bare("bare wave stream 8 KiB rd : 2176 B wr, default loads, 8 waves", (k_bare_wave<8, 3, 0>), 8);
+    {
+        // round 1's tile-shaped bare stream (256 threads x 64 cells read : 17 written)
+        const uint64_t n_tiles = n / 32, tpx32 = (n_tiles + 7) / 8;
+        u32x4* sink = nullptr;
+        vs.push_back({"tuned tile stream 64rd:17wr maxw1", (double)n_tiles * 32 * (8192 + 128 * W), [=]() {
+            hipLaunchKernelGGL((k_stream_tuned<64, 17, 1>), dim3((unsigned)(tpx32 * 8)), dim3(256), 0, 0, (const u32x4*)in, (u32x4*)out, n_tiles, tpx32, sink); }, {}});
+        vs.push_back({"tuned tile stream 64rd:17wr maxw2", (double)n_tiles * 32 * (8192 + 128 * W), [=]() {
+            hipLaunchKernelGGL((k_stream_tuned<64, 17, 2>), dim3((unsigned)(tpx32 * 8)), dim3(256), 0, 0, (const u32x4*)in, (u32x4*)out, n_tiles, tpx32, sink); }, {}});
+        vs.push_back({"read-only bare wave stream 8 KiB (no stores)", (double)in_b, [=]() {
+            hipLaunchKernelGGL((k_bare_wave<8, 0, 2>), dim3((unsigned)(tpx * 8)), dim3(256), lds_for_waves(5), 0, (const char*)in, out, n, tpx, 128u * W); }, {}});
+    }
+    lib("fl_u64_pack(17) as shipped (again)", 0, 0, n);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (auto& v : vs) v.launch();
+    CK(hipDeviceSynchronize());
+    for (int r = 0; r < rounds; ++r)
+        for (auto& v : vs) {
+            CK(hipEventRecord(e0, 0));
+            v.launch();
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            v.ms.push_back(ms);
+        }
+    CK(hipGetLastError());
+    printf("%-66s %9s %9s %9s %9s %7s\n", "variant", "med_ms", "min_ms", "GB/s_med", "GB/s_max", "frac");
+    for (auto& v : vs) {
+        std::sort(v.ms.begin(), v.ms.end());
+        float med = v.ms[v.ms.size() / 2], mn = v.ms[0];
+        printf("%-66s %9.4f %9.4f %9.1f %9.1f %7.3f\n", v.name.c_str(), med, mn, v.bytes / med / 1e6, v.bytes / mn / 1e6, v.bytes / med / 1e6 / 8000.0);
+    }
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc > 1 && std::string(argv[1]) == "pack64") return run_pack64(argc, argv);
+    if (argc > 1 && std::string(argv[1]) == "thin") return run_thin(argc, argv);
     const uint64_t n = argc > 1 ? strtoull(argv[1], 0, 10) : 10000000ull;
     const int rounds = argc > 2 ? atoi(argv[2]) : 7;
     u32x4 *in, *out, *sink;

@@ -189,6 +189,8 @@ def main():
     ap.add_argument("--cases", default="quick")
     ap.add_argument("--json", default=None)
     ap.add_argument("--placement", default="zoned", choices=("zoned", "separate"))
+    ap.add_argument("--batch-all", action="store_true", help="--cases batch: every element type and the pack direction too")
+    ap.add_argument("--batch-policies", default="", help="--cases batch: comma-separated kernel policies to time next to the default")
     args = ap.parse_args()
     cases = []
     if args.cases == "quick":
@@ -242,50 +244,74 @@ def main():
                   f"{nb * 1024 / us / 1e3:9.2f} Gint/s  {nb * 4992 / us / 1e3:8.1f} GB/s", flush=True)
         return
     if args.cases == "batch":
-        # many small arrays per launch (fl_<ty>_unpack_batch) next to one device-tier call per array: 10 000 chunks of
-        # 64 blocks (64 Ki values, the chunk size of the callers SURVEY.md 8(b) names), u32
-        for w in (7, 12, 20):
-            n_arr, nb = 10000, 64
-            pk_all = rnd(n_arr * nb * 128 * w, 1).view(torch.uint32)
-            out_all = torch.empty(n_arr * nb * 1024, dtype=torch.uint32, device=dev)
-            ppb, opb = nb * 32 * w, nb * 1024
-            packed = [pk_all[a * ppb:(a + 1) * ppb] for a in range(n_arr)]
-            outs = [out_all[a * opb:(a + 1) * opb] for a in range(n_arr)]
-            batch = fl.Batch(packed, outs, [w] * n_arr)
-            for _ in range(3):
-                batch.unpack()
+        # many small arrays per launch (fl_<ty>_unpack_batch / _pack_batch) next to one device-tier call per array: 10 000 chunks of
+        # 64 blocks (64 Ki values, the chunk size of the callers SURVEY.md 8(b) names)
+        lib = fl.load()
+        pols = [int(x, 0) for x in args.batch_policies.split(",")] if args.batch_policies else []
+
+        def timed(f, reps, warm=2):
+            for _ in range(warm):
+                f()
             torch.cuda.synchronize()
             ms = []
-            for _ in range(args.reps):
+            for _ in range(reps):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(); batch.unpack(); b.record(); b.synchronize()
+                a.record(); f(); b.record(); b.synchronize()
                 ms.append(a.elapsed_time(b))
-            t = sorted(ms)[len(ms) // 2]
-            want = fl.BitPacking.unpack(w, pk_all)
-            same = torch.equal(want.view(torch.int32), out_all.view(torch.int32))
-            # the yardstick: the same 640 000 blocks as ONE contiguous column through fl_u32_unpack, same buffers
-            ms_c = []
-            for _ in range(args.reps + 2):
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(); fl.BitPacking.unpack(w, pk_all, output=out_all); b.record(); b.synchronize()
-                ms_c.append(a.elapsed_time(b))
-            tc = sorted(ms_c[2:])[len(ms_c[2:]) // 2]
-            nbytes = n_arr * nb * (128 * w + 4096)
+            return sorted(ms)[len(ms) // 2]
+
+        cases = [("u32", 7, "unpack"), ("u32", 12, "unpack"), ("u32", 20, "unpack")]
+        if args.batch_all:
+            cases += [("u32", 7, "pack"), ("u32", 20, "pack"), ("u64", 17, "unpack"), ("u64", 17, "pack"), ("u16", 9, "unpack"),
+                      ("u16", 9, "pack"), ("u8", 3, "unpack"), ("u8", 3, "pack")]
+        for ty, w, op in cases:
+            n_arr, nb = 10000, 64
+            esz, T = ESZ[ty], ESZ[ty] * 8
+            ppb, opb = nb * 1024 * w // T, nb * 1024
+            pk_all = rnd(n_arr * ppb * esz, 1).view(TDT[ty])
+            un_all = (rnd(n_arr * opb * esz, 2) if op == "pack" else torch.empty(n_arr * opb * esz, dtype=torch.uint8, device=dev)).view(TDT[ty])
+            if op == "pack":
+                pk_all = torch.empty_like(pk_all)
+            packed = [pk_all[a * ppb:(a + 1) * ppb] for a in range(n_arr)]
+            outs = [un_all[a * opb:(a + 1) * opb] for a in range(n_arr)]
+            batch = fl.Batch(packed, outs, [w] * n_arr)
+            run = batch.unpack if op == "unpack" else batch.pack
+            t = timed(run, args.reps, 3)
+            for pol in pols:
+                # A/B of the batch kernel's launch shape on the same buffers (fastlanes_amd_internal.h: policy = 2 + 256 * waves/SIMD
+                # + 65536 * blocks per wavefront + 2^24 * prefetch)
+                lib.fl_internal_set_kernel_policy(pol)
+                tp = timed(run, args.reps)
+                lib.fl_internal_set_kernel_policy(0)
+                print(f"    policy waves={(pol >> 8) & 255} blocks/wave={(pol >> 16) & 255} prefetch={pol >> 24}: {tp:8.4f} ms  "
+                      f"{n_arr * nb * (128 * w + 128 * T) / tp / 8e9:.3f} of peak", flush=True)
+            run()
+            # the yardstick: the same 640 000 blocks as ONE contiguous column through fl_<ty>_unpack / _pack, same buffers
+            if op == "unpack":
+                got = un_all.clone()
+                one = lambda: fl.BitPacking.unpack(w, pk_all, output=un_all)
+            else:
+                got = pk_all.clone()
+                one = lambda: fl.BitPacking.pack(w, un_all, output=pk_all)
+            tc = timed(one, args.reps)
+            want = un_all if op == "unpack" else pk_all
+            same = torch.equal(want.view(torch.uint8), got.view(torch.uint8))
+            nbytes = n_arr * nb * (128 * w + 128 * T)
             # the same arrays as one call each (what a chunk-at-a-time caller does today), through the raw C ABI
-            lib = fl.load()
-            f = lib.fl_u32_unpack
-            ptrs = [(p.data_ptr(), o.data_ptr()) for p, o in zip(packed, outs)]
+            f = getattr(lib, f"fl_{ty}_{op}")
+            ptrs = [((p.data_ptr(), o.data_ptr()) if op == "unpack" else (o.data_ptr(), p.data_ptr())) for p, o in zip(packed, outs)]
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
             a.record()
-            for p, o in ptrs:
-                f(w, p, o, nb, None)
+            for src, dst in ptrs:
+                f(w, src, dst, nb, None)
             b.record(); b.synchronize()
             t1 = a.elapsed_time(b)
-            print(f"unpack_batch u32 W={w}: {n_arr} arrays x {nb} blocks in one launch {t:8.4f} ms  {n_arr * nb * 1024 / t / 1e6:7.1f} Gint/s  "
-                  f"{nbytes / t / 1e6:7.1f} GB/s ({nbytes / t / 8e9:.3f} of peak)  {'== one big unpack' if same else 'MISMATCH'} | "
-                  f"the same blocks as one contiguous column, one call: {tc:8.4f} ms | one call per array: {t1:8.3f} ms  {n_arr * nb * 1024 / t1 / 1e6:7.1f} Gint/s  (x{t1 / t:.1f})", flush=True)
-            del batch, pk_all, out_all, want
+            print(f"{op}_batch {ty} W={w}: {n_arr} arrays x {nb} blocks in one launch {t:8.4f} ms  {n_arr * nb * 1024 / t / 1e6:7.1f} Gint/s  "
+                  f"{nbytes / t / 1e6:7.1f} GB/s ({nbytes / t / 8e9:.3f} of peak)  {'== one big ' + op if same else 'MISMATCH'} | "
+                  f"the same blocks as one contiguous column, one call: {tc:8.4f} ms ({(t / tc - 1) * 100:+.1f} %) | one call per array: {t1:8.3f} ms  "
+                  f"{n_arr * nb * 1024 / t1 / 1e6:7.1f} Gint/s  (x{t1 / t:.1f})", flush=True)
+            del batch, pk_all, un_all, want, got, packed, outs
         return
     if args.cases == "refbench":
         # What the reference's own criterion benches time (besides benches/bitpacking.rs, which bench.py's headline and
