@@ -22,6 +22,7 @@ struct BatchArgs {
     const void* refs;            // FoR: references[a], one per ARRAY (ffor.rs:24-50); nullptr = plain BitPacking
     uint64_t n_arrays;
     uint64_t tiles_per_xcd;
+    unsigned window_shift;       // tile-map window (fl_kernels.hpp: xcd_tile)
     unsigned tiles_per_array;    // ceil(max_blocks / (4 * bpw))
     unsigned max_blocks;         // the caller's bound on n_blocks[a]
     unsigned bpw;                // consecutive blocks of the array per wavefront (>= 1); a workgroup takes 4 * bpw
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(WG) void k_batch(BatchArgs b)
     using G = WaveBlock<T>;
     extern __shared__ __attribute__((aligned(16))) char lds_all[];
     const uint64_t n_tiles = b.n_arrays * b.tiles_per_array;
-    const uint64_t tile = (uint64_t)(blockIdx.x & 7u) * b.tiles_per_xcd + (blockIdx.x >> 3);
+    const uint64_t tile = xcd_tile(blockIdx.x, b.tiles_per_xcd, b.window_shift);
     if (tile >= n_tiles) return;
     // the launcher keeps the grid below 2^31 workgroups: 32-bit division (a 64-bit one is ~3x the scalar instructions)
     const unsigned arr = (unsigned)tile / b.tiles_per_array;
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(WG) void k_batch(BatchArgs b)
     a.ref_stride = 0;
     a.n_blocks = d.n_blocks;
     a.tiles_per_xcd = 0;
+    a.window_shift = 63;
     a.uniform_width = d.width;
     a.bpw = b.bpw;
     a.packed_bytes = 0;
@@ -117,6 +119,7 @@ hipError_t launch_batch(const BatchArgs& b0, uint32_t max_blocks, int waves, hip
     const uint64_t n_tiles = b.n_arrays * b.tiles_per_array;
     b.tiles_per_xcd = (n_tiles + 7) / 8;
     if (b.tiles_per_array == 0 || b.tiles_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;
+    b.window_shift = tile_window_shift(PACK ? TRAFFIC_READ : TRAFFIC_WRITE, (unsigned)tile_blocks);
     const unsigned lds = widths_lds_bytes<T>(waves, b.prefetch ? b.bpw : 1u);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL((k_batch<T, PACK>), dim3((unsigned)(b.tiles_per_xcd * 8)), dim3(WG), lds, s, b);

@@ -102,6 +102,7 @@ int run_stream(stream_launch_t fn, const T* in, T* out, const void* aux, size_t 
     a.aux_stride = aux_stride;
     a.n_blocks = n_blocks;
     a.tiles_per_xcd = 0;   // filled by the launcher
+    a.window_shift = 63;   // filled by the launcher
     hipError_t e = fn(a, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
@@ -125,6 +126,7 @@ int run_chain(int op, int waves, unsigned w, const T* in, const T* bases, T* out
     a.bases = reinterpret_cast<const char*>(bases);
     a.n_blocks = n_blocks;
     a.tiles_per_xcd = 0;
+    a.window_shift = 63;
     a.width = w;
     hipError_t e = fn(a, waves, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? FL_OK : hip_fail(e);
@@ -148,6 +150,7 @@ int run_wave_uniform(bool pack, int waves, unsigned w, const T* packed, T* unpac
     a.ref_stride = ref_stride;
     a.n_blocks = n_blocks;
     a.tiles_per_xcd = 0;
+    a.window_shift = 63;
     a.uniform_width = w;
     a.bpw = uniform_blocks_per_wave(Elem<T>::BITS, pack);
     a.packed_bytes = 0;      // not read: uniform-width calls are validated here, on the host side
@@ -233,7 +236,7 @@ int dev_unpack_block_sums(unsigned w, const T* in, size_t n, uint64_t* sums, voi
     if (n == 0) return FL_OK;
     if (!sums || (w != 0 && !in)) return FL_ERR_NULL;
     if (misaligned(in)) return FL_ERR_ALIGN;
-    ReduceArgs a{reinterpret_cast<const u32x4*>(in), sums, nullptr, n, 0};
+    ReduceArgs a{reinterpret_cast<const u32x4*>(in), sums, nullptr, n, 0, 63};
     hipError_t e = sum_table_impl<T>().fn[w](a, static_cast<hipStream_t>(s));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
@@ -252,6 +255,7 @@ int dev_unpack_compare(unsigned w, const T* in, int op, T constant, size_t n, ui
     a.mask = reinterpret_cast<u32x4*>(mask);
     a.n_blocks = n;
     a.tiles_per_xcd = 0;
+    a.window_shift = 63;
     a.is_eq = 0;
     a.invert = 0;
     a.constant = constant;
@@ -267,7 +271,10 @@ int dev_unpack_compare(unsigned w, const T* in, int op, T constant, size_t n, ui
         if (constant == 0) a.constant = MAXV; else { a.constant = (T)(constant - 1); a.invert = 1; }
         break;
     }
-    hipError_t e = (a.is_eq ? compare_table_impl<T, true>() : compare_table_impl<T, false>()).fn[w](a, static_cast<hipStream_t>(s));
+    int waves = compare_launch_waves(Elem<T>::BITS, w);
+    const int pol = g_kernel_policy.load(std::memory_order_relaxed);       // A/B tools: 2 + 256 * waves
+    if ((pol & 0xff) == 2 && ((pol >> 8) & 0xff)) waves = (pol >> 8) & 0xff;
+    hipError_t e = (a.is_eq ? compare_table_impl<T, true>() : compare_table_impl<T, false>()).fn[w](a, waves, static_cast<hipStream_t>(s));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
 template <typename T>
@@ -276,7 +283,7 @@ int dev_block_min_max(const T* in, size_t n, T* mins, T* maxs, void* s)
     if (n == 0) return FL_OK;
     if (!in || !mins || !maxs) return FL_ERR_NULL;
     if (misaligned(in)) return FL_ERR_ALIGN;
-    ReduceArgs a{reinterpret_cast<const u32x4*>(in), mins, maxs, n, 0};
+    ReduceArgs a{reinterpret_cast<const u32x4*>(in), mins, maxs, n, 0, 63};
     hipError_t e = min_max_launcher<T>()(a, static_cast<hipStream_t>(s));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
@@ -508,6 +515,7 @@ int run_widths(bool pack, const uint8_t* widths, const uint64_t* offsets, const 
     a.ref_stride = 0;
     a.n_blocks = n_blocks;
     a.tiles_per_xcd = 0;
+    a.window_shift = 63;
     a.uniform_width = 0;
     a.packed_bytes = packed_bytes;
     a.bpw = mixed_blocks_per_wave(Elem<T>::BITS, pack);
@@ -539,6 +547,7 @@ int run_batch(bool pack, const void* const* packed, void* const* unpacked, const
     b.refs = with_refs ? refs : nullptr;
     b.n_arrays = n_arrays;
     b.tiles_per_xcd = 0;
+    b.window_shift = 63;
     b.tiles_per_array = 0;
     b.max_blocks = max_blocks;
     b.bpw = batch_blocks_per_wave(Elem<T>::BITS, pack);
@@ -703,10 +712,12 @@ const uint8_t* fl_mixed_plan_widths(const fl_mixed_plan* p) { return p ? p->d_wi
 void fl_host_release(void) { g_host.release(); }
 void fl_internal_set_kernel_policy(int policy)
 {
-    const int mode = policy & 0xff, waves = (policy >> 8) & 0xff, bpw = (policy >> 16) & 0xff, prefetch = policy >> 24;
-    const bool ok = policy >= 0 && prefetch <= 1 && mode <= 2 && (waves == 0 || (waves >= 3 && waves <= 8)) && bpw <= 16
-                    && (mode == 2 || (waves == 0 && bpw == 0)) && (prefetch == 0 || bpw >= 2);
+    const int mode = policy & 0xff, waves = (policy >> 8) & 0xff, bpw = (policy >> 16) & 0xff, prefetch = (policy >> 24) & 1,
+              window = (policy >> 25) & 31;
+    const bool ok = policy >= 0 && policy < (1 << 30) && mode <= 2 && (waves == 0 || (waves >= 3 && waves <= 8)) && bpw <= 16
+                    && (mode == 2 || (waves == 0 && bpw == 0)) && (prefetch == 0 || bpw >= 2) && (window == 0 || window >= 8);
     g_kernel_policy.store(ok ? policy : 0, std::memory_order_relaxed);
+    fl::window_override().store(ok ? window : 0, std::memory_order_relaxed);
 }
 int fl_internal_get_kernel_policy(void) { return g_kernel_policy.load(std::memory_order_relaxed); }
 

@@ -44,6 +44,7 @@ struct ChainArgs {
     const char* bases;       // [n_blocks][128 bytes]; unused by CHAIN_NONE
     uint64_t n_blocks;
     uint64_t tiles_per_xcd;
+    unsigned window_shift;     // tile-map window (fl_kernels.hpp: xcd_tile); filled by the launcher
     unsigned width;          // SRC_PACKED / SNK_PACKED only
 };
 
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(WG) void k_chain(ChainArgs a)
     constexpr unsigned WAVE_LDS = chain_wave_lds<T, SRC, SNK>();
     extern __shared__ __attribute__((aligned(16))) char lds_all[];
     const uint64_t n_tiles = (a.n_blocks + (WG / 64) - 1) / (WG / 64);
-    const uint64_t tile = (uint64_t)(blockIdx.x & 7u) * a.tiles_per_xcd + (blockIdx.x >> 3);
+    const uint64_t tile = xcd_tile(blockIdx.x, a.tiles_per_xcd, a.window_shift);
     if (tile >= n_tiles) return;
     const unsigned tid = threadIdx.x;
     const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
@@ -305,6 +306,7 @@ hipError_t launch_chain(const ChainArgs& a0, int waves, hipStream_t s)
     const uint64_t n_tiles = (a.n_blocks + (WG / 64) - 1) / (WG / 64);
     a.tiles_per_xcd = (n_tiles + 7) / 8;
     if (a.tiles_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;
+    a.window_shift = tile_window_shift(SNK == SNK_PACKED ? TRAFFIC_READ : SRC == SRC_PACKED ? TRAFFIC_WRITE : TRAFFIC_BALANCED, WG / 64);
     const unsigned need = (WG / 64) * chain_wave_lds<T, SRC, SNK>();
     if (waves < 3) waves = 3;
     const unsigned pad = (CU_LDS_BYTES / (unsigned)waves) & ~1023u;

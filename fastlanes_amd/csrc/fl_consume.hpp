@@ -17,6 +17,8 @@ namespace fl {
 // 87 % of the VALU issue slots at u16 W=3) and need every wave; from W = 6 up fewer, fatter waves with every load in flight
 // stream better: compare +3...6 % (u64 W=56: +17 %), sums +2...6 % at W = 6..12.
 constexpr int compare_max_waves(int w) { return w <= 5 ? 8 : w <= 9 ? 3 : 2; }
+// waves per SIMD the compare kernels are LAUNCHED at (0 = the cap above), see launch_unpack_compare
+inline int compare_launch_waves(unsigned type_bits, unsigned w) { (void)type_bits; (void)w; return 0; }
 constexpr int sums_max_waves(int w) { return (w >= 6 && w <= 12) ? 3 : 8; }
 
 struct ReduceArgs {
@@ -25,12 +27,13 @@ struct ReduceArgs {
     void* out1;            // maxs (T per block) or unused
     uint64_t n_blocks;
     uint64_t tiles_per_xcd;
+    unsigned window_shift;  // tile-map window (fl_kernels.hpp: xcd_tile)
 };
 
 __device__ __forceinline__ bool tile_of_workgroup(const ReduceArgs& a, uint64_t& tile)
 {
     const uint64_t n_tiles = (a.n_blocks + BLOCKS_PER_WG - 1) / BLOCKS_PER_WG;
-    tile = (uint64_t)(blockIdx.x & 7u) * a.tiles_per_xcd + (blockIdx.x >> 3);
+    tile = xcd_tile(blockIdx.x, a.tiles_per_xcd, a.window_shift);
     return tile < n_tiles;
 }
 
@@ -178,6 +181,7 @@ struct CompareArgs {
     uint32_t invert;       // complement the result
     uint64_t n_blocks;
     uint64_t tiles_per_xcd;
+    unsigned window_shift;  // tile-map window (fl_kernels.hpp: xcd_tile)
 };
 
 // u8 / u16 compare SWAR-wise: all elements of a 32-bit word at once, the verdict of an element landing in ONE bit of its
@@ -479,7 +483,7 @@ template <typename T, int W, bool IS_EQ>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, compare_max_waves(W)))) void k_unpack_compare(CompareArgs a)
 {
     const uint64_t n_tiles = (a.n_blocks + BLOCKS_PER_WG - 1) / BLOCKS_PER_WG;
-    const uint64_t tile = (uint64_t)(blockIdx.x & 7u) * a.tiles_per_xcd + (blockIdx.x >> 3);
+    const uint64_t tile = xcd_tile(blockIdx.x, a.tiles_per_xcd, a.window_shift);
     if (tile >= n_tiles) return;
     const unsigned tid = threadIdx.x;
     const uint64_t blk = tile * BLOCKS_PER_WG + (tid >> 3);
@@ -516,14 +520,20 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, compare_m
     __builtin_amdgcn_raw_buffer_store_b128(out, mask_rs, ((tid >> 3) & 7u) * 128u + c * 16u, 0, STORE_AUX);
 }
 
-typedef hipError_t (*compare_launch_t)(const CompareArgs&, hipStream_t);
-template <typename T, int W, bool IS_EQ> hipError_t launch_unpack_compare(const CompareArgs& a0, hipStream_t s)
+// `waves` (0 = whatever the kernel's own cap allows): workgroups per CU = waves per SIMD, enforced by padding the launch's
+// dynamic-LDS request (the kernel never touches it) -- occupancy as a launch parameter, as for the wave-per-block kernels
+typedef hipError_t (*compare_launch_t)(const CompareArgs&, int waves, hipStream_t);
+template <typename T, int W, bool IS_EQ> hipError_t launch_unpack_compare(const CompareArgs& a0, int waves, hipStream_t s)
 {
     if (a0.n_blocks == 0) return hipSuccess;
     CompareArgs a = a0;
     const uint64_t n_tiles = (a.n_blocks + BLOCKS_PER_WG - 1) / BLOCKS_PER_WG;
     a.tiles_per_xcd = (n_tiles + 7) / 8;
-    hipLaunchKernelGGL((k_unpack_compare<T, W, IS_EQ>), dim3((unsigned)(a.tiles_per_xcd * 8)), dim3(WG), 0, s, a);
+    a.window_shift = tile_window_shift(TRAFFIC_READ, BLOCKS_PER_WG);
+    constexpr unsigned STATIC_LDS = sizeof(T) >= 4 ? 0u : BLOCKS_PER_WG * 144u;
+    unsigned pad = 0;
+    if (waves >= 3 && waves < 8) pad = ((160u * 1024u / (unsigned)waves) & ~1023u) - STATIC_LDS;   // < 64 KiB for waves >= 3
+    hipLaunchKernelGGL((k_unpack_compare<T, W, IS_EQ>), dim3((unsigned)(a.tiles_per_xcd * 8)), dim3(WG), pad, s, a);
     return hipGetLastError();
 }
 template <typename T> struct CompareTable { compare_launch_t fn[Elem<T>::BITS + 1]; };
@@ -541,6 +551,7 @@ inline unsigned plan_grid(ReduceArgs& a)
 {
     const uint64_t n_tiles = (a.n_blocks + BLOCKS_PER_WG - 1) / BLOCKS_PER_WG;
     a.tiles_per_xcd = (n_tiles + 7) / 8;
+    a.window_shift = tile_window_shift(TRAFFIC_READ, BLOCKS_PER_WG);
     return (unsigned)(a.tiles_per_xcd * 8);
 }
 template <typename T, int W> hipError_t launch_unpack_block_sums(const ReduceArgs& a0, hipStream_t s)

@@ -10,6 +10,7 @@
 #pragma once
 #include "fl_device.hpp"
 #include "fl_dispatch.hpp"
+#include <atomic>
 
 namespace fl {
 
@@ -33,7 +34,42 @@ struct StreamArgs {
     uint64_t aux_stride;   // FoR: 0 = one scalar for all blocks, 1 = one per block
     uint64_t n_blocks;
     uint64_t tiles_per_xcd;   // ceil(ceil(n_blocks/32) / 8)
+    unsigned window_shift;    // log2 of the tile-map window in tiles (>= 32: one window = the whole column); see xcd_tile
 };
+
+// The XCD-aware tile map shared by every kernel: workgroup b -> tile.  The grid is 8 * tiles_per_xcd workgroups (a multiple
+// of 8; padding workgroups get tiles past the end and leave).  It is walked in windows of 2^window_shift tiles (the last one
+// shorter; every window a multiple of 8 tiles): workgroups [first, first + span) serve window [first, first + span), and
+// inside it workgroup r -- which runs on XCD r % 8 (observed dispatch order; used for speed only, results never depend on
+// it) -- takes tile first + (r % 8) * span / 8 + r / 8, so XCD x owns one contiguous eighth of the window.  One window =
+// rounds 1-3's map (XCD x owns one contiguous eighth of the whole column).  Why windows: fl_dispatch.hpp (TrafficKind).
+__device__ __forceinline__ uint64_t xcd_tile(unsigned b, uint64_t tiles_per_xcd, unsigned window_shift)
+{
+    if (window_shift >= 32) return (uint64_t)(b & 7u) * tiles_per_xcd + (b >> 3);
+    const unsigned first = (b >> window_shift) << window_shift;
+    const unsigned r = b - first;
+    const uint64_t left = tiles_per_xcd * 8 - first, full = 1ull << window_shift;
+    const uint64_t span = left < full ? left : full;
+    return first + (uint64_t)(r & 7u) * (span >> 3) + (r >> 3);
+}
+
+// A/B tools (fl_internal_set_kernel_policy bits 25-29): log2 of the window in blocks for EVERY kernel; 0 = each kernel's default
+inline std::atomic<int>& window_override()
+{
+    static std::atomic<int> v{0};
+    return v;
+}
+// window_shift of a launch: the kernel's traffic kind (or the override) in blocks -> tiles of `tile_blocks` blocks
+inline unsigned tile_window_shift(TrafficKind kind, unsigned tile_blocks)
+{
+    const int ov = window_override().load(std::memory_order_relaxed);
+    const int lg = ov ? ov : window_log2_blocks_default(kind);
+    if (lg >= WINDOW_WHOLE) return 63u;
+    int tl = 0;
+    while ((2u << tl) <= tile_blocks) ++tl;                  // floor(log2(tile_blocks))
+    const int sh = lg - tl;
+    return (unsigned)(sh < 3 ? 3 : sh);                      // a window is a multiple of 8 tiles
+}
 
 // ---------------------------------------------------------------------------
 // Streaming policy, fixed by measurement on MI355X (profiles/abbench_r01*.txt):
@@ -70,7 +106,7 @@ template <typename T> struct PackPolicy {
 __device__ __forceinline__ bool tile_of_workgroup(const StreamArgs& a, uint64_t& tile)
 {
     const uint64_t n_tiles = (a.n_blocks + BLOCKS_PER_WG - 1) / BLOCKS_PER_WG;
-    tile = (uint64_t)(blockIdx.x & 7u) * a.tiles_per_xcd + (blockIdx.x >> 3);
+    tile = xcd_tile(blockIdx.x, a.tiles_per_xcd, a.window_shift);
     return tile < n_tiles;
 }
 
@@ -321,10 +357,11 @@ void k_delta(StreamArgs a)
 typedef hipError_t (*stream_launch_t)(const StreamArgs&, hipStream_t);
 
 // grid = 8 XCD slots x tiles_per_xcd (padding workgroups exit immediately)
-inline unsigned plan_grid(StreamArgs& a)
+inline unsigned plan_grid(StreamArgs& a, TrafficKind kind = TRAFFIC_BALANCED)
 {
     const uint64_t n_tiles = (a.n_blocks + BLOCKS_PER_WG - 1) / BLOCKS_PER_WG;
     a.tiles_per_xcd = (n_tiles + 7) / 8;
+    a.window_shift = tile_window_shift(kind, BLOCKS_PER_WG);
     return (unsigned)(a.tiles_per_xcd * 8);
 }
 
@@ -333,7 +370,7 @@ hipError_t launch_unpack(const StreamArgs& a0, hipStream_t s)
 {
     if (a0.n_blocks == 0) return hipSuccess;
     StreamArgs a = a0;
-    const unsigned grid = plan_grid(a);
+    const unsigned grid = plan_grid(a, TRAFFIC_WRITE);
     hipLaunchKernelGGL((k_unpack<T, W, BODY>), dim3(grid), dim3(WG), 0, s, a);
     return hipGetLastError();
 }
@@ -342,7 +379,7 @@ hipError_t launch_pack(const StreamArgs& a0, hipStream_t s)
 {
     if (a0.n_blocks == 0 || W == 0) return hipSuccess;
     StreamArgs a = a0;
-    const unsigned grid = plan_grid(a);
+    const unsigned grid = plan_grid(a, TRAFFIC_READ);
     hipLaunchKernelGGL((k_pack<T, W, MODE>), dim3(grid), dim3(WG), 0, s, a);
     return hipGetLastError();
 }
@@ -351,7 +388,7 @@ hipError_t launch_delta(const StreamArgs& a0, hipStream_t s)
 {
     if (a0.n_blocks == 0) return hipSuccess;
     StreamArgs a = a0;
-    const unsigned grid = plan_grid(a);
+    const unsigned grid = plan_grid(a, TRAFFIC_BALANCED);
     hipLaunchKernelGGL((k_delta<T, INVERSE>), dim3(grid), dim3(WG), 0, s, a);
     return hipGetLastError();
 }

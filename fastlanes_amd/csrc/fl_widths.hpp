@@ -43,6 +43,7 @@ struct WidthsArgs {
     uint64_t packed_bytes;     // size of the packed column: a block must lie inside [0, packed_bytes) (only read when widths != nullptr)
     unsigned prefetch;         // bpw > 1: 1 = request all bpw blocks of the wavefront up front by LDS-DMA (one LDS image per block)
     unsigned linear_map;       // A/B tools: 1 = workgroup b takes tile b instead of the XCD-contiguous map
+    unsigned window_shift;     // tile-map window (fl_kernels.hpp: xcd_tile); filled by the launcher
 };
 
 template <typename T> struct WaveBlock {
@@ -365,7 +366,7 @@ __device__ __forceinline__ void for_each_block_of_wave(const WidthsArgs& a, F&& 
     const uint64_t n_tiles = (a.n_blocks + tile_blocks - 1) / tile_blocks;
     // XCD-contiguous map (workgroup ids go round-robin over the 8 XCDs: XCD x owns one contiguous eighth of the column);
     // linear_map (A/B tools only) = workgroup b takes tile b
-    const uint64_t tile = a.linear_map ? (uint64_t)blockIdx.x : (uint64_t)(blockIdx.x & 7u) * a.tiles_per_xcd + (blockIdx.x >> 3);
+    const uint64_t tile = a.linear_map ? (uint64_t)blockIdx.x : xcd_tile(blockIdx.x, a.tiles_per_xcd, a.window_shift);
     if (tile >= n_tiles) return;
     const unsigned tid = threadIdx.x;
     const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
@@ -604,6 +605,7 @@ hipError_t launch_widths(const WidthsArgs& a0, int waves, hipStream_t s)
     const uint64_t n_tiles = (a.n_blocks + tile_blocks - 1) / tile_blocks;
     a.tiles_per_xcd = (n_tiles + 7) / 8;
     if (a.tiles_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;   // > 2^33 blocks in one launch
+    a.window_shift = tile_window_shift(PACK ? TRAFFIC_READ : TRAFFIC_WRITE, (unsigned)tile_blocks);
     const dim3 grid((unsigned)(a.tiles_per_xcd * 8));
     if (a.bpw < 2 || a.bpw > 16) a.prefetch = 0;
     const unsigned lds = widths_lds_bytes<T>(waves, a.prefetch ? a.bpw : 1u);

@@ -24,6 +24,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 
 #include "fastlanes_amd.h"
 
@@ -226,6 +227,99 @@ template <typename T> struct Transpose : FastLanes<T> {
     { detail::check(A::untranspose(d_in, d_out, n_blocks, stream), "untranspose_device"); }
 };
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The reference's CALLER LOOP as one checked call.  Vortex (and benches/bitpacking.rs:80-97) hold a column as slices and loop
+//     for i in 0..n { T::unchecked_unpack(w, &packed[i*pl..(i+1)*pl], &mut out[i*1024..(i+1)*1024]) }
+// where every iteration asserts its two lengths (bitpacking.rs:78-80, :111-113).  A DeviceSlice is the device-resident
+// counterpart of such a slice -- pointer AND element count -- and the *_column functions below check the same lengths for the
+// whole column before the one asynchronous launch, so the fast path keeps what the slow path asserted.  A length mismatch
+// throws std::length_error (the reference's debug_assert), width > T throws Error(FL_ERR_WIDTH) (its unreachable!()).
+// (bindings/rust/src/device.rs is the same surface in Rust.)
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T> struct DeviceSlice {
+    T* ptr = nullptr;          // device pointer, 16-byte aligned
+    std::size_t len = 0;       // elements
+    DeviceSlice() = default;
+    DeviceSlice(T* p, std::size_t n) : ptr(p), len(n) {}
+    template <typename U, typename = std::enable_if_t<std::is_same<const U, T>::value>>
+    DeviceSlice(const DeviceSlice<U>& o) : ptr(o.ptr), len(o.len) {}          // DeviceSlice<T> -> DeviceSlice<const T>
+    // elements [first, first + count): the sub-slice a sharded caller hands each device / stream
+    DeviceSlice subslice(std::size_t first, std::size_t count) const
+    {
+        if (first > len || count > len - first) throw std::out_of_range("DeviceSlice::subslice");
+        return DeviceSlice(ptr + first, count);
+    }
+};
+
+namespace detail {
+// number of 1024-value blocks of a column given as (packed, unpacked) slices of width `width`; throws unless
+// unpacked.len == 1024 * n and packed.len == n * 1024 * width / T for one n  (bitpacking.rs:78-80, :111-113 for every block)
+template <typename T>
+inline std::size_t column_blocks(std::size_t width, std::size_t packed_len, std::size_t unpacked_len, const char* where)
+{
+    constexpr std::size_t TB = sizeof(T) * 8;
+    if (width > TB) throw Error(FL_ERR_WIDTH, where);
+    if (unpacked_len % 1024 != 0) throw std::length_error(std::string(where) + ": the unpacked slice must hold 1024 elements per block");
+    const std::size_t n = unpacked_len / 1024;
+    if (packed_len != n * (1024 * width / TB))
+        throw std::length_error(std::string(where) + ": the packed slice must hold 1024 * W / T elements per block");
+    return n;
+}
+}  // namespace detail
+
+// for b in blocks { T::unchecked_unpack(width, &packed[b*pl..], &mut out[b*1024..]) }   (bitpacking.rs:109-129)
+template <typename T>
+inline void unpack_column(std::size_t width, DeviceSlice<const T> packed, DeviceSlice<T> out, void* stream = nullptr)
+{
+    const std::size_t n = detail::column_blocks<T>(width, packed.len, out.len, "unpack_column");
+    detail::check(detail::Abi<T>::unpack((unsigned)width, packed.ptr, out.ptr, n, stream), "unpack_column");
+}
+// for b in blocks { T::unchecked_pack(width, &input[b*1024..], &mut packed[b*pl..]) }   (bitpacking.rs:76-96)
+template <typename T>
+inline void pack_column(std::size_t width, DeviceSlice<const T> input, DeviceSlice<T> packed, void* stream = nullptr)
+{
+    const std::size_t n = detail::column_blocks<T>(width, packed.len, input.len, "pack_column");
+    detail::check(detail::Abi<T>::pack((unsigned)width, input.ptr, packed.ptr, n, stream), "pack_column");
+}
+// for b in blocks { T::undelta_pack::<W>(&packed[b], &bases[b], &mut out[b]) }   (delta.rs:47-63); bases: LANES per block
+template <typename T>
+inline void undelta_pack_column(std::size_t width, DeviceSlice<const T> packed, DeviceSlice<const T> bases, DeviceSlice<T> out,
+                                void* stream = nullptr)
+{
+    const std::size_t n = detail::column_blocks<T>(width, packed.len, out.len, "undelta_pack_column");
+    if (bases.len != n * (1024 / (sizeof(T) * 8))) throw std::length_error("undelta_pack_column: bases must hold LANES elements per block");
+    detail::check(detail::Abi<T>::undelta_pack((unsigned)width, packed.ptr, bases.ptr, out.ptr, n, stream), "undelta_pack_column");
+}
+// for b in blocks { T::unfor_pack::<W>(&packed[b], references[b], &mut out[b]) }   (ffor.rs:38-50); one reference per block,
+// or ONE for the whole column (references.len == 1)
+template <typename T>
+inline void unfor_pack_column(std::size_t width, DeviceSlice<const T> packed, DeviceSlice<const T> references, DeviceSlice<T> out,
+                              void* stream = nullptr)
+{
+    const std::size_t n = detail::column_blocks<T>(width, packed.len, out.len, "unfor_pack_column");
+    if (references.len != n && references.len != 1) throw std::length_error("unfor_pack_column: one reference per block, or one in all");
+    detail::check(detail::Abi<T>::unfor_pack((unsigned)width, packed.ptr, references.ptr, references.len == 1 ? 0 : 1, out.ptr, n, stream),
+                  "unfor_pack_column");
+}
+
+// The same loop over MANY SMALL ARRAYS ("chunks": Vortex keeps 64 Ki values per chunk), one launch: the four per-chunk device
+// arrays of fl_<ty>_unpack_batch with their lengths.  unpack_chunks checks that the table is consistent (one entry per chunk in
+// every array); what only the device can see -- each chunk's width, pointers' alignment, block count against max_blocks -- is
+// checked by the kernel and reported through *err_flag (FL_DEVERR_*).
+template <typename T> struct ChunkTable {
+    DeviceSlice<const T* const> packed;          // [n_chunks] device pointers to the chunks' packed blocks
+    DeviceSlice<T* const> out;                   // [n_chunks] device pointers to where each chunk decodes
+    DeviceSlice<const std::uint8_t> widths;      // [n_chunks]
+    DeviceSlice<const std::uint32_t> n_blocks;   // [n_chunks]
+    std::uint32_t max_blocks = 0;                // host-side bound on n_blocks[c] (sizes the grid)
+};
+template <typename T>
+inline void unpack_chunks(const ChunkTable<T>& t, std::uint32_t* d_err_flag = nullptr, void* stream = nullptr)
+{
+    const std::size_t n = t.widths.len;
+    if (t.packed.len != n || t.out.len != n || t.n_blocks.len != n) throw std::length_error("unpack_chunks: every array of the table holds one entry per chunk");
+    detail::check(detail::Abi<T>::unpack_batch(t.packed.ptr, t.out.ptr, t.widths.ptr, t.n_blocks.ptr, n, t.max_blocks, d_err_flag, stream), "unpack_chunks");
+}
 // A column whose blocks each have their own width: the caller loop
 // `for b { T::unchecked_unpack(widths[b], ..) }` (bitpacking.rs:109-129) as one device call.
 template <typename T> class MixedWidthPlan {

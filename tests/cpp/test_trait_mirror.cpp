@@ -241,6 +241,101 @@ static void test_device_tier()
     EXPECT(hipDeviceSynchronize() == hipSuccess);
 }
 
+// The caller loop of benches/bitpacking.rs:80-97 as ONE checked call on device slices (fastlanes_amd.hpp: DeviceSlice,
+// unpack_column / pack_column / undelta_pack_column / unfor_pack_column / unpack_chunks): results equal the per-block host-tier
+// trait calls, and every length the reference's loop asserts per block (bitpacking.rs:78-80, :111-113) is refused up front.
+template <typename F> static bool throws_length(F&& f)
+{
+    try { f(); } catch (const std::length_error&) { return true; } catch (...) { return false; }
+    return false;
+}
+static void test_column_api()
+{
+    using T = uint32_t;
+    const size_t N = 37, W = 11, PL = 1024 * W / 32, LANES = 32;
+    std::vector<T> v(N * 1024), bases(N * LANES), refs(N);
+    for (size_t i = 0; i < v.size(); ++i) v[i] = (T)((i * 2654435761ull) >> 5) & ((1u << W) - 1u);
+    for (size_t i = 0; i < bases.size(); ++i) bases[i] = (T)(i * 40503u + 7u);
+    for (size_t b = 0; b < N; ++b) refs[b] = (T)(1000003u * (b + 1));
+    DevVec<T> dv(N * 1024), dp(N * PL), du(N * 1024), db(N * LANES), dr(N);
+    dv.up(v); db.up(bases); dr.up(refs);
+    const DeviceSlice<T> sv(dv.p, dv.n), sp(dp.p, dp.n), su(du.p, du.n);
+    const DeviceSlice<const T> cb(db.p, db.n), cr(dr.p, dr.n);
+    pack_column<T>(W, sv, sp);
+    unpack_column<T>(W, sp, su);
+    EXPECT(du.down() == v);
+    // == the loop of host-tier trait calls, block by block
+    const std::vector<T> pk = dp.down();
+    for (size_t b = 0; b < N; b += 9) {
+        std::vector<T> one(PL);
+        BitPacking<T>::unchecked_pack(W, v.data() + b * 1024, 1024, one.data(), PL);
+        EXPECT(std::memcmp(one.data(), pk.data() + b * PL, PL * sizeof(T)) == 0);
+    }
+    // fused Delta / FoR decode of the column == the per-block trait calls
+    undelta_pack_column<T>(W, sp, cb, su);
+    std::vector<T> got = du.down();
+    for (size_t b = 0; b < N; b += 12) {
+        T in1[PL], base1[LANES], out1[1024];
+        std::memcpy(in1, pk.data() + b * PL, sizeof in1);
+        std::memcpy(base1, bases.data() + b * LANES, sizeof base1);
+        Delta<T>::undelta_pack<W>(in1, base1, out1);
+        EXPECT(std::memcmp(out1, got.data() + b * 1024, sizeof out1) == 0);
+    }
+    unfor_pack_column<T>(W, sp, cr, su);
+    got = du.down();
+    for (size_t b = 0; b < N; b += 12) {
+        T in1[PL], out1[1024];
+        std::memcpy(in1, pk.data() + b * PL, sizeof in1);
+        FoR<T>::unfor_pack<W>(in1, refs[b], out1);
+        EXPECT(std::memcmp(out1, got.data() + b * 1024, sizeof out1) == 0);
+    }
+    unfor_pack_column<T>(W, sp, cr.subslice(3, 1), su);                     // one reference for the whole column
+    got = du.down();
+    for (size_t i = 0; i < got.size(); i += 401) EXPECT(got[i] == (T)(v[i] + refs[3]));
+    // a sharded caller hands each device / stream a sub-slice: blocks [10, 25)
+    DevVec<T> du2(15 * 1024);
+    unpack_column<T>(W, DeviceSlice<const T>(sp).subslice(10 * PL, 15 * PL), DeviceSlice<T>(du2.p, du2.n));
+    EXPECT(du2.down() == std::vector<T>(v.begin() + 10 * 1024, v.begin() + 25 * 1024));
+    // every length the per-block loop asserts (bitpacking.rs:78-80, :111-113) is refused BEFORE anything is launched
+    EXPECT(throws_length([&] { unpack_column<T>(W, sp.subslice(0, sp.len - 1), su); }));           // packed one element short
+    EXPECT(throws_length([&] { unpack_column<T>(W, sp, su.subslice(0, su.len - 1)); }));           // output not whole blocks
+    EXPECT(throws_length([&] { unpack_column<T>(W, sp, su.subslice(0, su.len - 1024)); }));        // one block fewer than packed
+    EXPECT(throws_length([&] { unpack_column<T>(W + 1, sp, su); }));                               // the width the data was not packed with
+    EXPECT(throws_length([&] { pack_column<T>(W, sv, sp.subslice(0, sp.len - PL)); }));
+    EXPECT(throws_length([&] { undelta_pack_column<T>(W, sp, cb.subslice(0, cb.len - 1), su); })); // bases: LANES per block
+    EXPECT(throws_length([&] { unfor_pack_column<T>(W, sp, cr.subslice(0, 2), su); }));            // neither one reference nor one per block
+    try { unpack_column<T>(33, sp, su); EXPECT(false); } catch (const Error& e) { EXPECT(e.status == FL_ERR_WIDTH); }   // bitpacking.rs:126
+    try { (void)sp.subslice(sp.len, 1); EXPECT(false); } catch (const std::out_of_range&) {}
+    unpack_column<T>(0, DeviceSlice<const T>(), DeviceSlice<T>());                                 // an empty column is a no-op
+    // many small arrays ("chunks") in one launch through the checked table: chunks of 5, 0, 7 and 25 blocks of the column above
+    const size_t cb_[4] = {5, 0, 7, 25}, first[4] = {0, 5, 5, 12};
+    std::vector<const T*> hp(4);
+    std::vector<T*> ho(4);
+    std::vector<uint8_t> hw(4, (uint8_t)W);
+    std::vector<uint32_t> hn(4);
+    DevVec<T> du3(N * 1024);
+    (void)hipMemset(du3.p, 0, du3.n * sizeof(T));
+    for (int c = 0; c < 4; ++c) { hp[c] = dp.p + first[c] * PL; ho[c] = du3.p + first[c] * 1024; hn[c] = (uint32_t)cb_[c]; }
+    DevVec<const T*> dpp(4);
+    DevVec<T*> dop(4);
+    DevVec<uint8_t> dw(4);
+    DevVec<uint32_t> dn(4), derr(1);
+    dpp.up(hp); dop.up(ho); dw.up(hw); dn.up(hn);
+    (void)hipMemset(derr.p, 0, 4);
+    ChunkTable<T> t;
+    t.packed = DeviceSlice<const T* const>(dpp.p, 4);
+    t.out = DeviceSlice<T* const>(dop.p, 4);
+    t.widths = DeviceSlice<const uint8_t>(dw.p, 4);
+    t.n_blocks = DeviceSlice<const uint32_t>(dn.p, 4);
+    t.max_blocks = 25;
+    unpack_chunks<T>(t, derr.p);
+    EXPECT(du3.down() == v);
+    EXPECT(derr.down()[0] == 0u);
+    t.n_blocks = DeviceSlice<const uint32_t>(dn.p, 3);                       // a table whose arrays disagree is refused on the host
+    EXPECT(throws_length([&] { unpack_chunks<T>(t, derr.p); }));
+    EXPECT(hipDeviceSynchronize() == hipSuccess);
+}
+
 int main()
 {
     try {
@@ -254,6 +349,7 @@ int main()
         test_panics();
         test_wide_and_narrow();
         test_device_tier();
+        test_column_api();
     } catch (const std::exception& e) {
         std::printf("EXCEPTION %s\n", e.what());
         return 2;

@@ -364,6 +364,30 @@ __global__ __launch_bounds__(256) void k_bare_wave(const char* in, char* out, ui
     if (OUT_G == 0 && acc.x == 0x12345678u && acc.y == 0x9abcdef0u) *reinterpret_cast<u32x4*>(out) = acc;   // keeps the loads of the read-only form alive
 }
 
+// the same bare stream under a WINDOWED tile map: the column is walked window by window (window_tiles tiles, a multiple of 8), and
+// inside a window XCD x owns one contiguous eighth -- every XCD still sees one dense stream, but the whole chip reads from one
+// stretch of the column at a time instead of from 8 places spread over all of it
+template <int IN_G, int OUT_G, int LAUX>
+__global__ __launch_bounds__(256) void k_bare_wave_windowed(const char* in, char* out, uint64_t n_blocks, uint64_t window_tiles, unsigned out_bytes)
+{
+    const uint64_t n_tiles = (n_blocks + 3) / 4;
+    const uint64_t b = blockIdx.x;
+    const uint64_t win = b / window_tiles, r = b - win * window_tiles;
+    const uint64_t tile = win * window_tiles + (r & 7u) * (window_tiles >> 3) + (r >> 3);
+    if (tile >= n_tiles) return;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint64_t blk = tile * 4 + wave;
+    if (blk >= n_blocks) return;
+    const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in) + blk * (uint64_t)(IN_G * 1024), 0, IN_G * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(out + blk * (uint64_t)out_bytes, 0, out_bytes, 0x00020000);
+    u32x4 v[IN_G];
+    static_for<IN_G>([&](auto G) { v[decltype(G)::value] = __builtin_amdgcn_raw_buffer_load_b128(in_rs, lane * 16u + decltype(G)::value * 1024u, 0, LAUX); });
+    u32x4 acc = {0, 0, 0, 0};
+    static_for<IN_G>([&](auto G) { acc ^= v[decltype(G)::value]; });
+    static_for<OUT_G>([&](auto G) { __builtin_amdgcn_raw_buffer_store_b128(acc + (unsigned)decltype(G)::value, out_rs, lane * 16u + decltype(G)::value * 1024u, 0, 18); });
+    if (OUT_G == 0 && acc.x == 0x12345678u && acc.y == 0x9abcdef0u) *reinterpret_cast<u32x4*>(out) = acc;
+}
+
 static unsigned lds_for_waves(int waves) { return (160u * 1024u / (unsigned)(waves < 3 ? 3 : waves)) & ~1023u; }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -423,6 +447,18 @@ static int run_thin_w(unsigned type_bits, uint64_t n, int rounds)
     };
     cmp("fl_unpack_compare  x < k", FL_CMP_LT);
     cmp("fl_unpack_compare  x == k", FL_CMP_EQ);
+    for (int wv : {3, 4, 5, 6}) {
+        static char names[8][64];
+        snprintf(names[wv], 64, "fl_unpack_compare  x < k, launched at %d waves/SIMD", wv);
+        vs.push_back({names[wv], bytes, [=]() {
+            fl_internal_set_kernel_policy(2 + 256 * wv);
+            int rc = type_bits == 16 ? fl_u16_unpack_compare(W, (const uint16_t*)in, FL_CMP_LT, (uint16_t)((1u << W) / 2), n, (uint32_t*)out, nullptr)
+                   : type_bits == 8  ? fl_u8_unpack_compare(W, (const uint8_t*)in, FL_CMP_LT, (uint8_t)((1u << W) / 2), n, (uint32_t*)out, nullptr)
+                                     : fl_u32_unpack_compare(W, (const uint32_t*)in, FL_CMP_LT, (1u << W) / 2, n, (uint32_t*)out, nullptr);
+            fl_internal_set_kernel_policy(0);
+            if (rc != 0) { printf("unpack_compare failed %d\n", rc); exit(1); }
+        }, {}});
+    }
     vs.push_back({"fl_unpack_block_sums (8 B written per block)", (double)(in_b + n * 8), [=]() {
         int rc = type_bits == 16 ? fl_u16_unpack_block_sums(W, (const uint16_t*)in, n, (uint64_t*)out, nullptr)
                : type_bits == 8  ? fl_u8_unpack_block_sums(W, (const uint8_t*)in, n, (uint64_t*)out, nullptr)
@@ -545,6 +581,22 @@ static int run_pack64(int argc, char** argv)
             hipLaunchKernelGGL((k_stream_tuned<64, 17, 2>), dim3((unsigned)(tpx32 * 8)), dim3(256), 0, 0, (const u32x4*)in, (u32x4*)out, n_tiles, tpx32, sink); }, {}});
         vs.push_back({"read-only bare wave stream 8 KiB (no stores)", (double)in_b, [=]() {
             hipLaunchKernelGGL((k_bare_wave<8, 0, 2>), dim3((unsigned)(tpx * 8)), dim3(256), lds_for_waves(5), 0, (const char*)in, out, n, tpx, 128u * W); }, {}});
+    }
+    {
+        // windowed tile map (see k_bare_wave_windowed): window = 2^k tiles of 4 blocks (32 KiB of input each)
+        static char names[2][8][96];
+        int i = 0;
+        for (int k : {11, 14, 17, 19, 21}) {
+            const uint64_t wt = 1ull << k;
+            const uint64_t grid = (((n + 3) / 4 + wt - 1) / wt) * wt;
+            snprintf(names[0][i], 96, "bare wave stream, nt, 5 waves, WINDOWED map: %6.0f MiB of input per window", wt * 32768.0 / (1 << 20));
+            vs.push_back({names[0][i], bytes, [=]() {
+                hipLaunchKernelGGL((k_bare_wave_windowed<8, 3, 2>), dim3((unsigned)grid), dim3(256), lds_for_waves(5), 0, (const char*)in, out, n, wt, 128u * W); }, {}});
+            snprintf(names[1][i], 96, "read-only bare wave stream, WINDOWED map: %6.0f MiB per window", wt * 32768.0 / (1 << 20));
+            vs.push_back({names[1][i], (double)in_b, [=]() {
+                hipLaunchKernelGGL((k_bare_wave_windowed<8, 0, 2>), dim3((unsigned)grid), dim3(256), lds_for_waves(5), 0, (const char*)in, out, n, wt, 128u * W); }, {}});
+            ++i;
+        }
     }
     lib("fl_u64_pack(17) as shipped (again)", 0, 0, n);
     hipEvent_t e0, e1;

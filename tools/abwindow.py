@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""A/B of the tile-map window (fl_kernels.hpp: xcd_tile) for every kernel family, same buffers, launches interleaved round-robin.
+    python tools/abwindow.py [--reps 9] [--gb 48] [--windows 31,12,14,16,18,20]
+Window = log2 of the window in 1024-value blocks (fastlanes_amd_internal.h: policy bits 25-29); 31 = one window = the whole-column
+map of rounds 1-3; 0 = the library's own choice per kernel.  Prints GB/s of algorithmic bytes per (op, window)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fastlanes_amd as fl  # noqa: E402
+
+ESZ = {"u8": 1, "u16": 2, "u32": 4, "u64": 8}
+TDT = {"u8": torch.uint8, "u16": torch.uint16, "u32": torch.uint32, "u64": torch.uint64}
+dev = torch.device("cuda:0")
+lib = fl.load()
+
+
+def filled(nbytes, seed):
+    t = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if nbytes & ~7:
+        assert lib.fl_fill_random(t.data_ptr(), nbytes & ~7, seed, None) == 0
+    return t
+
+
+def case(op, ty, w, gb):
+    """(label, algorithmic bytes per launch, callable)"""
+    T, esz = ESZ[ty] * 8, ESZ[ty]
+    un, pk = 128 * T, 128 * w
+    per = {"unpack": pk + un, "pack": pk + un, "undelta_pack": pk + 128 + un, "delta": 2 * un + 128, "undelta": 2 * un + 128,
+           "transpose": 2 * un, "untranspose": 2 * un, "unpack_compare": pk + 128, "unpack_block_sums": pk + 8, "block_min_max": un + 2 * esz,
+           "unpack_mixed": 128 * (T + 1) / 2 + un, "transpose_delta_pack": pk + 128 + un, "undelta_pack_untranspose": pk + 128 + un}[op]
+    n = min(10_000_000, int(gb * 1e9 / per))
+    v = lambda t: t.view(TDT[ty])
+    if op in ("unpack", "undelta_pack", "undelta_pack_untranspose"):
+        src, dst = v(filled(n * pk, 1)), v(torch.empty(n * un, dtype=torch.uint8, device=dev))
+        if op == "unpack":
+            f = lambda: fl.BitPacking.unpack(w, src, output=dst)
+        else:
+            bases = v(filled(n * 128, 2))
+            g = getattr(fl.Delta, op)
+            f = lambda: g(w, src, bases, output=dst)
+    elif op in ("pack", "transpose_delta_pack"):
+        src, dst = v(filled(n * un, 1)), v(torch.empty(n * pk, dtype=torch.uint8, device=dev))
+        if op == "pack":
+            f = lambda: fl.BitPacking.pack(w, src, output=dst)
+        else:
+            bases = v(filled(n * 128, 2))
+            f = lambda: fl.Delta.transpose_delta_pack(w, src, bases, output=dst)
+    elif op in ("delta", "undelta"):
+        src, bases, dst = v(filled(n * un, 1)), v(filled(n * 128, 2)), v(torch.empty(n * un, dtype=torch.uint8, device=dev))
+        g = getattr(fl.Delta, op)
+        f = lambda: g(src, bases, output=dst)
+    elif op in ("transpose", "untranspose"):
+        src, dst = v(filled(n * un, 1)), v(torch.empty(n * un, dtype=torch.uint8, device=dev))
+        g = getattr(fl.Transpose, op)
+        f = lambda: g(src, output=dst)
+    elif op == "unpack_compare":
+        src, mask = v(filled(n * pk, 1)), torch.empty(n * 32, dtype=torch.int32, device=dev)
+        f = lambda: fl.BitPacking.unpack_compare(w, src, "<", (1 << w) // 2, output=mask)
+    elif op == "unpack_block_sums":
+        src, sums = v(filled(n * pk, 1)), torch.empty(n, dtype=torch.int64, device=dev)
+        f = lambda: fl.BitPacking.unpack_block_sums(w, src, output=sums)
+    elif op == "block_min_max":
+        src = v(filled(n * un, 1))
+        mm = (v(torch.empty(n * esz, dtype=torch.uint8, device=dev)), v(torch.empty(n * esz, dtype=torch.uint8, device=dev)))
+        f = lambda: fl.BitPacking.block_min_max(src, output=mm)
+    else:  # unpack_mixed: width[b] = 1 + b mod T
+        widths = (1 + torch.arange(n, dtype=torch.int64, device=dev) % T).to(torch.uint8)
+        offsets, total = fl.widths_to_offsets(ty, widths)
+        src, dst = v(filled(int(total.item()), 1)), v(torch.empty(n * un, dtype=torch.uint8, device=dev))
+        per = (int(total.item()) + n * un) / n
+        f = lambda: fl.unpack_widths(widths, offsets, src, output=dst, check=False)
+    return f"{op} {ty} W={w if op != 'unpack_mixed' else '1..T'} ({n} blocks)", n * per, f
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=9)
+    ap.add_argument("--gb", type=float, default=48.0)
+    ap.add_argument("--windows", default="31,12,14,16,18,20")
+    ap.add_argument("--cases", default="all")
+    args = ap.parse_args()
+    windows = [int(x) for x in args.windows.split(",")]
+    cases = [("unpack", "u32", 7), ("pack", "u32", 7), ("unpack", "u64", 17), ("pack", "u64", 17), ("undelta_pack", "u32", 12),
+             ("unpack_mixed", "u32", 0), ("unpack", "u16", 3), ("pack", "u16", 3), ("unpack", "u8", 3), ("pack", "u8", 3),
+             ("delta", "u32", 0), ("undelta", "u32", 0), ("transpose", "u32", 0), ("untranspose", "u64", 0),
+             ("transpose_delta_pack", "u32", 12), ("undelta_pack_untranspose", "u32", 12),
+             ("unpack_compare", "u16", 3), ("unpack_compare", "u32", 7), ("unpack_compare", "u64", 17),
+             ("unpack_block_sums", "u32", 7), ("unpack_block_sums", "u16", 3), ("block_min_max", "u32", 0)]
+    if args.cases != "all":
+        keep = args.cases.split(",")
+        cases = [c for c in cases if c[0] in keep]
+    print(f"# {lib.fl_version().decode()}\n# GB/s of algorithmic bytes (fraction of 8 TB/s), median of {args.reps} round-robin launches per window; window = log2 blocks, "
+          "31 = whole column (rounds 1-3), 0 = the library's per-kernel default", flush=True)
+    print(f"{'case':58s} " + " ".join(f"{('w=' + str(x)):>13s}" for x in [0] + windows), flush=True)
+    for op, ty, w in cases:
+        label, nbytes, f = case(op, ty, w, args.gb)
+        ms = {x: [] for x in [0] + windows}
+        for x in [0] + windows:           # warm every variant
+            lib.fl_internal_set_kernel_policy(x << 25)
+            f()
+        torch.cuda.synchronize()
+        for _ in range(args.reps):
+            for x in [0] + windows:
+                lib.fl_internal_set_kernel_policy(x << 25)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); f(); b.record(); b.synchronize()
+                ms[x].append(a.elapsed_time(b))
+        lib.fl_internal_set_kernel_policy(0)
+        row = []
+        for x in [0] + windows:
+            t = sorted(ms[x])[len(ms[x]) // 2]
+            row.append(f"{nbytes / t / 1e6:6.0f} ({nbytes / t / 8e9:.3f})")
+        print(f"{label:58s} " + " ".join(row), flush=True)
+        del f
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

@@ -249,16 +249,20 @@ def main():
         lib = fl.load()
         pols = [int(x, 0) for x in args.batch_policies.split(",")] if args.batch_policies else []
 
-        def timed(f, reps, warm=2):
-            for _ in range(warm):
-                f()
+        def interleaved(variants, reps):
+            """median ms of every variant, timed ROUND-ROBIN (one launch of each per round): a variant timed alone right after an
+            idle stretch runs at lower clocks than the ones after it -- round 3's batch-vs-contiguous gap was partly that"""
+            for _ in range(3):
+                for f in variants.values():
+                    f()
             torch.cuda.synchronize()
-            ms = []
+            ms = {k: [] for k in variants}
             for _ in range(reps):
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(); f(); b.record(); b.synchronize()
-                ms.append(a.elapsed_time(b))
-            return sorted(ms)[len(ms) // 2]
+                for k, f in variants.items():
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(); f(); b.record(); b.synchronize()
+                    ms[k].append(a.elapsed_time(b))
+            return {k: sorted(v)[len(v) // 2] for k, v in ms.items()}
 
         cases = [("u32", 7, "unpack"), ("u32", 12, "unpack"), ("u32", 20, "unpack")]
         if args.batch_all:
@@ -276,27 +280,33 @@ def main():
             outs = [un_all[a * opb:(a + 1) * opb] for a in range(n_arr)]
             batch = fl.Batch(packed, outs, [w] * n_arr)
             run = batch.unpack if op == "unpack" else batch.pack
-            t = timed(run, args.reps, 3)
+
+            def with_policy(pol):
+                def f():
+                    lib.fl_internal_set_kernel_policy(pol)
+                    run()
+                    lib.fl_internal_set_kernel_policy(0)
+                return f
+            # the yardstick: the same 640 000 blocks as ONE contiguous column through fl_<ty>_unpack / _pack, same buffers
+            if op == "unpack":
+                one = lambda: fl.BitPacking.unpack(w, pk_all, output=un_all)
+            else:
+                one = lambda: fl.BitPacking.pack(w, un_all, output=pk_all)
+            variants = {"batch": run, "contiguous": one}
+            variants.update({pol: with_policy(pol) for pol in pols})
+            med = interleaved(variants, max(args.reps, 15))
+            t, tc = med["batch"], med["contiguous"]
+            nbytes = n_arr * nb * (128 * w + 128 * T)
             for pol in pols:
                 # A/B of the batch kernel's launch shape on the same buffers (fastlanes_amd_internal.h: policy = 2 + 256 * waves/SIMD
                 # + 65536 * blocks per wavefront + 2^24 * prefetch)
-                lib.fl_internal_set_kernel_policy(pol)
-                tp = timed(run, args.reps)
-                lib.fl_internal_set_kernel_policy(0)
-                print(f"    policy waves={(pol >> 8) & 255} blocks/wave={(pol >> 16) & 255} prefetch={pol >> 24}: {tp:8.4f} ms  "
-                      f"{n_arr * nb * (128 * w + 128 * T) / tp / 8e9:.3f} of peak", flush=True)
+                print(f"    policy waves={(pol >> 8) & 255} blocks/wave={(pol >> 16) & 255} prefetch={pol >> 24}: {med[pol]:8.4f} ms  "
+                      f"{nbytes / med[pol] / 8e9:.3f} of peak", flush=True)
+            one()
+            want = (un_all if op == "unpack" else pk_all).clone()
+            (un_all if op == "unpack" else pk_all).zero_()
             run()
-            # the yardstick: the same 640 000 blocks as ONE contiguous column through fl_<ty>_unpack / _pack, same buffers
-            if op == "unpack":
-                got = un_all.clone()
-                one = lambda: fl.BitPacking.unpack(w, pk_all, output=un_all)
-            else:
-                got = pk_all.clone()
-                one = lambda: fl.BitPacking.pack(w, un_all, output=pk_all)
-            tc = timed(one, args.reps)
-            want = un_all if op == "unpack" else pk_all
-            same = torch.equal(want.view(torch.uint8), got.view(torch.uint8))
-            nbytes = n_arr * nb * (128 * w + 128 * T)
+            same = torch.equal(want.view(torch.uint8), (un_all if op == "unpack" else pk_all).view(torch.uint8))
             # the same arrays as one call each (what a chunk-at-a-time caller does today), through the raw C ABI
             f = getattr(lib, f"fl_{ty}_{op}")
             ptrs = [((p.data_ptr(), o.data_ptr()) if op == "unpack" else (o.data_ptr(), p.data_ptr())) for p, o in zip(packed, outs)]
@@ -311,7 +321,7 @@ def main():
                   f"{nbytes / t / 1e6:7.1f} GB/s ({nbytes / t / 8e9:.3f} of peak)  {'== one big ' + op if same else 'MISMATCH'} | "
                   f"the same blocks as one contiguous column, one call: {tc:8.4f} ms ({(t / tc - 1) * 100:+.1f} %) | one call per array: {t1:8.3f} ms  "
                   f"{n_arr * nb * 1024 / t1 / 1e6:7.1f} Gint/s  (x{t1 / t:.1f})", flush=True)
-            del batch, pk_all, un_all, want, got, packed, outs
+            del batch, pk_all, un_all, want, packed, outs
         return
     if args.cases == "refbench":
         # What the reference's own criterion benches time (besides benches/bitpacking.rs, which bench.py's headline and
