@@ -79,12 +79,18 @@ def parse():
                     help="control plane for the barrier / max-time reduction: auto = RCCL if every rank gets it working, "
                          "else gloo; nccl = the same (the fallback still applies, the line reports it); gloo = never try RCCL")
     ap.add_argument("--no-check", action="store_true", help="skip the per-rank oracle check of the timed output")
-    ap.add_argument("--placement", default="zoned", choices=("zoned", "separate"),
-                    help="zoned (default): a workload's input and output are carved from one allocation, the input inside one 64-GiB "
-                         "zone of the device memory, the output split over two "
-                         "(fastlanes_amd/placement.py; the same kernels on separately allocated buffers are timed next to it and "
-                         "reported as roofline.separate_allocations); "
-                         "separate: one allocation per buffer, wherever the driver puts it")
+    ap.add_argument("--placement", default="auto", choices=("auto", "zoned", "separate"),
+                    help="where a workload's buffers live in HBM moves every streaming kernel by a few per cent (DESIGN.md section 4). "
+                         "auto (default): both layouts below are allocated, filled and timed for a few launches before the timed region, "
+                         "the faster one is kept, both figures are reported (roofline.placement_probe); "
+                         "separate: one allocation per buffer, wherever the driver puts it; "
+                         "zoned: input and output carved from one allocation, the output centred on a 64-GiB multiple "
+                         "(fastlanes_amd/placement.py)")
+    ap.add_argument("--verify", default="auto", choices=("auto", "full", "sample"),
+                    help="what every rank checks of what it just timed, outside the timed region: sample = the first / last / sampled "
+                         "blocks of its slice against the oracle; full = that, plus two 64-bit content hashes per block of its WHOLE "
+                         "slice against the multithreaded CPU oracle decoding the same counter-based stream regenerated on the host "
+                         "(decode workloads) or a device-side round trip of the whole slice (pack); auto = full")
     ap.add_argument("--probe-nccl", action="store_true", help="with --dry-run: still attempt the RCCL probe (exercises the "
                     "fallback on a box without GPUs)")
     ap.add_argument("--inject-mismatch", type=int, default=-1, help="with --dry-run: pretend this rank's oracle check failed "
@@ -241,7 +247,7 @@ def cpu_baseline(args, ty, width, op):
 class Workload:
     """One rank's share of a workload: device buffers + step()."""
 
-    def __init__(self, name, n, first_block, rank, dev, placement="zoned"):
+    def __init__(self, name, n, first_block, rank, dev, placement="separate"):
         """placement: "zoned" = input and output carved from ONE allocation, the input at offset 0 (reads like to stay inside one
         64-GiB zone of the device memory), the output centred on a 64-GiB multiple (writes like to be split over two zones)
         (fastlanes_amd/placement.py; falls back to "separate" when the slab does not fit); "separate" = one torch allocation
@@ -271,7 +277,8 @@ class Workload:
                 dst = torch.empty(out_bytes, dtype=torch.uint8, device=dev)
                 self.placement = "separate"
             st = ctypes_stream(dev)
-            for t, seed in ((src, 1234 + rank), (aux, 99 + rank)):
+            self.src_seed, self.aux_seed = 1234 + rank, 99 + rank
+            for t, seed in ((src, self.src_seed), (aux, self.aux_seed)):
                 nb = t.numel() & ~7
                 if nb and lib.fl_fill_random(t.data_ptr(), nb, seed, st) != 0:
                     raise RuntimeError("fl_fill_random failed")
@@ -339,11 +346,98 @@ class Workload:
         return ok, len(blocks)
 
 
-def check_text(flags, n_checked):
+    def verify_full(self, threads, chunk=250_000):
+        """EVERY block of this rank's slice (SURVEY.md 8(d) "correctness at scale" (2)), outside the timed region.
+        Decode workloads: the input is a counter-based stream (fl_fill_random), so the host regenerates it chunk by chunk without a
+        PCIe transfer, the multithreaded CPU oracle decodes it, and two 64-bit content hashes per block (sum and position-weighted
+        sum, wrapping) of what the GPU wrote must equal the oracle's.  pack: unpack(pack(x)) == x & mask for the whole slice on
+        the device (the packed bytes themselves are compared with the oracle on the sampled blocks).
+        Returns (all equal, number of blocks verified)."""
+        import numpy as np
+        import torch
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle_lib import load_oracle
+        import fastlanes_amd as fl
+        o = load_oracle()
+        ty, width, op, n = self.ty, self.width, self.op, self.n
+        esz = ESZ[ty]
+        npdt = {"u8": np.uint8, "u16": np.uint16, "u32": np.uint32, "u64": np.uint64}[ty]
+        GOLDEN, M64 = 0x9E3779B97F4A7C15, (1 << 64) - 1
+        dev = self.dst.device
+        w_idx = torch.arange(1, 1025, dtype=torch.int64, device=dev)
+
+        def regenerated(seed, first_word, n_words):
+            """64-bit words [first_word, first_word + n_words) of fl_fill_random's stream `seed`, on the host"""
+            a = np.empty(n_words, dtype=np.uint64)
+            o.parallel_fill(a, 8, n_words, (seed * GOLDEN + first_word * GOLDEN) & M64, threads)
+            return a
+
+        def device_hashes(t):
+            """(sum, position-weighted sum) per 1024-value block of a device tensor, wrapping uint64"""
+            k = t.numel() // 1024
+            if ty == "u64":
+                vals = t.view(torch.int64).view(k, 1024)
+            elif ty == "u32":
+                vals = t.view(torch.int32).view(k, 1024).to(torch.int64) & 0xFFFFFFFF
+            elif ty == "u16":
+                vals = t.view(torch.int16).view(k, 1024).to(torch.int64) & 0xFFFF
+            else:
+                vals = t.view(torch.uint8).view(k, 1024).to(torch.int64)
+            return vals.sum(dim=1).cpu().numpy().view(np.uint64), (vals * w_idx).sum(dim=1).cpu().numpy().view(np.uint64)
+
+        verified = 0
+        if op == "pack":
+            mask = (1 << width) - 1
+            for k0 in range(0, n, chunk):
+                nb = min(chunk, n - k0)
+                pl = 1024 * width // (8 * esz)
+                back = fl.BitPacking.unpack(width, self.dst[k0 * pl:(k0 + nb) * pl])
+                want = self.src[k0 * 1024:(k0 + nb) * 1024]
+                if width < 8 * esz:
+                    want = (want.view(getattr(torch, TORCH_DT[ty].replace("u", ""))) & (mask if mask < (1 << 63) else -1)).view(want.dtype)
+                if not torch.equal(back.view(torch.uint8), want.view(torch.uint8)):
+                    return False, verified
+                verified += nb
+                del back, want
+            return True, verified
+        if op == "unpack_mixed":
+            offsets = self.offsets.cpu().numpy().view(np.uint64)
+            widths = self.widths.cpu().numpy()
+            total = int(self.in_bytes)
+        for k0 in range(0, n, chunk):
+            nb = min(chunk, n - k0)
+            if op == "unpack_mixed":
+                b0 = int(offsets[k0])
+                b1 = int(offsets[k0 + nb]) if k0 + nb < n else total
+                host_pk = regenerated(self.src_seed, b0 // 8, (b1 - b0) // 8).view(np.uint32)
+                rel = (offsets[k0:k0 + nb] - np.uint64(b0)).astype(np.uint64)
+                host_out = o.fast_unpack_mixed_u32(widths[k0:k0 + nb], rel, host_pk, nthreads=threads)
+            else:
+                wpb = 16 * width                                    # 64-bit words per packed block
+                host_pk = regenerated(self.src_seed, k0 * wpb, nb * wpb).view(npdt)
+                if op == "undelta_pack":
+                    host_bases = regenerated(self.aux_seed, k0 * 16, nb * 16).view(npdt)
+                    host_out = o.fast(op, ty, width, host_pk, aux=host_bases, n_blocks=nb, nthreads=threads)
+                else:
+                    host_out = o.fast("unpack", ty, width, host_pk, n_blocks=nb, nthreads=threads)
+            s_cpu, w_cpu = o.block_hashes(ty, host_out, threads)
+            s_gpu, w_gpu = device_hashes(self.dst[k0 * 1024:(k0 + nb) * 1024])
+            if not (np.array_equal(s_gpu, s_cpu) and np.array_equal(w_gpu, w_cpu)):
+                return False, verified
+            verified += nb
+            del host_pk, host_out
+        return True, verified
+
+
+def check_text(flags, n_checked, verified=None):
     if not flags:
         return None
     if all(flags):
-        return f"bit-exact vs oracle on {n_checked} blocks per rank (first, last and sampled blocks of every rank's slice)"
+        t = f"bit-exact vs oracle on {n_checked} blocks per rank (first, last and sampled blocks of every rank's slice)"
+        if verified:
+            t += (f"; every block of every rank's slice verified ({sum(verified)} blocks in all: content hashes vs the CPU oracle "
+                  "decoding the regenerated stream, or a device round trip for pack)")
+        return t
     return "MISMATCH vs oracle on rank(s) " + ",".join(str(r) for r, f in enumerate(flags) if not f)
 
 
@@ -538,7 +632,7 @@ def pmc_child(args):
     torch.cuda.synchronize()
     del a, b
     n = CONFIG5_BLOCKS if (WORKLOADS[args.workload][2] == "unpack_mixed" and args.blocks == 10_000_000) else args.blocks
-    w = Workload(args.workload, n, 0, 0, dev)
+    w = Workload(args.workload, n, 0, 0, dev, "separate")     # HBM traffic does not depend on where the buffers live
     for _ in range(3):
         w.step()
     torch.cuda.synchronize()
@@ -613,51 +707,96 @@ def roofline(w, kern_ms, traffic=None, traffic_source=None):
 
 
 def run_check(w, args, ctl):
-    """Per-rank oracle check; (flags of every rank, blocks compared per rank) or ([], 0) with --no-check."""
+    """Per-rank check of what was just timed; (flags of every rank, blocks compared with the oracle per rank, blocks fully verified
+    per rank) or ([], 0, []) with --no-check."""
     if args.no_check:
-        return [], 0
+        return [], 0, []
+    verified = 0
     try:
         ok, n_checked = w.check_against_oracle()
+        if ok and args.verify != "sample":
+            local = int(os.environ.get("LOCAL_WORLD_SIZE", str(ctl.world)))
+            ok, verified = w.verify_full(max(1, min(64, (os.cpu_count() or 1) // max(1, local))))
     except Exception as e:          # an unloadable checker is a failed check, not a crash that strands the other ranks
         print(f"rank {ctl.rank}: oracle check could not run: {e!r}", file=sys.stderr)
         ok, n_checked = False, 0
-    flags = [bool(v[0]) for v in ctl.gather([1.0 if ok else 0.0])]
-    return flags, n_checked
+    got = ctl.gather([1.0 if ok else 0.0, float(verified)])
+    return [bool(v[0]) for v in got], n_checked, [int(v[1]) for v in got]
 
 
 PLACEMENT_TEXT = {
     "zoned": "input and output carved from ONE allocation: the input at offset 0, the output centred on the 64-GiB multiple behind "
-             "it, where a fresh allocation changes from one class of device memory to the next, so that the kernel's concurrent "
-             "writes are split over two classes (fastlanes_amd/placement.py, DESIGN.md section 4); "
-             "roofline.separate_allocations = the same kernel on separately allocated buffers in the same run",
+             "it (fastlanes_amd/placement.py, DESIGN.md section 4)",
     "separate": "one torch allocation per buffer, wherever the driver puts it",
 }
 
 
-def separate_allocations_leg(name, n, first, rank, dev, args):
-    """The same workload on separately allocated buffers (the lottery the zoned placement removes), a few untimed-by-the-contract
-    launches next to the headline, for the record: {"GBps", "frac", "kernel_ms_avg"}."""
+def placement_text(placed, probe):
+    t = PLACEMENT_TEXT[placed]
+    if probe:
+        t += ("; chosen by measurement (--placement auto): a few launches on each layout before the timed region, GB/s " +
+              ", ".join(f"{k} {v:.0f}" for k, v in probe.items()))
+    return t
+
+
+def release(w):
+    """free a workload's device buffers NOW (w.step closes over w: without breaking the cycle they would outlive `del w`)"""
+    import gc
     import torch
-    try:
-        w = Workload(name, n, first, rank, dev, "separate")
-        for _ in range(2):
-            w.step()
-        torch.cuda.synchronize()
-        ms = []
-        for _ in range(max(5, args.steps // 2)):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(); w.step(); b.record(); b.synchronize()
-            ms.append(a.elapsed_time(b))
-        avg = sum(ms) / len(ms)
-        gbps = w.bytes / (avg / 1e3) / 1e9
-        del w
-        torch.cuda.empty_cache()
-        return {"GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4), "kernel_ms_avg": round(avg, 4)}
-    except Exception as e:          # a comparison figure must never take the bench down
-        return {"error": repr(e)[:200]}
+    if w is not None:
+        w.step = w.src = w.dst = w.bases = w.slab = None
+    gc.collect()
+    torch.cuda.empty_cache()
 
 
-def config5_leg(args, world, rank, dev, ctl, w=None, place="zoned"):
+def probe_rate(w, launches=5):
+    """GB/s (median of a few launches) of a workload's kernel on the buffers it holds"""
+    import torch
+    for _ in range(2):
+        w.step()
+    torch.cuda.synchronize()
+    ms = []
+    for _ in range(launches):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); w.step(); b.record(); b.synchronize()
+        ms.append(a.elapsed_time(b))
+    return w.bytes / (sorted(ms)[len(ms) // 2] / 1e3) / 1e9
+
+
+def placed_workload(name, n, first, rank, dev, args, single_device=False):
+    """(workload, {"layout": GB/s of the probe, ...} or None).  --placement auto: where a column lives in HBM moves the same kernel
+    by a few per cent, differently per workload and per box, and nothing in an address tells: so both layouts
+    are allocated and filled, each is timed for a few launches, the slower one is freed and the faster one -- the very buffers that
+    were probed -- goes into the timed region.  The choice is a measurement made before the timed region; both figures go into the
+    line.  A layout that does not fit next to the other one is skipped."""
+    if single_device:               # several ranks on one device: no room for a slab each
+        return Workload(name, n, first, rank, dev, "separate"), None
+    if args.placement != "auto":
+        return Workload(name, n, first, rank, dev, args.placement), None
+    best, probe = None, {}
+    for layout in ("separate", "zoned"):
+        w = None
+        try:
+            w = Workload(name, n, first, rank, dev, layout)
+            if w.placement != layout:          # the zoned slab did not fit: Workload fell back to separate buffers
+                raise MemoryError(layout)
+            rate = probe_rate(w)
+        except Exception as e:                 # a candidate that cannot be built (out of memory next to the other one) is no candidate
+            if best is None and layout == "zoned":
+                raise
+            print(f"rank {rank}: placement candidate '{layout}' skipped: {e!r}"[:300], file=sys.stderr)
+            release(w)
+            continue
+        probe[layout] = round(rate, 1)
+        if best is None or rate > probe[best.placement]:
+            release(best)
+            best = w
+        else:
+            release(w)
+    return best, probe
+
+
+def config5_leg(args, world, rank, dev, ctl):
     """BASELINE.json configs[4], STRONG scaling: the 10 B-integer u32 column (9 765 625 blocks, width[b] = 1 + b mod 32)
     sharded by contiguous block range over the ranks (no collective on the data path).  `w` = this rank's slice, already
     resident in HBM (main() builds both legs' columns before anything is timed)."""
@@ -667,12 +806,11 @@ def config5_leg(args, world, rank, dev, ctl, w=None, place="zoned"):
         per_rank = ctl.gather([float(n), 0.0, 0.0])
         return {"dry_run": True, "per_rank": [{"rank": r, "first_block": block_range(CONFIG5_BLOCKS, world, r)[0],
                                                "blocks": int(v[0])} for r, v in enumerate(per_rank)]}
-    if w is None:
-        w = Workload("u32_mixed_unpack", n, first, rank, dev, place)
+    w, probe = placed_workload("u32_mixed_unpack", n, first, rank, dev, args, args.single_device)
     elapsed, kern_ms = timed_region(w.step, args, ctl)
     avg_ms = sum(kern_ms) / len(kern_ms)
     per_rank = ctl.gather([float(n), avg_ms, float(w.bytes)])
-    flags, n_checked = run_check(w, args, ctl)
+    flags, n_checked, verified = run_check(w, args, ctl)
     if rank != 0:
         return {"flags": flags}
     traffic = source = None
@@ -680,7 +818,6 @@ def config5_leg(args, world, rank, dev, ctl, w=None, place="zoned"):
     import torch
     w.src = w.dst = w.slab = None            # measured and checked (the PMC child builds its own copy of the column)
     torch.cuda.empty_cache()
-    separate = separate_allocations_leg("u32_mixed_unpack", n, first, rank, dev, args) if (world == 1 and placed == "zoned") else None
     if world == 1 and not args.no_pmc:
         live = live_pmc_traffic(args, "u32_mixed_unpack")
         if live is not None:
@@ -693,6 +830,7 @@ def config5_leg(args, world, rank, dev, ctl, w=None, place="zoned"):
               "frac": round(v[2] / (v[1] / 1e3) / 1e9 / HBM_PEAK_GBPS, 4)} for r, v in enumerate(per_rank)]
     for r, f in enumerate(flags):
         ranks[r]["correct"] = f
+        ranks[r]["verified_blocks"] = verified[r]
     return {
         "metric": "billion integers/sec decoded (u32 mixed widths 1-32, 10 B-integer column sharded over the GPUs)",
         "workload": "unpack u32 width[b] = 1 + b mod 32, 9 765 625 blocks in total (BASELINE.json configs[4]); widths[] / "
@@ -705,9 +843,9 @@ def config5_leg(args, world, rank, dev, ctl, w=None, place="zoned"):
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "aggregate_GBps": round(sum(v[2] for v in per_rank) * args.steps / elapsed / 1e9, 1),
         "per_rank": ranks,
-        "roofline_rank0": dict(roofline(w, kern_ms, traffic, source), **({"separate_allocations": separate} if separate else {})),
-        "placement": PLACEMENT_TEXT[placed],
-        "correctness": check_text(flags, n_checked),
+        "roofline_rank0": dict(roofline(w, kern_ms, traffic, source), **({"placement_probe_GBps": probe} if probe else {})),
+        "placement": placement_text(placed, probe),
+        "correctness": check_text(flags, n_checked, verified),
         "flags": flags,
     }
 
@@ -774,16 +912,14 @@ def main():
     import fastlanes_amd as fl
     fl.load()  # fails loudly if the HIP extension is missing
 
-    place = "separate" if args.single_device else args.placement     # several ranks on one device: no room for a slab each
-    w = Workload(args.workload, n, first, rank, dev, place)
+    w, probe = placed_workload(args.workload, n, first, rank, dev, args, args.single_device)
     elapsed, kern_ms = timed_region(w.step, args, ctl)
     avg_ms = sum(kern_ms) / len(kern_ms)
     per_rank = ctl.gather([float(n), avg_ms, float(w.bytes)])
-    flags, n_checked = run_check(w, args, ctl)       # every rank, its own slice, outside the timed region
+    flags, n_checked, verified = run_check(w, args, ctl)       # every rank, its own slice, outside the timed region
     placed = w.placement
     w.src = w.dst = w.bases = w.slab = None          # leg 1 is measured and checked: its column can go
     torch.cuda.empty_cache()
-    separate = separate_allocations_leg(args.workload, n, first, rank, dev, args) if (rank == 0 and world == 1 and placed == "zoned") else None
 
     # ---- rank 0, N=1: the cpu_baseline leg (with the checks, the only place bench.py touches oracle/)
     cpu = None
@@ -822,6 +958,7 @@ def main():
                   "GBps": round(v[2] / (v[1] / 1e3) / 1e9, 1)} for r, v in enumerate(per_rank)]
         for r, f in enumerate(flags):
             ranks[r]["correct"] = f
+            ranks[r]["verified_blocks"] = verified[r]
         out = {
             # BASELINE.json "metric", verbatim, for the headline workload
             "metric": "billion integers/sec decoded (u32 width-7) + achieved HBM GB/s vs peak, 1-8 GPU"
@@ -841,11 +978,11 @@ def main():
             "config": {"workload": workload, "blocks_per_gpu": n, "sharding": "contiguous block range per GPU, no collective"},
             "roofline": roofline(w, kern_ms, traffic, traffic_source),
             "per_rank": ranks,
-            "correctness": check_text(flags, n_checked),
+            "correctness": check_text(flags, n_checked, verified),
         }
-        out["config"]["placement"] = PLACEMENT_TEXT[placed]
-        if separate is not None:
-            out["roofline"]["separate_allocations"] = separate
+        out["config"]["placement"] = placement_text(placed, probe)
+        if probe:
+            out["roofline"]["placement_probe_GBps"] = probe
         out.update(control)
         if cpu is not None:
             out["cpu_baseline"] = cpu
@@ -853,7 +990,7 @@ def main():
     # ---- second leg: BASELINE.json configs[4] strong-scaled over the same ranks ------------------
     bad = not all(flags)
     if not args.no_config5 and not strong_main:
-        c5 = config5_leg(args, world, rank, dev, ctl, None, place)
+        c5 = config5_leg(args, world, rank, dev, ctl)
         bad = bad or not all(c5.pop("flags"))
         if rank == 0:
             out["config5_strong"] = c5

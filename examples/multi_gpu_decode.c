@@ -33,19 +33,19 @@
 #include "fastlanes_amd.h"
 
 #define MAX_THREADS 64
-/* The device memory behaves as 64-GiB zones: a kernel whose input and output share a zone streams ~8 % slower than one whose
- * buffers lie in different zones, and fastest when its OUTPUT is split over two zones (writes like to be spread, reads like to
- * stay inside one zone: DESIGN.md section 4).  Two separate hipMalloc calls land wherever the driver puts them; inside ONE
- * allocation the zone boundaries lie at multiples of 64 GiB -- so each leg carves its buffers from one slab: the input at 0, the
- * output centred on the slab's 64-GiB offset (the layout of fastlanes_amd/placement.py). */
+/* Where a column lives in HBM moves the same kernel by a few per cent; nothing in an address tells which
+ * layout is the fast one on a given box, and the library takes any 16-byte aligned pointers.  Default: two plain hipMalloc's.
+ * --zoned carves each leg's buffers from ONE allocation instead -- the input at 0, the output centred on the slab's 64-GiB offset
+ * (the other layout bench.py's --placement auto times; fastlanes_amd/placement.py). */
 #define ZONE_BYTES ((size_t)64 << 30)
+static int g_zoned = 0;
 
 /* two separate allocations if the slab does not fit (or the input would run into the output) */
 static int alloc_pair(size_t in_bytes, size_t out_bytes, void **slab, void **in, void **out)
 {
     const size_t out_off = (ZONE_BYTES - out_bytes / 2) & ~(size_t)255;
     *slab = NULL;
-    if (out_bytes / 2 <= ZONE_BYTES && in_bytes <= out_off && hipMalloc(slab, out_off + (out_bytes ? out_bytes : 16)) == hipSuccess) {
+    if (g_zoned && out_bytes / 2 <= ZONE_BYTES && in_bytes <= out_off && hipMalloc(slab, out_off + (out_bytes ? out_bytes : 16)) == hipSuccess) {
         *in = *slab;
         *out = (char *)*slab + out_off;
         return 0;
@@ -120,24 +120,26 @@ typedef int (*launch_fn)(void *ctx, hipStream_t st);
 
 static int timed_leg(worker_t *wk, hipStream_t st, launch_fn launch, void *ctx, double *kernel_ms, double *wall_s)
 {
+    /* ALWAYS passes both barriers, whatever fails: the other threads wait in them (the caller counts two per call) */
     hipEvent_t e0 = NULL, e1 = NULL;
     int rc = FL_OK;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return FL_ERR_HIP;
+    if (hipEventCreate(&e0) != hipSuccess) { e0 = NULL; rc = FL_ERR_HIP; }
+    if (rc == FL_OK && hipEventCreate(&e1) != hipSuccess) { e1 = NULL; rc = FL_ERR_HIP; }
     for (int i = 0; i < wk->warmup && rc == FL_OK; ++i) rc = launch(ctx, st);
     if (hipStreamSynchronize(st) != hipSuccess) rc = FL_ERR_HIP;
     pthread_barrier_wait(wk->bar);                 /* every device starts its K steps together ... */
     const double t0 = now_s();
-    (void)hipEventRecord(e0, st);
+    if (rc == FL_OK && hipEventRecord(e0, st) != hipSuccess) rc = FL_ERR_HIP;
     for (int i = 0; i < wk->steps && rc == FL_OK; ++i) rc = launch(ctx, st);
-    (void)hipEventRecord(e1, st);
+    if (rc == FL_OK && hipEventRecord(e1, st) != hipSuccess) rc = FL_ERR_HIP;
     if (hipStreamSynchronize(st) != hipSuccess) rc = FL_ERR_HIP;
     *wall_s = now_s() - t0;
     pthread_barrier_wait(wk->bar);                 /* ... and the leg ends when the slowest one is done */
     float ms = 0.f;
     if (rc == FL_OK && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = FL_ERR_HIP;
     *kernel_ms = (double)ms / (wk->steps > 0 ? wk->steps : 1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
     return rc;
 }
 

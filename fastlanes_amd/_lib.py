@@ -94,6 +94,14 @@ def load():
             f"{LIB_PATH} not found: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C fastlanes_amd/csrc). "
             "fastlanes_amd has no CPU fallback.")
+    # ONE HIP runtime per process: PyTorch ships its own libamdhip64.so, libfastlanes_amd.so is linked against /opt/rocm's.  Whichever
+    # is loaded first serves both (same SONAME) -- but if this library came first, torch would still load its bundled copy next to
+    # it, and a kernel launched through one runtime on memory allocated through the other fails with hipErrorNoDevice (seen in
+    # round 4).  The Python mirror exists to be used with torch tensors, so torch goes first whenever it is installed.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     lib.fl_version.restype = ctypes.c_char_p
     lib.fl_status_string.restype = ctypes.c_char_p

@@ -122,7 +122,7 @@ hipError_t launch_batch(const BatchArgs& b0, uint32_t max_blocks, int waves, hip
     b.window_shift = tile_window_shift(PACK ? TRAFFIC_READ : TRAFFIC_WRITE, (unsigned)tile_blocks);
     const unsigned lds = widths_lds_bytes<T>(waves, b.prefetch ? b.bpw : 1u);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_batch<T, PACK>), dim3((unsigned)(b.tiles_per_xcd * 8)), dim3(WG), lds, s, b);
+    FL_LAUNCH((k_batch<T, PACK>), dim3((unsigned)(b.tiles_per_xcd * 8)), dim3(WG), lds, s, b);
     return hipGetLastError();
 }
 

@@ -126,6 +126,49 @@ template <typename T> __device__ __forceinline__ Cell<T> cell_from_group_below(c
     return __builtin_bit_cast(Cell<T>, r);
 }
 
+#ifdef FL_TEST_R03_REGISTER_SCAN
+// KNOWN-BAD, never built into libfastlanes_amd.so (make BADSCAN=1 -> libfastlanes_amd_badscan.so only): round 3's register-only
+// form of the lane-group scan (DPP + v_permlane16/32_swap instead of ds_bpermute).  It passed every per-(T, W) parity test and was
+// wrong on ~3 % of the blocks of a u64 undelta_pack, differently on every run, with all CUs busy (profiles/abscan_r03.txt), and was
+// dropped.  It is kept behind this macro for one purpose: to show that tests/test_gpu_full_check.py catches that class of error
+// (profiles/full_check_r04.txt).
+template <typename T> __device__ __forceinline__ Cell<T> scan_lane_groups_r03(Cell<T> v, unsigned lane)
+{
+    const bool odd_row = lane & 16u, upper_half = lane & 32u;
+    auto upper_group_to_both = [](const Cell<T>& x) {
+        u32x4 w = __builtin_bit_cast(u32x4, x), r;
+        for (int k = 0; k < 4; ++k) r[k] = (uint32_t)__builtin_amdgcn_update_dpp((int)w[k], (int)w[k], 0x108 /* row_shl:8 */, 0xF, 0xF, false);
+        return r;
+    };
+    {
+        const u32x4 w = __builtin_bit_cast(u32x4, v);
+        u32x4 below;
+        for (int k = 0; k < 4; ++k) below[k] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[k], 0x118 /* row_shr:8 */, 0xF, 0xF, true);
+        v = v.add(__builtin_bit_cast(Cell<T>, below));
+    }
+    {
+        const u32x4 t = upper_group_to_both(v);
+        u32x4 below;
+        for (int k = 0; k < 4; ++k) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(t[k], t[k], false, false);
+            below[k] = odd_row ? (uint32_t)sw[0] : 0u;
+        }
+        v = v.add(__builtin_bit_cast(Cell<T>, below));
+    }
+    {
+        const u32x4 t = upper_group_to_both(v);
+        u32x4 below;
+        for (int k = 0; k < 4; ++k) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(t[k], t[k], false, false);
+            const auto hf = __builtin_amdgcn_permlane32_swap(sw[1], sw[1], false, false);
+            below[k] = upper_half ? (uint32_t)hf[0] : 0u;
+        }
+        v = v.add(__builtin_bit_cast(Cell<T>, below));
+    }
+    return v;
+}
+#endif
+
 // n x n element tile: in[j] = cell of row j (n lanes), out[e] = cell of lane e (n rows)  -- and back (the map is an involution)
 template <typename T> __device__ __forceinline__ void tile_transpose(const Cell<T>* in, Cell<T>* out)
 {
@@ -243,12 +286,16 @@ __global__ __launch_bounds__(WG) void k_chain(ChainArgs a)
         // scan of the segment totals over the 8 lane groups (Hillis-Steele, 3 steps), base entering at segment 0
         if (i == 0) x[0] = x[0].add(base);
         static_for<R - 1>([&](auto J) { x[decltype(J)::value + 1] = x[decltype(J)::value + 1].add(x[decltype(J)::value]); });
+#ifdef FL_TEST_R03_REGISTER_SCAN
+        const Cell<T> excl = scan_lane_groups_r03<T>(x[R - 1], lane).sub(x[R - 1]);      // KNOWN-BAD test build only (see above)
+#else
         Cell<T> incl = x[R - 1];
         static_for<3>([&](auto S) {
             constexpr unsigned d = 1u << decltype(S)::value;
             incl = incl.add(cell_from_group_below<T>(incl, lane, d));
         });
         const Cell<T> excl = cell_from_group_below<T>(incl, lane, 1);
+#endif
         static_for<R>([&](auto J) { x[decltype(J)::value] = x[decltype(J)::value].add(excl); });
     }
     // the source image is dead once every lane has taken its rows (lanes re-use other lanes' cells below, except ROWS -> ROWS)
@@ -310,7 +357,7 @@ hipError_t launch_chain(const ChainArgs& a0, int waves, hipStream_t s)
     const unsigned need = (WG / 64) * chain_wave_lds<T, SRC, SNK>();
     if (waves < 3) waves = 3;
     const unsigned pad = (CU_LDS_BYTES / (unsigned)waves) & ~1023u;
-    hipLaunchKernelGGL((k_chain<T, SRC, BODY, SNK, RD>), dim3((unsigned)(a.tiles_per_xcd * 8)), dim3(WG), pad > need ? pad : need, s, a);
+    FL_LAUNCH((k_chain<T, SRC, BODY, SNK, RD>), dim3((unsigned)(a.tiles_per_xcd * 8)), dim3(WG), pad > need ? pad : need, s, a);
     return hipGetLastError();
 }
 

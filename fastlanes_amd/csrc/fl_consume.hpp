@@ -533,7 +533,7 @@ template <typename T, int W, bool IS_EQ> hipError_t launch_unpack_compare(const 
     constexpr unsigned STATIC_LDS = sizeof(T) >= 4 ? 0u : BLOCKS_PER_WG * 144u;
     unsigned pad = 0;
     if (waves >= 3 && waves < 8) pad = ((160u * 1024u / (unsigned)waves) & ~1023u) - STATIC_LDS;   // < 64 KiB for waves >= 3
-    hipLaunchKernelGGL((k_unpack_compare<T, W, IS_EQ>), dim3((unsigned)(a.tiles_per_xcd * 8)), dim3(WG), pad, s, a);
+    FL_LAUNCH((k_unpack_compare<T, W, IS_EQ>), dim3((unsigned)(a.tiles_per_xcd * 8)), dim3(WG), pad, s, a);
     return hipGetLastError();
 }
 template <typename T> struct CompareTable { compare_launch_t fn[Elem<T>::BITS + 1]; };
@@ -559,7 +559,7 @@ template <typename T, int W> hipError_t launch_unpack_block_sums(const ReduceArg
     if (a0.n_blocks == 0) return hipSuccess;
     ReduceArgs a = a0;
     const unsigned grid = plan_grid(a);
-    hipLaunchKernelGGL((k_unpack_block_sums<T, W>), dim3(grid), dim3(WG), 0, s, a);
+    FL_LAUNCH((k_unpack_block_sums<T, W>), dim3(grid), dim3(WG), 0, s, a);
     return hipGetLastError();
 }
 template <typename T> hipError_t launch_block_min_max(const ReduceArgs& a0, hipStream_t s)
@@ -567,7 +567,7 @@ template <typename T> hipError_t launch_block_min_max(const ReduceArgs& a0, hipS
     if (a0.n_blocks == 0) return hipSuccess;
     ReduceArgs a = a0;
     const unsigned grid = plan_grid(a);
-    hipLaunchKernelGGL((k_block_min_max<T>), dim3(grid), dim3(WG), 0, s, a);
+    FL_LAUNCH((k_block_min_max<T>), dim3(grid), dim3(WG), 0, s, a);
     return hipGetLastError();
 }
 

@@ -36,6 +36,13 @@ namespace fl {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
+// Every kernel launch of the library.  hipGetLastError() reports the calling thread's most recent HIP error, whoever caused
+// it: a host framework's benign failure before our launch (an event query that is not ready yet, a pointer-attribute lookup
+// on plain host memory) would come back as OUR launch failing (seen in round 4: fl_fill_random returned FL_ERR_HIP as the
+// first call after torch had created a stream).  So the slot is cleared first, and the launchers' closing hipGetLastError()
+// reports this launch only.
+#define FL_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 // lib.rs:22 FL_ORDER = [0,4,2,6,1,5,3,7], nibble-packed so it folds.
 __host__ __device__ constexpr int fl_order(int o) { return (0x73516240u >> (4 * o)) & 7; }
 

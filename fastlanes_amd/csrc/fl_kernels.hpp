@@ -371,7 +371,7 @@ hipError_t launch_unpack(const StreamArgs& a0, hipStream_t s)
     if (a0.n_blocks == 0) return hipSuccess;
     StreamArgs a = a0;
     const unsigned grid = plan_grid(a, TRAFFIC_WRITE);
-    hipLaunchKernelGGL((k_unpack<T, W, BODY>), dim3(grid), dim3(WG), 0, s, a);
+    FL_LAUNCH((k_unpack<T, W, BODY>), dim3(grid), dim3(WG), 0, s, a);
     return hipGetLastError();
 }
 template <typename T, int W, int MODE>
@@ -380,7 +380,7 @@ hipError_t launch_pack(const StreamArgs& a0, hipStream_t s)
     if (a0.n_blocks == 0 || W == 0) return hipSuccess;
     StreamArgs a = a0;
     const unsigned grid = plan_grid(a, TRAFFIC_READ);
-    hipLaunchKernelGGL((k_pack<T, W, MODE>), dim3(grid), dim3(WG), 0, s, a);
+    FL_LAUNCH((k_pack<T, W, MODE>), dim3(grid), dim3(WG), 0, s, a);
     return hipGetLastError();
 }
 template <typename T, bool INVERSE>
@@ -389,7 +389,7 @@ hipError_t launch_delta(const StreamArgs& a0, hipStream_t s)
     if (a0.n_blocks == 0) return hipSuccess;
     StreamArgs a = a0;
     const unsigned grid = plan_grid(a, TRAFFIC_BALANCED);
-    hipLaunchKernelGGL((k_delta<T, INVERSE>), dim3(grid), dim3(WG), 0, s, a);
+    FL_LAUNCH((k_delta<T, INVERSE>), dim3(grid), dim3(WG), 0, s, a);
     return hipGetLastError();
 }
 

@@ -67,7 +67,7 @@ hipError_t launch_transpose(const StreamArgs& a0, hipStream_t s)
     if (a0.n_blocks == 0) return hipSuccess;
     StreamArgs a = a0;
     const unsigned grid = plan_grid(a, TRAFFIC_BALANCED);
-    hipLaunchKernelGGL((k_transpose<T, INVERSE>), dim3(grid), dim3(WG), 0, s, a);
+    FL_LAUNCH((k_transpose<T, INVERSE>), dim3(grid), dim3(WG), 0, s, a);
     return hipGetLastError();
 }
 
@@ -150,7 +150,7 @@ template <typename T>
 hipError_t launch_unpack_single(const SingleArgs& a, hipStream_t s)
 {
     if (a.n_indices == 0) return hipSuccess;
-    hipLaunchKernelGGL((k_unpack_single<T>), dim3((unsigned)((a.n_indices + WG - 1) / WG)), dim3(WG), 0, s, a);
+    FL_LAUNCH((k_unpack_single<T>), dim3((unsigned)((a.n_indices + WG - 1) / WG)), dim3(WG), 0, s, a);
     return hipGetLastError();
 }
 

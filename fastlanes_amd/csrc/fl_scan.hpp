@@ -106,9 +106,9 @@ inline hipError_t launch_widths_to_offsets(const ScanArgs& a, hipStream_t s)
         return hipSuccess;
     }
     const unsigned n_chunks = (unsigned)((a.n_blocks + SCAN_CHUNK - 1) / SCAN_CHUNK);
-    hipLaunchKernelGGL(k_scan_local, dim3(n_chunks), dim3(WG), 0, s, a);
-    hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(WG), 0, s, a);
-    hipLaunchKernelGGL(k_scan_add, dim3(n_chunks), dim3(WG), 0, s, a);
+    FL_LAUNCH(k_scan_local, dim3(n_chunks), dim3(WG), 0, s, a);
+    FL_LAUNCH(k_scan_chunks, dim3(1), dim3(WG), 0, s, a);
+    FL_LAUNCH(k_scan_add, dim3(n_chunks), dim3(WG), 0, s, a);
     return hipGetLastError();
 }
 
@@ -134,7 +134,7 @@ inline hipError_t launch_fill_random(uint64_t* dst, uint64_t n_words, uint64_t s
 {
     if (n_words == 0) return hipSuccess;
     const uint64_t want = (n_words + WG - 1) / WG;
-    hipLaunchKernelGGL(k_fill_splitmix64, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(WG), 0, s, dst, n_words, seed);
+    FL_LAUNCH(k_fill_splitmix64, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(WG), 0, s, dst, n_words, seed);
     return hipGetLastError();
 }
 

@@ -610,8 +610,8 @@ hipError_t launch_widths(const WidthsArgs& a0, int waves, hipStream_t s)
     if (a.bpw < 2 || a.bpw > 16) a.prefetch = 0;
     const unsigned lds = widths_lds_bytes<T>(waves, a.prefetch ? a.bpw : 1u);
     if (lds > 64 * 1024) return hipErrorInvalidValue;         // beyond the default dynamic-LDS limit
-    if constexpr (PACK) hipLaunchKernelGGL((k_pack_widths<T, RD>), grid, dim3(WG), lds, s, a);
-    else hipLaunchKernelGGL((k_unpack_widths<T, RD>), grid, dim3(WG), lds, s, a);
+    if constexpr (PACK) FL_LAUNCH((k_pack_widths<T, RD>), grid, dim3(WG), lds, s, a);
+    else FL_LAUNCH((k_unpack_widths<T, RD>), grid, dim3(WG), lds, s, a);
     return hipGetLastError();
 }
 

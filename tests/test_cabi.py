@@ -187,6 +187,7 @@ def test_functor_api_example_builds():
     sos = ge.build_examples()
     assert hasattr(ctypes.CDLL(sos["fused_dict_decode"]), "example_dict_unpack_u32_w8")
     assert hasattr(ctypes.CDLL(sos["iterate_running_max"]), "example_running_max_u32")
+    assert hasattr(ctypes.CDLL(sos["fused_for_pack"]), "example_min_for_pack_u32")            # the pack_rows (pack!) counterpart
     assert os.access(sos["column_decode"], os.X_OK)          # the plain-C caller links against the C ABI
 
 

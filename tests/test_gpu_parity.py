@@ -846,6 +846,76 @@ def test_functor_api_user_kernel_on_iterate_rows(fl, oracle):
     assert np.array_equal(got, wsum)
 
 
+def test_fl_check_device_refuses_foreign_pointers():
+    """FL_CHECK_DEVICE=1 (include/fastlanes_amd.h "Threading and device selection"): every device-tier entry verifies that its
+    pointers are memory the current device can use and that the stream is one of its streams, and returns FL_ERR_DEVICE (7)
+    instead of launching.  The variable is read once per process, hence a child process.  Without it the same call with a host
+    pointer is undefined behaviour, exactly like a raw kernel launch -- not exercised."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.getcwd())
+import fastlanes_amd as fl
+lib = fl.load()
+n = 8
+dev_pk = torch.zeros(n * 224, dtype=torch.int32, device="cuda:0")
+dev_out = torch.zeros(n * 1024, dtype=torch.int32, device="cuda:0")
+host = np.zeros(n * 1024, dtype=np.uint32)
+pinned = torch.zeros(n * 1024, dtype=torch.int32).pin_memory()
+st = torch.cuda.Stream()
+res = {
+    "device_ok": lib.fl_u32_unpack(7, dev_pk.data_ptr(), dev_out.data_ptr(), n, None),
+    "stream_ok": lib.fl_u32_unpack(7, dev_pk.data_ptr(), dev_out.data_ptr(), n, ctypes.c_void_p(st.cuda_stream)),
+    "host_out": lib.fl_u32_unpack(7, dev_pk.data_ptr(), host.ctypes.data, n, None),
+    "host_in": lib.fl_u32_pack(7, host.ctypes.data, dev_pk.data_ptr(), n, None),
+    "pinned_out": lib.fl_u32_unpack(7, dev_pk.data_ptr(), pinned.data_ptr(), n, None),
+    "fill_host": lib.fl_fill_random(host.ctypes.data, 4096, 1, None),
+    "null_is_not_a_device_error": lib.fl_u32_unpack(7, None, dev_out.data_ptr(), n, None),
+    "host_widths": lib.fl_u32_unpack_widths(host.ctypes.data, dev_out.data_ptr(), dev_pk.data_ptr(), 896 * n, dev_out.data_ptr(), n, None, None),
+}
+torch.cuda.synchronize()
+print(res)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root, env=dict(os.environ, FL_CHECK_DEVICE="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = eval([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert res == {"device_ok": 0, "stream_ok": 0, "host_out": 7, "host_in": 7, "pinned_out": 0, "fill_host": 7,
+                   "null_is_not_a_device_error": 3, "host_widths": 7}, res
+
+
+def test_functor_api_user_kernel_on_pack_rows(fl, oracle):
+    """examples/fused_for_pack.hip: a body spliced into fl::pack_rows (the pack! counterpart, macros.rs:34-98) -- frame-of-reference
+    encoding with the reference (the block's minimum) computed in the same kernel.  Specified as the oracle composition
+    for_pack::<W>(v, min(v)) (ffor.rs:24-36), every width, ragged block count; and the library's unfor_pack with those
+    minima brings the values back wherever W covers their range."""
+    import ctypes
+    import torch
+    import __graft_entry__ as ge
+    lib = ctypes.CDLL(ge.build_examples()["fused_for_pack"])
+    lib.example_min_for_pack_u32.argtypes = [ctypes.c_uint] + [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p]
+    n = 45
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for w in range(33):
+        # values spread over a window of 2^w above a per-block floor, so that W bits hold value - min exactly
+        floor = values("u32", n, 700 + w) >> np.uint32(1)
+        v = (np.repeat(floor, 1024) + values("u32", n * 1024, 800 + w, bits=max(w - 1, 0)) if w else np.repeat(floor, 1024)).astype(np.uint32)
+        dv = to_dev(v)
+        pk = torch.zeros(max(n * 32 * w, 4), dtype=torch.uint32, device="cuda:0")
+        mins = torch.zeros(n, dtype=torch.uint32, device="cuda:0")
+        assert lib.example_min_for_pack_u32(w, dv.data_ptr(), pk.data_ptr(), mins.data_ptr(), n, st) == 0
+        torch.cuda.synchronize()
+        want_min = v.reshape(n, 1024).min(axis=1)
+        assert np.array_equal(to_np(mins, "u32"), want_min), w
+        assert np.array_equal(to_np(pk, "u32")[:n * 32 * w], oracle.batch("for_pack", "u32", w, v, aux=want_min)), w
+        if w:
+            back = fl.FoR.unfor_pack(w, pk[:n * 32 * w], mins)
+            assert np.array_equal(to_np(back, "u32"), v), w
+    assert lib.example_min_for_pack_u32(33, dv.data_ptr(), pk.data_ptr(), mins.data_ptr(), n, st) == 1      # width > T
+
+
 # ---------------------------------------------------------------------------
 # several tiles per XCD slot (n_blocks > 256) for every kernel family, and launch plumbing
 # ---------------------------------------------------------------------------

@@ -7,7 +7,7 @@ import os
 import shutil
 import sys
 
-RD = sys.argv[1] if len(sys.argv) > 1 else "r03"
+RD = sys.argv[1] if len(sys.argv) > 1 else "r04"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out", RD)
 P = os.path.join(ROOT, "profiles")
@@ -35,15 +35,16 @@ cp(os.path.join(G, "multi_gpu_decode.json"), f"{RD}_multi_gpu_decode_c_driver.js
 cp(os.path.join(G, "multi_gpu_decode_2threads.json"), f"{RD}_multi_gpu_decode_c_driver_2threads.json")
 for c in ("quick", "fused", "consume", "refbench", "batch"):
     cp(os.path.join(G, f"sweep_{c}.txt"), f"{RD}_sweep_{c}.txt")
-for tag, dst in (("prof_trace", f"{RD}_bench_u32w7"), ("prof_trace_mixed", f"{RD}_bench_u32_mixed")):
+# one rocprofv3 kernel trace per BASELINE config (2, 5, 3 unpack, 3 pack, 4): the stats summary + the line printed inside that run
+for tag, dst in (("prof_trace", f"{RD}_bench_u32w7"), ("prof_trace_mixed", f"{RD}_bench_u32_mixed"), ("prof_trace_u64_unpack", f"{RD}_bench_u64w17_unpack"),
+                 ("prof_trace_u64_pack", f"{RD}_bench_u64w17_pack"), ("prof_trace_undelta_pack", f"{RD}_bench_u32w12_undelta_pack")):
     for f in glob.glob(os.path.join(G, tag, "**", "*kernel_stats.csv"), recursive=True):
         cp(f, dst + "_kernel_stats.csv")
-for log, dst in (("bench_under_rocprof.log", f"{RD}_bench_u32w7_under_rocprof.json"),
-                 ("bench_mixed_under_rocprof.log", f"{RD}_bench_u32_mixed_under_rocprof.json")):
-    src = os.path.join(G, log)
+    src = os.path.join(G, tag + ".log")
     if os.path.exists(src):
-        with open(src) as f, open(os.path.join(P, dst), "w") as o:
+        with open(src) as f, open(os.path.join(P, dst + "_under_rocprof.json"), "w") as o:
             o.writelines(l for l in f if l.startswith('{"metric"'))
+        print("copied", dst + "_under_rocprof.json")
 # SQ / LDS counter passes (bash tools/gpu/sq_counters.sh tools/pmc_probe_r03.py gpurun_out/<round>), when the run made them
 if os.path.exists(os.path.join(G, "sq_counters.csv")):
     cp(os.path.join(G, "sq_counters.csv"), f"{RD}_pmc_sq_counters.csv")
