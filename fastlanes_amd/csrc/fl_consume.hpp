@@ -18,7 +18,10 @@ namespace fl {
 // stream better: compare +3...6 % (u64 W=56: +17 %), sums +2...6 % at W = 6..12.
 constexpr int compare_max_waves(int w) { return w <= 5 ? 8 : w <= 9 ? 3 : 2; }
 // waves per SIMD the compare kernels are LAUNCHED at (0 = the cap above), see launch_unpack_compare
-inline int compare_launch_waves(unsigned type_bits, unsigned w) { (void)type_bits; (void)w; return 0; }
+// Round 4 (profiles/abcompare_thin_r04.txt, three boxes, same buffers): once the narrow widths stopped being VALU-bound, fewer
+// resident waves stream better for the narrow TYPES as well -- u8 W=3 at 4 waves 0.803 -> 0.865 / 0.803 -> 0.842 / a tie, u16 W=3 at
+// 6 waves 0.798 -> 0.830 / 0.758 -> 0.765 -- as a bare stream of the same bytes does (4 waves: +2...4 %).
+inline int compare_launch_waves(unsigned type_bits, unsigned w) { return w > 5 ? 0 : type_bits == 8 ? 4 : type_bits == 16 ? 6 : 0; }
 constexpr int sums_max_waves(int w) { return (w >= 6 && w <= 12) ? 3 : 8; }
 
 struct ReduceArgs {

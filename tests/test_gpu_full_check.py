@@ -203,10 +203,12 @@ def test_every_element_of_every_family_under_load(fl, checker, ty, policy):
         for op, call in (("delta", lambda: fl.Delta.delta(un, bases)), ("undelta", lambda: fl.Delta.undelta(un, bases)),
                          ("transpose", lambda: fl.Transpose.transpose(un)), ("untranspose", lambda: fl.Transpose.untranspose(un))):
             got = under_load(call)
-            assert checker.mismatches(ty, op, 0, un, got, n, aux=bases) == 0, (ty, policy, op)
+            differing = checker.mismatches(ty, op, 0, un, got, n, aux=bases)
+            assert differing == 0, (ty, policy, op, f"{differing} elements differ")
             del got
         mins, maxs = under_load(lambda: fl.BitPacking.block_min_max(un))
-        assert checker.mismatches(ty, "min_max", 0, un, mins, n, got2=maxs) == 0, (ty, policy, "block_min_max")
+        differing = checker.mismatches(ty, "min_max", 0, un, mins, n, got2=maxs)
+        assert differing == 0, (ty, policy, "block_min_max", f"{differing} elements differ")
         for w in FULL_WIDTHS[ty]:
             pk = filled(n * packed_len(ty, w), 11 + w)
             for op, src, call, kw in (
@@ -220,12 +222,14 @@ def test_every_element_of_every_family_under_load(fl, checker, ty, policy):
                     ("transpose_delta_pack", un, lambda: fl.Delta.transpose_delta_pack(w, un, bases), dict(aux=bases)),
                     ("block_sums", pk, lambda: fl.BitPacking.unpack_block_sums(w, pk), {})):
                 got = under_load(call)
-                assert checker.mismatches(ty, op, w, src, got, n, **kw) == 0, (ty, policy, w, op, kw.get("aux_stride"))
+                differing = checker.mismatches(ty, op, w, src, got, n, **kw)
+                assert differing == 0, (ty, policy, w, op, kw.get("aux_stride"), f"{differing} elements differ")
                 del got
             kc = (1 << w) // 3
             for name in ("<=", "==", ">"):
                 mask = under_load(lambda: fl.BitPacking.unpack_compare(w, pk, name, kc))
-                assert checker.mismatches(ty, "compare", w, pk, mask, n, cmp_op=name, cmp_k=kc) == 0, (ty, policy, w, "compare", name)
+                differing = checker.mismatches(ty, "compare", w, pk, mask, n, cmp_op=name, cmp_k=kc)
+                assert differing == 0, (ty, policy, w, "compare", name, f"{differing} elements differ")
             del pk
         # mixed widths (always the wave-per-block kernels): seeded-random widths 0..T, offsets built on the device
         g = torch.Generator(device="cuda:0")
@@ -234,10 +238,12 @@ def test_every_element_of_every_family_under_load(fl, checker, ty, policy):
         offsets, total = fl.widths_to_offsets(ty, widths)
         col = filled(max(int(total.item()) // (T // 8), 16), 13)
         got = under_load(lambda: fl.unpack_widths(widths, offsets, col, check=True))
-        assert checker.mismatches(ty, "unpack", 0, col, got, n, widths=widths, offsets=offsets) == 0, (ty, policy, "unpack_widths")
+        differing = checker.mismatches(ty, "unpack", 0, col, got, n, widths=widths, offsets=offsets)
+        assert differing == 0, (ty, policy, "unpack_widths", f"{differing} elements differ")
         back = torch.zeros_like(col)
         under_load(lambda: fl.pack_widths(widths, offsets, un, back, check=True))
-        assert checker.mismatches(ty, "pack", 0, un, back, n, widths=widths, offsets=offsets) == 0, (ty, policy, "pack_widths")
+        differing = checker.mismatches(ty, "pack", 0, un, back, n, widths=widths, offsets=offsets)
+        assert differing == 0, (ty, policy, "pack_widths", f"{differing} elements differ")
         load.drain()
     finally:
         lib.fl_internal_set_kernel_policy(0)

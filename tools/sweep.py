@@ -279,12 +279,12 @@ def main():
             packed = [pk_all[a * ppb:(a + 1) * ppb] for a in range(n_arr)]
             outs = [un_all[a * opb:(a + 1) * opb] for a in range(n_arr)]
             batch = fl.Batch(packed, outs, [w] * n_arr)
-            run = batch.unpack if op == "unpack" else batch.pack
+            run_batch = batch.unpack if op == "unpack" else batch.pack
 
             def with_policy(pol):
                 def f():
                     lib.fl_internal_set_kernel_policy(pol)
-                    run()
+                    run_batch()
                     lib.fl_internal_set_kernel_policy(0)
                 return f
             # the yardstick: the same 640 000 blocks as ONE contiguous column through fl_<ty>_unpack / _pack, same buffers
@@ -292,7 +292,7 @@ def main():
                 one = lambda: fl.BitPacking.unpack(w, pk_all, output=un_all)
             else:
                 one = lambda: fl.BitPacking.pack(w, un_all, output=pk_all)
-            variants = {"batch": run, "contiguous": one}
+            variants = {"batch": run_batch, "contiguous": one}
             variants.update({pol: with_policy(pol) for pol in pols})
             med = interleaved(variants, max(args.reps, 15))
             t, tc = med["batch"], med["contiguous"]
@@ -305,7 +305,7 @@ def main():
             one()
             want = (un_all if op == "unpack" else pk_all).clone()
             (un_all if op == "unpack" else pk_all).zero_()
-            run()
+            run_batch()
             same = torch.equal(want.view(torch.uint8), (un_all if op == "unpack" else pk_all).view(torch.uint8))
             # the same arrays as one call each (what a chunk-at-a-time caller does today), through the raw C ABI
             f = getattr(lib, f"fl_{ty}_{op}")
