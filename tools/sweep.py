@@ -13,6 +13,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fastlanes_amd as fl  # noqa: E402
 
+WINDOW_AB = "--window-ab" in sys.argv
 PLACEMENT = "separate" if "--placement" in sys.argv and sys.argv[sys.argv.index("--placement") + 1] == "separate" else "zoned"
 ESZ = {"u8": 1, "u16": 2, "u32": 4, "u64": 8}
 TDT = {"u8": torch.uint8, "u16": torch.uint16, "u32": torch.uint32, "u64": torch.uint64}
@@ -166,6 +167,20 @@ def run(op, ty, w, gb, reps):
     ms.sort()
     med = ms[len(ms) // 2]
     gbps = n * bpb / med / 1e6
+    if WINDOW_AB:
+        # the same buffers under the whole-column tile map of rounds 1-3 (window 31) and under 2^16-block windows, whatever the
+        # library's own choice for this kernel is (fl_kernels.hpp: xcd_tile), round-robin
+        big = {"u64": 20, "u32": 21, "u16": 22, "u8": 23}[ty]            # 8 GiB of unpacked blocks per window
+        alt = {31: [], 16: [], big: []}
+        for _ in range(reps):
+            for wnd in alt:
+                lib.fl_internal_set_kernel_policy(wnd << 25)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); f(); b.record(); b.synchronize()
+                alt[wnd].append(a.elapsed_time(b))
+        lib.fl_internal_set_kernel_policy(0)
+        placed = (placed + " " if placed else "") + "whole-column map %.3f, 2^16-block windows %.3f, 8-GiB windows %.3f" % tuple(
+            n * bpb / sorted(alt[k])[len(alt[k]) // 2] / 8e9 for k in (31, 16, big))
     return {"op": op, "ty": ty, "w": w, "n_blocks": n, "ms": round(med, 4), "GBps": round(gbps, 1),
             "frac": round(gbps / 8000, 4), "Gints": round(n * 1024 / med / 1e6, 1), "placed": placed}
 
@@ -189,6 +204,7 @@ def main():
     ap.add_argument("--cases", default="quick")
     ap.add_argument("--json", default=None)
     ap.add_argument("--placement", default="zoned", choices=("zoned", "separate"))
+    ap.add_argument("--window-ab", action="store_true", help="every row also under the whole-column tile map and under 2^16-block windows")
     ap.add_argument("--batch-all", action="store_true", help="--cases batch: every element type and the pack direction too")
     ap.add_argument("--batch-policies", default="", help="--cases batch: comma-separated kernel policies to time next to the default")
     args = ap.parse_args()
