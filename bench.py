@@ -19,9 +19,17 @@ timeout, not the run), then in-process -- and used for the barrier / reductions 
 EVERY rank got it working; otherwise the run continues on gloo.  The line says which
 (`control_backend`, `control_fallback_reason`).
 
-Every rank checks what it just timed -- the first and last block of ITS slice plus
-sampled blocks, both legs -- against the oracle outside the timed region
-(`per_rank[i].correct`); any mismatch makes every rank exit non-zero.
+Every rank checks what it just timed, both legs, outside the timed region: the first and
+last block of ITS slice plus sampled blocks byte for byte against the oracle, then
+(--verify full, the default) EVERY block of its slice -- two 64-bit content hashes per
+block computed on the device against the multithreaded CPU oracle decoding the same
+counter-based stream regenerated on the host (`per_rank[i].correct`,
+`per_rank[i].verified_blocks`); any mismatch makes every rank exit non-zero.
+
+Where a workload's buffers live in HBM moves the kernel by a few per cent (DESIGN.md
+section 4): --placement auto (default) allocates and fills both layouts it knows, times a
+few launches on each BEFORE the timed region, keeps the faster buffers and prints both
+figures (`roofline.placement_probe_GBps`).
 
 After the headline leg the same processes time BASELINE.json configs[4] --
 u32, width[b] = 1 + b mod 32, the 10 B-integer column (9 765 625 blocks) sharded
@@ -248,10 +256,9 @@ class Workload:
     """One rank's share of a workload: device buffers + step()."""
 
     def __init__(self, name, n, first_block, rank, dev, placement="separate"):
-        """placement: "zoned" = input and output carved from ONE allocation, the input at offset 0 (reads like to stay inside one
-        64-GiB zone of the device memory), the output centred on a 64-GiB multiple (writes like to be split over two zones)
-        (fastlanes_amd/placement.py; falls back to "separate" when the slab does not fit); "separate" = one torch allocation
-        per buffer, wherever the driver puts them."""
+        """placement: "separate" = one torch allocation per buffer, wherever the driver puts them; "zoned" = input and output
+        carved from ONE allocation, the input at offset 0, the output centred on a 64-GiB multiple (fastlanes_amd/placement.py;
+        falls back to "separate" when the slab does not fit).  main() picks by measurement (placed_workload)."""
         import torch
         import fastlanes_amd as fl
         from fastlanes_amd import placement as pl
