@@ -33,10 +33,13 @@ std::atomic<int> g_kernel_policy{0};
 // waves per SIMD to run the wave-per-block kernel at, or 0 = use the cell-column kernel.  The per-(T,W) cell-column
 // families are only built where the table chose them (cell_column_built); Delta's / Transpose's per-type cell-column
 // kernels (no width parameter) always exist.
-inline int chosen_waves(unsigned type_bits, unsigned w, fl::WaveOp op)
+inline int chosen_waves(unsigned type_bits, unsigned w, fl::WaveOp op, bool with_refs = false)
 {
     const int p = g_kernel_policy.load(std::memory_order_relaxed);
-    const int table = fl::wave_policy(type_bits, w, op);
+    int table = fl::wave_policy(type_bits, w, op);
+    // the one exception to the generated table (fl_dispatch.hpp: u8_two_blocks_in_flight)
+    if ((op == fl::WAVE_PACK || op == fl::WAVE_UNPACK) && fl::u8_two_blocks_in_flight(type_bits, w, op == fl::WAVE_PACK, op == fl::WAVE_PACK && with_refs))
+        table = 8;
     const bool per_type = op == fl::WAVE_UNDELTA || op == fl::WAVE_DELTA || op == fl::WAVE_TRANSPOSE || op == fl::WAVE_UNTRANSPOSE;
     if ((p & 0xff) == 1) return (per_type || fl::cell_column_built(type_bits, w, op)) ? 0 : table;
     if ((p & 0xff) != 2) return table;
@@ -152,10 +155,14 @@ int run_wave_uniform(bool pack, int waves, unsigned w, const T* packed, T* unpac
     a.tiles_per_xcd = 0;
     a.window_shift = 63;
     a.uniform_width = w;
-    a.bpw = uniform_blocks_per_wave(Elem<T>::BITS, pack);
+    a.bpw = uniform_blocks_per_wave(Elem<T>::BITS, pack, w, refs != nullptr);
     a.packed_bytes = 0;      // not read: uniform-width calls are validated here, on the host side
     a.prefetch = a.bpw > 1;
     a.linear_map = 0;
+    const int pol = g_kernel_policy.load(std::memory_order_relaxed);       // A/B tools: 2 + ... + 65536 * blocks-per-wavefront (+ 2^24: prefetch)
+    if ((pol & 0xff) == 2 && ((pol >> 16) & 0xff)) { a.bpw = (pol >> 16) & 0xff; a.prefetch = (pol >> 24) & 1; }
+    if (a.prefetch && (refs != nullptr) && pack) a.prefetch = 0;          // FoR subtracts on the way into the image: no LDS-DMA
+    if (a.prefetch && (WG / 64) * a.bpw * WaveBlock<T>::BLOCK_BYTES > 64u * 1024u) a.prefetch = 0;   // images would not fit a workgroup's LDS
     hipError_t e = widths_launcher<T>(pack)(a, waves, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
@@ -180,7 +187,7 @@ template <typename T>
 int dev_for_pack(unsigned w, const T* in, const T* refs, size_t stride, T* out, size_t n, void* s)
 {
     if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
-    if (const int waves = chosen_waves(Elem<T>::BITS, w, WAVE_PACK)) {
+    if (const int waves = chosen_waves(Elem<T>::BITS, w, WAVE_PACK, true)) {
         if (n && (!in || !refs)) return FL_ERR_NULL;
         return run_wave_uniform<T>(true, waves, w, out, const_cast<T*>(in), refs, stride, n, s);
     }
@@ -654,7 +661,12 @@ int fl_internal_probe_memory_classes(void* slab, size_t slab_bytes, int* classes
         for (int i = -1; i < 3; ++i) {
             hipError_t h = hipEventRecord(t0, s);
             if (h != hipSuccess) return hip_fail(h);
+            // under the whole-column tile map the class map was characterised with (a windowed read stream interferes less with the
+            // thin write stream, which is the point of the window and blunts the probe): process-wide override, restored at once --
+            // this is measurement tooling, synchronous by contract
+            const int saved = fl::window_override().exchange(fl::WINDOW_WHOLE, std::memory_order_relaxed);
             const int r = fl_u32_unpack_compare(PROBE_WIDTH, src, FL_CMP_LT, 1u << (PROBE_WIDTH - 1), PROBE_BLOCKS, mask, s);
+            fl::window_override().store(saved, std::memory_order_relaxed);
             if (r != FL_OK) return r;
             h = hipEventRecord(t1, s);
             if (h == hipSuccess) h = hipEventSynchronize(t1);

@@ -92,7 +92,15 @@ def _probe_rate(lib, slab, in_granule, mask_granule, reps=3):
     # on torch's CURRENT stream -- the one the torch events below are recorded on (the NULL stream would not be bracketed by
     # events of a non-blocking side stream)
     st = ctypes.c_void_p(torch.cuda.current_stream(slab.device).cuda_stream)
-    run = lambda: lib.fl_u32_unpack_compare(w, src.data_ptr(), 2, k, n, dst.data_ptr(), st)
+    def run():
+        # under the whole-column tile map the classes were characterised with (policy window 31: fastlanes_amd_internal.h); a
+        # windowed read stream interferes less with the thin write stream -- the point of the window -- and blunts the probe
+        saved = lib.fl_internal_get_kernel_policy()
+        lib.fl_internal_set_kernel_policy(31 << 25)
+        try:
+            return lib.fl_u32_unpack_compare(w, src.data_ptr(), 2, k, n, dst.data_ptr(), st)
+        finally:
+            lib.fl_internal_set_kernel_policy(saved)
     ms = []
     for i in range(reps + 1):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
