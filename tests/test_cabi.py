@@ -66,13 +66,15 @@ def test_width_validation_needs_no_gpu(lib):
 
 
 def test_internal_kernel_policy_is_validated(lib):
-    """include/fastlanes_amd_internal.h: mode 0..2, waves 0 or 3..8 and blocks-per-wave 0..16 (mode 2 only); anything
-    else resets to 0 -- a stray value must not select a kernel shape that was never tested."""
+    """include/fastlanes_amd_internal.h: mode 0..2, waves 0 or 3..8 and blocks-per-wave 0..16 (mode 2 only), tile-map window 0 or
+    8..31 (any mode); anything else resets to 0 -- a stray value must not select a kernel shape that was never tested."""
     try:
-        for ok in (0, 1, 2, 2 + 256 * 3, 2 + 256 * 8, 2 + 65536 * 16, 2 + 256 * 6 + 65536 * 8, 2 + 65536 * 8 + (1 << 24)):
+        for ok in (0, 1, 2, 2 + 256 * 3, 2 + 256 * 8, 2 + 65536 * 16, 2 + 256 * 6 + 65536 * 8, 2 + 65536 * 8 + (1 << 24),
+                   16 << 25, 31 << 25, 8 << 25, 2 + 256 * 8 + (12 << 25)):      # bits 25-29: the tile-map window, any mode
             lib.fl_internal_set_kernel_policy(ok)
             assert lib.fl_internal_get_kernel_policy() == ok
-        for bad in (-1, 3, 255, 2 + 256 * 2, 2 + 256 * 9, 2 + 65536 * 17, 1 + 256 * 4, 65536 * 2, 1 << 24, 2 + (1 << 24), 2 + 65536 * 4 + (2 << 24), 2 + (1 << 30)):
+        for bad in (-1, 3, 255, 2 + 256 * 2, 2 + 256 * 9, 2 + 65536 * 17, 1 + 256 * 4, 65536 * 2, 1 << 24, 2 + (1 << 24), 2 + 65536 * 4 + (2 << 24), 2 + (1 << 30),
+                    1 << 25, 7 << 25):                                          # a window below 2^8 blocks
             lib.fl_internal_set_kernel_policy(bad)
             assert lib.fl_internal_get_kernel_policy() == 0, bad
     finally:

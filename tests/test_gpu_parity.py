@@ -846,6 +846,52 @@ def test_functor_api_user_kernel_on_iterate_rows(fl, oracle):
     assert np.array_equal(got, wsum)
 
 
+@pytest.mark.parametrize("ty", TYS)
+def test_results_do_not_depend_on_the_tile_map(fl, oracle, ty):
+    """fl_kernels.hpp: xcd_tile -- which workgroup takes which tile is chosen for speed (round 4: read-dominated kernels walk the
+    column in windows) and must never change a byte.  Every family under windows of 2^8, 2^9 and 2^12 blocks (many windows, a
+    short last one: the block count is ragged against all of them) and under the whole-column map, with both kernel designs,
+    against the default's output -- which the other tests tie to the oracle -- and, for unpack, against the oracle directly."""
+    import torch
+    T, L = tbits(ty), lanes(ty)
+    n = 5000 + 37
+    w = {8: 5, 16: 9, 32: 7, 64: 17}[T]
+    lib = fl.load()
+    v = values(ty, n * 1024, 4100 + T)
+    pk = values(ty, n * packed_len(ty, w), 4200 + T)
+    bases = values(ty, n * L, 4300 + T)
+    refs = values(ty, n, 4400 + T)
+    dv, dpk, db, dr = to_dev(v), to_dev(pk), to_dev(bases), to_dev(refs)
+    widths = torch.from_numpy((np.arange(n) * 7 % (T + 1)).astype(np.uint8)).cuda()
+    offsets, total = fl.widths_to_offsets(ty, widths)
+    col = to_dev(values(ty, max(int(total.item()) // (T // 8), 16), 4500 + T))
+    chunks = [dpk[a * 100 * packed_len(ty, w):(a + 1) * 100 * packed_len(ty, w)] for a in range(50)]
+
+    def everything():
+        outs = [torch.empty(100 * 1024, dtype=dv.dtype, device="cuda:0") for _ in range(50)]
+        fl.Batch(chunks, outs, [w] * 50).unpack(check=True)
+        r = [fl.BitPacking.unpack(w, dpk), fl.BitPacking.pack(w, dv), fl.FoR.unfor_pack(w, dpk, dr), fl.FoR.for_pack(w, dv, dr),
+             fl.Delta.delta(dv, db), fl.Delta.undelta(dv, db), fl.Delta.undelta_pack(w, dpk, db), fl.Transpose.transpose(dv),
+             fl.Transpose.untranspose(dv), fl.Delta.undelta_pack_untranspose(w, dpk, db), fl.Delta.transpose_delta_pack(w, dv, db),
+             fl.BitPacking.unpack_compare(w, dpk, "<=", (1 << w) // 3), fl.BitPacking.unpack_block_sums(w, dpk),
+             *fl.BitPacking.block_min_max(dv), fl.unpack_widths(widths, offsets, col), torch.cat(outs)]
+        torch.cuda.synchronize()
+        return [t.view(torch.uint8).clone() for t in r]
+
+    try:
+        want = everything()
+        assert np.array_equal(want[0].cpu().numpy().view(TYPES[ty][0]), oracle.batch("unpack", ty, w, pk, n_blocks=n))
+        for design in (0, 1, 2):
+            for window in (8, 9, 12, 31):
+                lib.fl_internal_set_kernel_policy(design + (window << 25))
+                assert lib.fl_internal_get_kernel_policy() == design + (window << 25)
+                got = everything()
+                for i, (g, e) in enumerate(zip(got, want)):
+                    assert torch.equal(g, e), (ty, design, window, i)
+    finally:
+        lib.fl_internal_set_kernel_policy(0)
+
+
 def test_fl_check_device_refuses_foreign_pointers():
     """FL_CHECK_DEVICE=1 (include/fastlanes_amd.h "Threading and device selection"): every device-tier entry verifies that its
     pointers are memory the current device can use and that the stream is one of its streams, and returns FL_ERR_DEVICE (7)

@@ -13,17 +13,22 @@ import fastlanes_amd as fl  # noqa: E402
 
 lib = fl.load()
 dev = torch.device("cuda:0")
-TDT = {"u8": torch.uint8, "u16": torch.uint16}
+TDT = {"u8": torch.uint8, "u16": torch.uint16, "u32": torch.uint32, "u64": torch.uint64}
 ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=9)
 ap.add_argument("--gb", type=float, default=16.0)
+ap.add_argument("--wide", action="store_true", help="u32 W=7 / 20 and u64 W=17 instead of the narrow types (does the headline want more blocks in flight?)")
 args = ap.parse_args()
 POL = {"table": 0, "wpb 8x1": 2 + 256 * 8, "wpb 8x2 pf": 2 + 256 * 8 + 65536 * 2 + (1 << 24), "wpb 8x4 pf": 2 + 256 * 8 + 65536 * 4 + (1 << 24),
        "wpb 8x8 pf": 2 + 256 * 8 + 65536 * 8 + (1 << 24), "wpb 6x4 pf": 2 + 256 * 6 + 65536 * 4 + (1 << 24), "cell-column": 1}
 print(f"# {lib.fl_version().decode()}\n# fraction of 8 TB/s (algorithmic bytes), median of {args.reps} round-robin launches; wpb AxB = wave-per-block kernel at A "
       "waves/SIMD, B blocks per wavefront, pf = all requested up front by LDS-DMA\n" + f"{'case':22s} " + " ".join(f"{k:>12s}" for k in POL), flush=True)
-for ty, T in (("u8", 8), ("u16", 16)):
-    for w in ((1, 3, 5, 7, 8) if T == 8 else (1, 3, 5, 9, 13, 16)):
+if args.wide:
+    POL = {"table": 0, "wpb 8x1": 2 + 256 * 8, "wpb 6x1": 2 + 256 * 6, "wpb 8x2 pf": 2 + 256 * 8 + 65536 * 2 + (1 << 24), "wpb 5x2 pf": 2 + 256 * 5 + 65536 * 2 + (1 << 24),
+           "wpb 4x2 pf": 2 + 256 * 4 + 65536 * 2 + (1 << 24), "wpb 3x3 pf": 2 + 256 * 3 + 65536 * 3 + (1 << 24), "wpb 8x2": 2 + 256 * 8 + 65536 * 2}
+    print(f"{'case':22s} " + " ".join(f"{k:>12s}" for k in POL), flush=True)
+for ty, T in ((("u32", 32), ("u64", 64)) if args.wide else (("u8", 8), ("u16", 16))):
+    for w in ((7, 20) if T == 32 else (17,) if T == 64 else (1, 3, 5, 7, 8) if T == 8 else (1, 3, 5, 9, 13, 16)):
         per = 128 * w + 128 * T
         n = int(args.gb * 1e9 / per)
         un = torch.empty(n * 128 * T, dtype=torch.uint8, device=dev)
