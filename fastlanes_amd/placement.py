@@ -1,30 +1,24 @@
-"""Zone-aware placement of a column's input and output in HBM.
+"""Layout helpers for MEASURING where a column's buffers live in HBM -- not a policy, and never needed to use the codec (every
+entry point takes any 16-byte aligned device pointers).
 
-Measured on MI355X (tools/abplacement*.cpp, tools/exp_zones.py; profiles/abplacement_r03.txt, profiles/abzones_r03.txt): the device
-memory behaves as 64-GiB ZONES, and reads and writes want opposite things from them:
+What round 3 measured on MI355X (tools/abplacement*.cpp, tools/exp_*.py; profiles/abplacement_r03.txt, abzones_r03.txt,
+exp_region_map_r03.txt): every 8-GiB granule of an allocation behaves as one of three classes of memory, in an order the driver
+chooses (runs of 32-64 GiB at the start of a fresh allocation, shorter and differently ordered further in and in every process);
+two concurrent WRITE streams sustain 5.6 TB/s together inside one stretch and 7.05 TB/s in two, two concurrent READ streams do the
+opposite (6.8 / 6.35); a thin write stream next to a bulk read stream of the same class costs the consumers up to 14 %.  So the same
+kernel moves by a few per cent with the allocation its buffers happen to lie in -- and nothing in an address tells.
 
-  * two concurrent WRITE streams inside one zone sustain 5.6 TB/s together, in two different zones 7.05 TB/s (+26 %);
-  * two concurrent READ streams inside one zone sustain 6.8 TB/s together, in two different zones 6.35 TB/s (-7 %).
+What the repository does with that since round 4:
+  * the KERNELS use the read / write asymmetry themselves (the tile-map window, fl_kernels.hpp: xcd_tile);
+  * bench.py --placement auto treats the layout as a measurement: it allocates both layouts it knows -- one allocation per buffer,
+    and `column_pair` below -- times a few launches on each BEFORE its timed region and keeps the faster buffers.  Round 3 shipped
+    `column_pair` as the default and it cost one workload 9 %;
+  * tools/sweep.py carves every row from one slab and places its consumers' thin outputs with `consumer_pair` (classes by a probe
+    kernel), so that rows of one sweep are comparable.
 
-The codec kernels (all of whose global accesses are streaming reads or writes) follow: unpack u32 W=7 runs at ~6.2 TB/s when its
-packed input and its unpacked output share a zone, ~6.75 when they lie in different zones and 6.85-6.9 when the OUTPUT is split
-half and half over two zones -- the whole "which allocation did the buffers land in" spread of the bench numbers (0.75-0.86 of the
-HBM peak) -- while a read-dominated pack loses when its INPUT is split.  Whether two separate allocations share a zone is the
-driver's choice; inside ONE allocation it is the caller's: in every process measured, the zone boundaries of a large allocation
-lay at multiples of 64 GiB from its start.
-
-`column_pair` carves both buffers from one allocation: the INPUT (and aux) at offset 0 -- inside one zone as long as it is shorter
-than 64 GiB --, the OUTPUT centred on the first 64-GiB multiple that leaves room for the input in front of it, so that the writes
-are split over two zones.  If the allocation does not start on the zone grid after all, the worst case is still "input and output
-in different zones" (the span exceeds one zone).  It is an allocation helper, nothing else: the codec entry points take any 16-byte
-aligned device pointers.  The price is the unused memory between the two buffers (a column store would keep other columns there).
-
-What the "zones" are (the last experiments of round 3, profiles/exp_region_map_r03.txt): every 8-GiB granule of an allocation
-belongs to one of three CLASSES of memory -- 3 x 96 GB, most likely the three ranks of the 12-high HBM3E stacks -- which the
-driver strings together in an order of its own (runs of 32-64 GiB at the start of a fresh allocation, hence "multiples of 64 GiB";
-shorter runs further in).  Writes next to reads of the same class pay for it; a kernel whose 8 XCDs write at 8 evenly spaced
-positions of its output (the XCD-contiguous tile map) is fastest when those positions fall into two classes, which is what
-"output centred on a class boundary" achieves.  consumer_pair() below measures instead of assuming.
+`column_pair` carves both buffers from one allocation: the INPUT (and aux) at offset 0, the OUTPUT centred on the first 64-GiB
+multiple that leaves room for the input in front of it -- in a fresh allocation that is where the first class boundary usually
+lies, so the kernel's concurrent writes fall into two classes.  The price is the unused memory between the two buffers.
 """
 
 ZONE_BYTES = 64 << 30
