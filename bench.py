@@ -65,7 +65,21 @@ WORKLOADS = {
     "u16_w3_unpack": ("u16", 3, "unpack", 128 * 3 + 128 * 16),
     # BASELINE.json configs[4]: width[b] = 1 + b % 32; bytes per block averaged over the 32 widths
     "u32_mixed_unpack": ("u32", None, "unpack_mixed", 128 * 16.5 + 128 * 32),
+    # SURVEY.md 8(d) config 5 "also run a seeded-random width variant": width[b] uniform in 1..32 from a generator seeded with 42,
+    # a function of the GLOBAL block index (so every sharding decodes the same column)
+    "u32_mixed_random_unpack": ("u32", None, "unpack_mixed", 128 * 16.5 + 128 * 32),
 }
+
+
+def mixed_widths(name, first_block, n, device):
+    """widths[first_block .. first_block + n) of a mixed-width workload's column, uint8 on `device`"""
+    import torch
+    if "random" in name:
+        g = torch.Generator(device="cpu")
+        g.manual_seed(42)
+        total = max(CONFIG5_BLOCKS, first_block + n)
+        return torch.randint(1, 33, (total,), dtype=torch.int64, generator=g)[first_block:first_block + n].to(torch.uint8).to(device)
+    return (1 + (torch.arange(n, dtype=torch.int64, device=device) + first_block) % 32).to(torch.uint8)
 TORCH_DT = {"u8": "uint8", "u16": "uint16", "u32": "uint32", "u64": "uint64"}
 ESZ = {"u8": 1, "u16": 2, "u32": 4, "u64": 8}
 
@@ -181,16 +195,17 @@ def cpu_baseline(args, ty, width, op):
     res = {}
     if op == "unpack_mixed":
         # the reference's caller loop over per-block widths (bitpacking.rs:109-129), width[b] = 1 + b mod 32
-        widths = (1 + np.arange(n, dtype=np.int64) % 32).astype(np.uint8)
+        widths = mixed_widths(args.workload, 0, n, "cpu").numpy()
         off = np.zeros(n + 1, dtype=np.uint64)
         np.cumsum(widths.astype(np.uint64) * np.uint64(128), out=off[1:])
         # one fill per 32-block period keeps every thread's pages first-touched by (roughly) its own range
-        src = o.parallel_fill(np.empty(int(off[-1]) // 4, dtype=np.uint32), int(off[32]), n // 32, 7, cores)
+        src = o.parallel_fill(np.empty(int(off[-1]) // 4, dtype=np.uint32), 8, int(off[-1]) // 8, 7, cores)
         out = o.parallel_fill(np.empty(n * 1024, dtype=np.uint32), 4096, n, 9, cores)
 
         def run(nt):
             o.fast_unpack_mixed_u32(widths, off[:-1], src, n_blocks=n, nthreads=nt, out=out)
-        what = f"unpack u32 width[b] = 1 + b mod 32 (caller loop over per-block widths), {n} blocks"
+        what = (f"unpack u32 width[b] = {'seeded-random in 1..32' if 'random' in args.workload else '1 + b mod 32'} "
+                f"(caller loop over per-block widths), {n} blocks")
     else:
         pl = packed_len(ty, width)
         npdt = values(ty, 1, 0).dtype
@@ -293,7 +308,7 @@ class Workload:
 
         if op == "unpack_mixed":
             # widths and offsets are DEVICE arrays, built on the device: nothing about the column touches the host
-            self.widths = (1 + (torch.arange(n, dtype=torch.int64, device=dev) + first_block) % 32).to(torch.uint8)
+            self.widths = mixed_widths(name, first_block, n, dev)
             self.offsets, total = fl.widths_to_offsets(ty, self.widths)
             packed_bytes = int(total.item())
             src, _, dst = buffers(packed_bytes, n * un_bytes)
@@ -957,7 +972,9 @@ def main():
         if args.workload == "u32_w7_unpack":
             workload = f"{op} {ty} W={width}, {n} blocks x 1024 values per GPU (BASELINE.json configs[1])"
         elif op == "unpack_mixed":
-            workload = (f"{op} {ty} width[b] = 1 + b mod 32 (BASELINE.json configs[4]), widths[]/offsets[] device-resident, "
+            pattern = ("seeded-random in 1..32 (the variant SURVEY.md 8(d) asks for next to BASELINE.json configs[4])" if "random" in args.workload
+                       else "1 + b mod 32 (BASELINE.json configs[4])")
+            workload = (f"{op} {ty} width[b] = {pattern}, widths[]/offsets[] device-resident, "
                         f"{n} blocks on rank 0" + (f" of {CONFIG5_BLOCKS} in total" if strong_main else " per GPU"))
         else:
             workload = f"{op} {ty} W={width}, {n} blocks per GPU"

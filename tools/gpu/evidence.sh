@@ -8,7 +8,7 @@ mkdir -p $R
 ROOT=$(pwd)
 timeout 900 python bench.py > $R/bench_u32w7.json 2> $R/bench.err; echo "bench rc=$?"
 rm -f $R/bench_other.jsonl
-for wl in u32_mixed_unpack u64_w17_unpack u64_w17_pack u32_w12_undelta_pack u32_w7_pack u16_w3_unpack; do
+for wl in u32_mixed_unpack u32_mixed_random_unpack u64_w17_unpack u64_w17_pack u32_w12_undelta_pack u32_w7_pack u16_w3_unpack; do
   timeout 500 python bench.py --workload $wl --steps 10 --cpu-seconds 3 --no-config5 >> $R/bench_other.jsonl 2>> $R/bench_other.err; echo "$wl rc=$?"
 done
 # rocprofv3 kernel traces, one workload per pass (the stats average of a kernel must be comparable with the live average of ONE workload:
