@@ -34,7 +34,7 @@ struct StreamArgs {
     uint64_t aux_stride;   // FoR: 0 = one scalar for all blocks, 1 = one per block
     uint64_t n_blocks;
     uint64_t tiles_per_xcd;   // ceil(ceil(n_blocks/32) / 8)
-    unsigned window_shift;    // log2 of the tile-map window in tiles (>= 32: one window = the whole column); see xcd_tile
+    unsigned window_shift;    // log2 of the tile-map window in tiles (>= 32: one window = the whole column) [| TILE_MAP_ROTATE]; see xcd_tile
 };
 
 // The XCD-aware tile map shared by every kernel: workgroup b -> tile.  The grid is 8 * tiles_per_xcd workgroups (a multiple
@@ -43,14 +43,28 @@ struct StreamArgs {
 // inside it workgroup r -- which runs on XCD r % 8 (observed dispatch order; used for speed only, results never depend on
 // it) -- takes tile first + (r % 8) * span / 8 + r / 8, so XCD x owns one contiguous eighth of the window.  One window =
 // rounds 1-3's map (XCD x owns one contiguous eighth of the whole column).  Why windows: fl_dispatch.hpp (TrafficKind).
-__device__ __forceinline__ uint64_t xcd_tile(unsigned b, uint64_t tiles_per_xcd, unsigned window_shift)
+// TILE_MAP_ROTATE (a flag next to the window shift; round 4, profiles/abmixed_rotate_r04.txt): inside an XCD's run the k-th row of
+// 32 tiles is rotated by k tiles.  An XCD has 32 CUs and its workgroups go to them round-robin, so WITHOUT the rotation CU c is
+// handed tiles c, c + 32, c + 64, ... of the run: if the data has a period that divides 32 tiles (BASELINE config 5: width[b] =
+// 1 + b mod 32 -- 8 tiles) every CU sits at ONE phase of the pattern for the whole launch, some decoding only wide blocks, others only
+// narrow ones.  Rotated, every CU walks through all phases: the ramp 0.798 -> 0.812 (what seeded-random widths get), random widths
+// -0.2 %.  Uniform-width kernels have nothing to decorrelate and lose 0.2-1 % to it, so only the mixed-width kernels set it.
+constexpr unsigned TILE_MAP_ROTATE = 0x80u;
+__device__ __forceinline__ uint64_t rotate_rows_of_32(uint64_t r, uint64_t run, bool rotate)
 {
-    if (window_shift >= 32) return (uint64_t)(b & 7u) * tiles_per_xcd + (b >> 3);
+    const uint64_t row = r >> 5;
+    return (rotate && ((row + 1) << 5) <= run) ? ((row << 5) | ((r + row) & 31u)) : r;      // a short last row stays as it is
+}
+__device__ __forceinline__ uint64_t xcd_tile(unsigned b, uint64_t tiles_per_xcd, unsigned window_shift_and_flags)
+{
+    const unsigned window_shift = window_shift_and_flags & 0x7fu;
+    const bool rotate = (window_shift_and_flags & TILE_MAP_ROTATE) != 0;
+    if (window_shift >= 32) return (uint64_t)(b & 7u) * tiles_per_xcd + rotate_rows_of_32(b >> 3, tiles_per_xcd, rotate);
     const unsigned first = (b >> window_shift) << window_shift;
     const unsigned r = b - first;
     const uint64_t left = tiles_per_xcd * 8 - first, full = 1ull << window_shift;
     const uint64_t span = left < full ? left : full;
-    return first + (uint64_t)(r & 7u) * (span >> 3) + (r >> 3);
+    return first + (uint64_t)(r & 7u) * (span >> 3) + rotate_rows_of_32(r >> 3, span >> 3, rotate);
 }
 
 // A/B tools (fl_internal_set_kernel_policy bits 25-29): log2 of the window in blocks for EVERY kernel; 0 = each kernel's default

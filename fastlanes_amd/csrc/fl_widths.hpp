@@ -606,6 +606,7 @@ hipError_t launch_widths(const WidthsArgs& a0, int waves, hipStream_t s)
     a.tiles_per_xcd = (n_tiles + 7) / 8;
     if (a.tiles_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;   // > 2^33 blocks in one launch
     a.window_shift = tile_window_shift(PACK ? TRAFFIC_READ : TRAFFIC_WRITE, (unsigned)tile_blocks);
+    if (a.widths) a.window_shift |= TILE_MAP_ROTATE;         // per-block widths may be periodic: keep CUs from locking onto one phase
     const dim3 grid((unsigned)(a.tiles_per_xcd * 8));
     if (a.bpw < 2 || a.bpw > 16) a.prefetch = 0;
     const unsigned lds = widths_lds_bytes<T>(waves, a.prefetch ? a.bpw : 1u);
