@@ -12,14 +12,15 @@ for wl in u32_mixed_unpack u32_mixed_random_unpack u64_w17_unpack u64_w17_pack u
   timeout 500 python bench.py --workload $wl --steps 10 --cpu-seconds 3 --no-config5 >> $R/bench_other.jsonl 2>> $R/bench_other.err; echo "$wl rc=$?"
 done
 # rocprofv3 kernel traces, one workload per pass (the stats average of a kernel must be comparable with the live average of ONE workload:
-# configs 2 and 5 run the same kernel template, k_unpack_widths<u32>, hence --no-config5).  Default placement (auto): the average then also
-# covers the 2 x 7 launches of the placement probe -- the same kernel on the same bytes, one layout a per cent or two slower -- next to
-# the 3 warm-ups and the 10 timed launches
+# configs 2 and 5 run the same kernel template, k_unpack_widths<u32>, hence --no-config5), with the layout --placement auto keeps on this box
 ( cd /tmp && export TMPDIR=/tmp
   for spec in "u32_w7_unpack:prof_trace" "u32_mixed_unpack:prof_trace_mixed" "u64_w17_unpack:prof_trace_u64_unpack" "u64_w17_pack:prof_trace_u64_pack" "u32_w12_undelta_pack:prof_trace_undelta_pack"; do
     wl=${spec%%:*}; d=${spec##*:}
     rm -rf $ROOT/$R/$d
-    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$R/$d -o bench -- python $ROOT/bench.py --workload $wl --steps 10 --no-cpu-baseline --no-pmc --no-config5 > $ROOT/$R/$d.log 2>&1; echo "rocprof $wl rc=$?"
+    # which layout does --placement auto keep for this workload on this box?  Ask an unprofiled run, then profile with that layout passed
+    # explicitly: the trace then holds nothing but the warm-ups and the timed launches of the kernel (no probe launches on the other layout)
+    lay=$(timeout 300 python $ROOT/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-pmc --no-config5 --verify sample 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('zoned' if d['config']['placement'].startswith('input and output carved') else 'separate')")
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$R/$d -o bench -- python $ROOT/bench.py --workload $wl --steps 10 --no-cpu-baseline --no-pmc --no-config5 --placement ${lay:-separate} > $ROOT/$R/$d.log 2>&1; echo "rocprof $wl (placement ${lay:-separate}) rc=$?"
   done )
 for c in quick fused consume refbench; do timeout 600 python tools/sweep.py --cases $c 2>&1 | grep -v amdgpu.ids > $R/sweep_$c.txt; done
 timeout 600 python tools/sweep.py --cases batch --batch-all 2>&1 | grep -v amdgpu.ids > $R/sweep_batch.txt
