@@ -3,6 +3,7 @@
  *
  *     for b in 0..n { u32::unchecked_unpack(width[b], &packed[off[b]..], &mut out[b*1024..]) }     (bitpacking.rs:109-129)
  *     let v = u32::unchecked_unpack_single(width[b], &packed[off[b]..], i);                        (bitpacking.rs:181-200)
+ *     for b in 0..n { u32::for_pack::<W_b>(&v[b*1024..], min_b, ..) / unfor_pack::<W_b>(..) }                (ffor.rs:24-50)
  *
  * keeps its column in HBM and makes ONE call per loop.  Everything below is the C ABI of include/fastlanes_amd.h plus
  * the HIP runtime for memory; no C++.
@@ -55,6 +56,32 @@ int main(void)
     CHECK_HIP(hipMalloc((void **)&d_picked, 4 * sizeof(uint32_t)));
     CHECK_HIP(hipMemcpy(d_idx, idx, sizeof idx, hipMemcpyHostToDevice));
     CHECK_FL(fl_u32_unpack_single_widths(d_widths, d_offsets, d_packed, total, N, d_idx, 4, d_picked, d_err, NULL));
+    /* a FoR column, widths chosen ON THE DEVICE: the same values shifted by a per-block frame of reference; the encoder finds every
+     * block's minimum and maximum, takes the bit length of their difference as the width, lays the blocks out back to back and packs
+     * `value - minimum` (for_pack::<W>, ffor.rs:24-36); the decoder adds the minimum back (unfor_pack::<W>, :38-50).  Five calls, no
+     * host pass over the column. */
+    uint32_t *shifted = malloc((size_t)N * 4096);
+    for (int b = 0; b < N; ++b)
+        for (int i = 0; i < 1024; ++i) shifted[(size_t)b * 1024 + i] = values[(size_t)b * 1024 + i] / 2u + 1000003u * (uint32_t)b;
+    uint32_t *d_shifted, *d_mins, *d_maxs, *d_for_packed, *d_for_decoded; uint8_t *d_for_widths; uint64_t *d_for_offsets;
+    CHECK_HIP(hipMalloc((void **)&d_shifted, (size_t)N * 4096));
+    CHECK_HIP(hipMalloc((void **)&d_for_decoded, (size_t)N * 4096));
+    CHECK_HIP(hipMalloc((void **)&d_mins, N * sizeof(uint32_t)));
+    CHECK_HIP(hipMalloc((void **)&d_maxs, N * sizeof(uint32_t)));
+    CHECK_HIP(hipMalloc((void **)&d_for_widths, N));
+    CHECK_HIP(hipMalloc((void **)&d_for_offsets, N * sizeof(uint64_t)));
+    CHECK_HIP(hipMemcpy(d_shifted, shifted, (size_t)N * 4096, hipMemcpyHostToDevice));
+    CHECK_FL(fl_u32_block_min_max(d_shifted, N, d_mins, d_maxs, NULL));
+    CHECK_FL(fl_u32_for_widths(d_mins, d_maxs, N, d_for_widths, NULL));
+    CHECK_FL(fl_widths_to_offsets(32, d_for_widths, N, d_for_offsets, d_total, d_err, NULL));
+    uint64_t for_total = 0;
+    CHECK_HIP(hipMemcpy(&for_total, d_total, sizeof for_total, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMalloc((void **)&d_for_packed, for_total ? for_total : 16));
+    CHECK_FL(fl_u32_for_pack_widths(d_for_widths, d_for_offsets, d_shifted, d_mins, 1, d_for_packed, for_total, N, d_err, NULL));
+    CHECK_FL(fl_u32_unfor_pack_widths(d_for_widths, d_for_offsets, d_for_packed, for_total, d_mins, 1, d_for_decoded, N, d_err, NULL));
+    uint32_t *for_decoded = malloc((size_t)N * 4096);
+    CHECK_HIP(hipMemcpy(for_decoded, d_for_decoded, (size_t)N * 4096, hipMemcpyDeviceToHost));
+    const int for_bad = memcmp(for_decoded, shifted, (size_t)N * 4096) != 0 || for_total >= total;   /* halved values: smaller than the plain column */
     /* the same trait call on host slices, one block (what a trait-for-trait binding does): block 517 */
     uint64_t off517 = 0;
     CHECK_HIP(hipMemcpy(&off517, d_offsets + 517, sizeof off517, hipMemcpyDeviceToHost));
@@ -67,7 +94,7 @@ int main(void)
     CHECK_HIP(hipMemcpy(decoded, d_decoded, (size_t)N * 4096, hipMemcpyDeviceToHost));
     CHECK_HIP(hipMemcpy(picked, d_picked, sizeof picked, hipMemcpyDeviceToHost));
     CHECK_HIP(hipMemcpy(&err, d_err, sizeof err, hipMemcpyDeviceToHost));
-    int bad = err != 0 || memcmp(decoded, values, (size_t)N * 4096) != 0 || memcmp(one_block, values + 517 * 1024, 4096) != 0;
+    int bad = err != 0 || for_bad || memcmp(decoded, values, (size_t)N * 4096) != 0 || memcmp(one_block, values + 517 * 1024, 4096) != 0;
     for (int k = 0; k < 4; ++k) bad |= picked[k] != values[idx[k]];
     printf(bad ? "MISMATCH\n" : "ok\n");
     fl_host_release();

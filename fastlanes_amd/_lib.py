@@ -45,6 +45,12 @@ def _signatures(ty):
         "unpack_widths": [_P, _P, _P, _Z, _P, _Z, _P, _P],
         "pack_widths": [_P, _P, _P, _P, _Z, _Z, _P, _P],
         "unpack_single_widths": [_P, _P, _P, _Z, _Z, _P, _Z, _P, _P, _P],
+        "unfor_pack_widths": [_P, _P, _P, _Z, _P, _Z, _P, _Z, _P, _P],
+        "for_pack_widths": [_P, _P, _P, _P, _Z, _P, _Z, _Z, _P, _P],
+        "undelta_pack_widths": [_P, _P, _P, _Z, _P, _P, _Z, _P, _P],
+        "undelta_pack_untranspose_widths": [_P, _P, _P, _Z, _P, _P, _Z, _P, _P],
+        "transpose_delta_pack_widths": [_P, _P, _P, _P, _P, _Z, _Z, _P, _P],
+        "for_widths": [_P, _P, _Z, _P, _P],
         "unpack_batch": [_P, _P, _P, _P, _Z, ctypes.c_uint32, _P, _P],
         "pack_batch": [_P, _P, _P, _P, _Z, ctypes.c_uint32, _P, _P],
         "unfor_pack_batch": [_P, _P, _P, _P, _P, _Z, ctypes.c_uint32, _P, _P],

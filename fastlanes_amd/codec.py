@@ -496,7 +496,12 @@ def widths_to_offsets(ty, widths):
     return offsets, total
 
 
-def _widths_call(method, ty, widths, offsets, packed, unpacked, check):
+# the packed side comes first for the decoders, last for the encoders; FoR's references / Delta's bases sit between the two sides
+_WIDTHS_DECODERS = ("unpack_widths", "unfor_pack_widths", "undelta_pack_widths", "undelta_pack_untranspose_widths")
+
+
+def _widths_call(method, ty, widths, offsets, packed, unpacked, check, aux=()):
+    """`aux`: the C arguments between the two sides -- (references pointer, stride) for FoR, (bases pointer,) for Delta."""
     import torch
     w = _Arg(widths, "u8")
     o = _Arg(offsets, "u64")
@@ -511,14 +516,32 @@ def _widths_call(method, ty, widths, offsets, packed, unpacked, check):
     dev = packed.x.device
     err = torch.zeros(1, dtype=torch.int32, device=dev) if check else None
     pbytes = packed.n * (_lib.BITS[ty] // 8)     # the kernel skips (and flags) any block that does not lie inside these bytes
-    # C ABI argument order is (widths, offsets, in, out, ..): packed, packed_bytes -> unpacked for unpack, the reverse for pack
-    args = (packed.ptr, pbytes, unpacked.ptr) if method == "unpack_widths" else (unpacked.ptr, packed.ptr, pbytes)
+    # C ABI argument order is (widths, offsets, in, [aux], out, ..): packed, packed_bytes -> unpacked for the decoders, the reverse
+    # for the encoders
+    args = (packed.ptr, pbytes, *aux, unpacked.ptr) if method in _WIDTHS_DECODERS else (unpacked.ptr, *aux, packed.ptr, pbytes)
     with torch.cuda.device(dev):
         _check(getattr(_lib.load(), f"fl_{ty}_{method}")(w.ptr, o.ptr, *args, n,
                                                          err.data_ptr() if check else None, _stream(packed)),
                f"fl_{ty}_{method}")
     if check:
         _check_flag(err, f"fl_{ty}_{method}")                   # bitpacking.rs:93,126 unreachable!(); :78-80,111-113
+
+
+def _block_references(src, ty, references, n):
+    """FoR references of a mixed-width column: a CUDA tensor with one scalar per block, or one scalar for all (stride 0)."""
+    r = _Arg(references, ty)
+    _same_tier(src, r)
+    if r.n not in (1, n):
+        raise ValueError("references must hold one scalar per block (or exactly one, broadcast)")
+    return r, (r.ptr, 0 if r.n == 1 and n != 1 else 1)
+
+
+def _block_bases(src, ty, base, n):
+    b = _Arg(base, ty)
+    _same_tier(src, b)
+    if b.n != n * (1024 // _lib.BITS[ty]):
+        raise ValueError("base must hold LANES elements per block")
+    return b, (b.ptr,)
 
 
 def unpack_widths(widths, offsets, packed, output=None, check=True):
@@ -544,6 +567,71 @@ def pack_widths(widths, offsets, input, output, check=True):
     ty = src.ty
     out = _Arg(output, ty)
     _widths_call("pack_widths", ty, widths, offsets, out, src, check)
+    return out.x
+
+
+def unfor_pack_widths(widths, offsets, packed, references, output=None, check=True):
+    """`for b: FoR::unfor_pack::<widths[b]>(&packed[offsets[b]..], references[b], ..)` (ffor.rs:38-50) -- unpack_widths with
+    FoR's body; `references` is a CUDA tensor of one scalar per block (or a single one, broadcast)."""
+    src = _Arg(packed)
+    ty = src.ty
+    n = _Arg(widths, "u8").n
+    r, aux = _block_references(src, ty, references, n)
+    out = _out(src, output, ty, n * 1024, "unfor_pack_widths")
+    _widths_call("unfor_pack_widths", ty, widths, offsets, src, out, check, aux)
+    return out.x
+
+
+def for_pack_widths(widths, offsets, input, references, output, check=True):
+    """`for b: FoR::for_pack::<widths[b]>(&input[b*1024..], references[b], &mut output[offsets[b]..])` (ffor.rs:24-36)."""
+    src = _Arg(input)
+    ty = src.ty
+    out = _Arg(output, ty)
+    r, aux = _block_references(src, ty, references, _Arg(widths, "u8").n)
+    _widths_call("for_pack_widths", ty, widths, offsets, out, src, check, aux)
+    return out.x
+
+
+def for_widths(mins, maxs):
+    """The encoder's step between block_min_max and for_pack_widths: widths[b] = bit length of maxs[b] - mins[b], the
+    smallest W for which for_pack::<W>(block b, mins[b]) loses nothing (0 for a constant block).  CUDA tensors in, a CUDA
+    uint8 tensor out; asynchronous.  (The reference selects no widths: this is its callers' arithmetic.)"""
+    import torch
+    lo = _Arg(mins)
+    ty = lo.ty
+    hi = _Arg(maxs, ty)
+    _same_tier(lo, hi)
+    if not lo.torch:
+        raise TypeError("for_widths is device tier: pass CUDA tensors")
+    if hi.n != lo.n:
+        raise ValueError("mins and maxs must hold one entry per block")
+    widths = torch.empty(lo.n, dtype=torch.uint8, device=lo.x.device)
+    with torch.cuda.device(lo.x.device):
+        _check(getattr(_lib.load(), f"fl_{ty}_for_widths")(lo.ptr, hi.ptr, lo.n, widths.data_ptr(), _stream(lo)), f"fl_{ty}_for_widths")
+    return widths
+
+
+def undelta_pack_widths(widths, offsets, packed, base, output=None, check=True, untranspose=False):
+    """`for b: Delta::undelta_pack::<widths[b]>(&packed[offsets[b]..], &base[b], ..)` (delta.rs:47-63); the output is in
+    transposed order like the reference's, or in ORIGINAL order with `untranspose=True` (the fused extension)."""
+    src = _Arg(packed)
+    ty = src.ty
+    n = _Arg(widths, "u8").n
+    b, aux = _block_bases(src, ty, base, n)
+    method = "undelta_pack_untranspose_widths" if untranspose else "undelta_pack_widths"
+    out = _out(src, output, ty, n * 1024, method)
+    _widths_call(method, ty, widths, offsets, src, out, check, aux)
+    return out.x
+
+
+def transpose_delta_pack_widths(widths, offsets, input, base, output, check=True):
+    """`for b: pack::<widths[b]>(delta(transpose(&input[b*1024..]), &base[b]))` into output[offsets[b]..] -- the fused encode
+    extension (delta.rs:88-95 composed) over per-block widths."""
+    src = _Arg(input)
+    ty = src.ty
+    out = _Arg(output, ty)
+    b, aux = _block_bases(src, ty, base, _Arg(widths, "u8").n)
+    _widths_call("transpose_delta_pack_widths", ty, widths, offsets, out, src, check, aux)
     return out.x
 
 

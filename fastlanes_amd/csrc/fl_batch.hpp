@@ -92,7 +92,7 @@ __global__ __launch_bounds__(WG) void k_batch(BatchArgs b)
     const unsigned left = d.n_blocks - first;
     const unsigned count = left < b.bpw ? left : b.bpw;
     char* lds = lds_all + wave * G::BLOCK_BYTES * (b.prefetch ? b.bpw : 1u);
-    if (b.prefetch && count > 1 && !(PACK && a.refs)) {
+    if (b.prefetch && count > 1) {
         if constexpr (PACK) pack_blocks_wave_prefetched<T>(a, first, count, lds, lane);
         else unpack_blocks_wave_prefetched<T>(a, first, count, lds, lane);
         return;

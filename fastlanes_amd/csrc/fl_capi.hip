@@ -112,16 +112,26 @@ int run_stream(stream_launch_t fn, const T* in, T* out, const void* aux, size_t 
 
 // Delta's bodies and the transposes on the wave-per-block pipeline kernel (fl_chain.hpp).  Returns -1 when no such form
 // exists for the op: the caller then uses the cell-column kernel.
+// Mixed-width form (widths != nullptr; the three ops with a packed side only): per-block widths[] / offsets[] read and checked
+// by the kernel, `w` unused.
 template <typename T>
-int run_chain(int op, int waves, unsigned w, const T* in, const T* bases, T* out, size_t n_blocks, void* stream)
+int run_chain(int op, int waves, unsigned w, const T* in, const T* bases, T* out, size_t n_blocks, void* stream,
+              const uint8_t* widths = nullptr, const uint64_t* offsets = nullptr, size_t packed_bytes = 0, uint32_t* err_flag = nullptr)
 {
-    const fl::chain_launch_t fn = fl::chain_launcher<T>(op);
+    const fl::chain_launch_t fn = widths ? fl::chain_widths_launcher<T>(op) : fl::chain_launcher<T>(op);
     if (!fn) return -1;
     if (n_blocks == 0) return FL_OK;
     const bool packed_in = op == fl::OP_UNDELTA_PACK || op == fl::OP_UNDELTA_PACK_UNTRANSPOSE;
     const bool packed_out = op == fl::OP_TRANSPOSE_DELTA_PACK;
     const bool needs_bases = op != fl::OP_TRANSPOSE && op != fl::OP_UNTRANSPOSE;
-    if ((!out && !(packed_out && w == 0)) || (needs_bases && !bases) || (!(packed_in && w == 0) && !in)) return FL_ERR_NULL;
+    if (widths) {
+        // a column whose blocks all have width 0 has no packed bytes: its packed pointer may be NULL (run_widths)
+        static const T no_bytes[16 / sizeof(T)] __attribute__((aligned(16))) = {0};
+        if (packed_bytes == 0 && packed_in && !in) in = no_bytes;
+        if (packed_bytes == 0 && packed_out && !out) out = const_cast<T*>(no_bytes);   // never written: every block is skipped or has W = 0
+        if (!(packed_in || packed_out) || !offsets) return FL_ERR_NULL;
+    }
+    if ((!out && !(packed_out && w == 0 && !widths)) || (needs_bases && !bases) || (!(packed_in && w == 0 && !widths) && !in)) return FL_ERR_NULL;
     if (misaligned(in) || misaligned(out) || misaligned(bases)) return FL_ERR_ALIGN;
     fl::ChainArgs a;
     a.in = reinterpret_cast<const char*>(in);
@@ -131,6 +141,10 @@ int run_chain(int op, int waves, unsigned w, const T* in, const T* bases, T* out
     a.tiles_per_xcd = 0;
     a.window_shift = 63;
     a.width = w;
+    a.widths = widths;
+    a.offsets = offsets;
+    a.err_flag = err_flag;
+    a.packed_bytes = packed_bytes;
     hipError_t e = fn(a, waves, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
@@ -161,7 +175,6 @@ int run_wave_uniform(bool pack, int waves, unsigned w, const T* packed, T* unpac
     a.linear_map = 0;
     const int pol = g_kernel_policy.load(std::memory_order_relaxed);       // A/B tools: 2 + ... + 65536 * blocks-per-wavefront (+ 2^24: prefetch)
     if ((pol & 0xff) == 2 && ((pol >> 16) & 0xff)) { a.bpw = (pol >> 16) & 0xff; a.prefetch = (pol >> 24) & 1; }
-    if (a.prefetch && (refs != nullptr) && pack) a.prefetch = 0;          // FoR subtracts on the way into the image: no LDS-DMA
     if (a.prefetch && (WG / 64) * a.bpw * WaveBlock<T>::BLOCK_BYTES > 64u * 1024u) a.prefetch = 0;   // images would not fit a workgroup's LDS
     hipError_t e = widths_launcher<T>(pack)(a, waves, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? FL_OK : hip_fail(e);
@@ -503,9 +516,10 @@ namespace {
 
 template <typename T>
 int run_widths(bool pack, const uint8_t* widths, const uint64_t* offsets, const void* packed, size_t packed_bytes, void* unpacked,
-               size_t n_blocks, uint32_t* err_flag, void* stream)
+               size_t n_blocks, uint32_t* err_flag, void* stream, const T* refs = nullptr, size_t ref_stride = 0, bool with_refs = false)
 {
     if (n_blocks == 0) return FL_OK;
+    if (with_refs && !refs) return FL_ERR_NULL;
     // a column whose blocks all have width 0 has no packed bytes at all: its packed pointer may be NULL (any block with a
     // width > 0 then fails the kernel's bounds check against packed_bytes == 0)
     static const char no_bytes[16] __attribute__((aligned(16))) = {0};
@@ -518,8 +532,8 @@ int run_widths(bool pack, const uint8_t* widths, const uint64_t* offsets, const 
     a.widths = widths;
     a.offsets = offsets;
     a.err_flag = err_flag;
-    a.refs = nullptr;
-    a.ref_stride = 0;
+    a.refs = with_refs ? refs : nullptr;
+    a.ref_stride = ref_stride;
     a.n_blocks = n_blocks;
     a.tiles_per_xcd = 0;
     a.window_shift = 63;
@@ -534,6 +548,28 @@ int run_widths(bool pack, const uint8_t* widths, const uint64_t* offsets, const 
     if ((pol & 0xff) == 2 && ((pol >> 16) & 0xff)) { a.bpw = (pol >> 16) & 0xff; a.prefetch = (pol >> 24) & 1; }
     if (a.prefetch && (WG / 64) * a.bpw * WaveBlock<T>::BLOCK_BYTES > 64u * 1024u) a.prefetch = 0;   // images would not fit a workgroup's LDS
     hipError_t e = widths_launcher<T>(pack)(a, waves, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? FL_OK : hip_fail(e);
+}
+
+// Delta over a mixed-width column: the pipeline kernel with per-block widths[] / offsets[] on its packed side (fl_chain.hpp)
+template <typename T>
+int run_chain_widths(int op, const uint8_t* widths, const uint64_t* offsets, const T* in, const T* bases, T* out, size_t packed_bytes,
+                     size_t n_blocks, uint32_t* err_flag, void* stream)
+{
+    if (n_blocks == 0) return FL_OK;
+    if (!widths || !offsets) return FL_ERR_NULL;
+    int waves = mixed_waves(Elem<T>::BITS, op == OP_TRANSPOSE_DELTA_PACK);
+    const int pol = g_kernel_policy.load(std::memory_order_relaxed);       // A/B tools: 2 + 256 * waves
+    if ((pol & 0xff) == 2 && ((pol >> 8) & 0xff)) waves = (pol >> 8) & 0xff;
+    const int rc = run_chain<T>(op, waves, 0, in, bases, out, n_blocks, stream, widths, offsets, packed_bytes, err_flag);
+    return rc >= 0 ? rc : hip_fail(hipErrorInvalidDeviceFunction);
+}
+
+template <typename T> int dev_for_widths(const T* mins, const T* maxs, size_t n, uint8_t* widths, void* s)
+{
+    if (n == 0) return FL_OK;
+    if (!mins || !maxs || !widths) return FL_ERR_NULL;
+    hipError_t e = launch_for_widths<T>(mins, maxs, n, widths, static_cast<hipStream_t>(s));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
 
@@ -795,6 +831,23 @@ size_t fl_packed_len(unsigned type_bits, unsigned width)
     { FL_DEVICE_TIER(s, w, o, pk, out, ef); return run_widths<T>(false, w, o, pk, pb, out, n, ef, s); }                                         \
     int fl_##S##_pack_widths(const uint8_t* w, const uint64_t* o, const T* in, T* pk, size_t pb, size_t n, uint32_t* ef, void* s) \
     { FL_DEVICE_TIER(s, w, o, in, pk, ef); return run_widths<T>(true, w, o, pk, pb, const_cast<T*>(in), n, ef, s); }                           \
+    int fl_##S##_unfor_pack_widths(const uint8_t* w, const uint64_t* o, const T* pk, size_t pb, const T* r, size_t rs, T* out, \
+                                   size_t n, uint32_t* ef, void* s)                                        \
+    { FL_DEVICE_TIER(s, w, o, pk, r, out, ef); return run_widths<T>(false, w, o, pk, pb, out, n, ef, s, r, rs, true); }                        \
+    int fl_##S##_for_pack_widths(const uint8_t* w, const uint64_t* o, const T* in, const T* r, size_t rs, T* pk, size_t pb, \
+                                 size_t n, uint32_t* ef, void* s)                                          \
+    { FL_DEVICE_TIER(s, w, o, in, r, pk, ef); return run_widths<T>(true, w, o, pk, pb, const_cast<T*>(in), n, ef, s, r, rs, true); }          \
+    int fl_##S##_for_widths(const T* mins, const T* maxs, size_t n, uint8_t* w, void* s)                   \
+    { FL_DEVICE_TIER(s, mins, maxs, w); return dev_for_widths<T>(mins, maxs, n, w, s); }                                                      \
+    int fl_##S##_undelta_pack_widths(const uint8_t* w, const uint64_t* o, const T* pk, size_t pb, const T* b, T* out, size_t n, \
+                                     uint32_t* ef, void* s)                                                \
+    { FL_DEVICE_TIER(s, w, o, pk, b, out, ef); return run_chain_widths<T>(OP_UNDELTA_PACK, w, o, pk, b, out, pb, n, ef, s); }                  \
+    int fl_##S##_undelta_pack_untranspose_widths(const uint8_t* w, const uint64_t* o, const T* pk, size_t pb, const T* b, T* out, \
+                                                 size_t n, uint32_t* ef, void* s)                          \
+    { FL_DEVICE_TIER(s, w, o, pk, b, out, ef); return run_chain_widths<T>(OP_UNDELTA_PACK_UNTRANSPOSE, w, o, pk, b, out, pb, n, ef, s); }      \
+    int fl_##S##_transpose_delta_pack_widths(const uint8_t* w, const uint64_t* o, const T* in, const T* b, T* pk, size_t pb, \
+                                             size_t n, uint32_t* ef, void* s)                              \
+    { FL_DEVICE_TIER(s, w, o, in, b, pk, ef); return run_chain_widths<T>(OP_TRANSPOSE_DELTA_PACK, w, o, in, b, pk, pb, n, ef, s); }            \
     int fl_##S##_unpack_batch(const T* const* pk, T* const* out, const uint8_t* w, const uint32_t* nb, size_t na, uint32_t mb, \
                               uint32_t* ef, void* s)                                                      \
     { FL_DEVICE_TIER(s, pk, out, w, nb, ef); return run_batch<T>(false, reinterpret_cast<const void* const*>(pk), reinterpret_cast<void* const*>(out), w, nullptr, false, nb, na, mb, ef, s); } \

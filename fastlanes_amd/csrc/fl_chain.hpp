@@ -46,6 +46,12 @@ struct ChainArgs {
     uint64_t tiles_per_xcd;
     unsigned window_shift;     // tile-map window (fl_kernels.hpp: xcd_tile); filled by the launcher
     unsigned width;          // SRC_PACKED / SNK_PACKED only
+    // mixed-width form of the packed side (SRC_PACKED / SNK_PACKED only; fl_widths.hpp's surface): block b has widths[b] and its
+    // 128*widths[b] bytes start at byte offsets[b] of the packed column.  nullptr = every block has `width`, back to back.
+    const uint8_t* widths;
+    const uint64_t* offsets;
+    uint32_t* err_flag;      // FL_DEVERR_* of skipped blocks (may be nullptr)
+    uint64_t packed_bytes;   // size of the packed column (only read when widths != nullptr)
 };
 
 // LDS image of a block in ORIGINAL order: byte a of the block lives at pad(a).  u32: +16 bytes per 128-byte line and +32 per
@@ -177,35 +183,67 @@ template <typename T> __device__ __forceinline__ void tile_transpose(const Cell<
         for (int j = 0; j < N; ++j) out[e].x[j] = in[j].x[e];
 }
 
-template <typename T, int SRC, int BODY, int SNK, int RD = RD_VGPR>
-__global__ __launch_bounds__(WG) void k_chain(ChainArgs a)
+// Blocks per wavefront of the MIXED-WIDTH form (BPW template parameter of k_chain; every uniform-width call runs BPW = 1, the
+// kernels the dispatch table was measured with).  A narrow type's block is small (u8: 1 KiB unpacked): with one block per wavefront
+// the wave spends its life waiting on a single short request and the launch is millions of 4-KiB workgroups.  So a u8 / u16
+// wavefront owns several CONSECUTIVE blocks and requests all of them up front by LDS-DMA, one LDS image per block, bases included
+// -- the shape fl_widths.hpp's *_blocks_wave_prefetched use for the same reason (mixed-width undelta_pack u8 0.47 -> 0.58 of the
+// peak, u16 0.73 -> 0.76; profiles/r04_sweep_mixed.txt).  Tried for the uniform-width calls too and NOT adopted
+// (profiles/abchain_narrow_r04.txt): the per-(T,W) cell-column kernels stay far ahead for u8 either way, and u16's fused encode
+// lost 8-12 % (unpacked blocks read by LDS-DMA instead of through VGPRs: the known loss of profiles/ab_ldsdma_r03.txt).
+template <typename T> constexpr unsigned chain_blocks_per_wave() { return sizeof(T) == 1 ? 4u : sizeof(T) == 2 ? 2u : 1u; }
+
+// width and packed-side byte offset of block `blk` (wave-uniform); false = the block fails a device-side precondition (flag raised)
+template <typename T, int SRC, int SNK>
+__device__ __forceinline__ bool chain_block_meta(const ChainArgs& a, uint64_t blk, unsigned lane, unsigned& w, uint64_t& packed_at)
+{
+    constexpr bool PACKED_SIDE = SRC == SRC_PACKED || SNK == SNK_PACKED;
+    w = PACKED_SIDE ? a.width : (unsigned)WaveBlock<T>::TB;
+    packed_at = blk * (uint64_t)(128u * w);
+    if constexpr (PACKED_SIDE) {
+        if (a.widths) {                                        // wave-uniform: per-block width / offset, checked on the device
+            const unsigned z = opaque_zero();                  // (fl_widths.hpp: block_meta / block_precondition)
+            const unsigned wv = a.widths[blk + z];
+            const uint64_t ov = a.offsets[blk + z];
+            w = (unsigned)__builtin_amdgcn_readfirstlane(wv);
+            packed_at = wave_uniform_u64(ov);
+            if (const uint32_t e = block_precondition(true, a.packed_bytes, w, packed_at, WaveBlock<T>::TB)) {
+                raise_device_error(a.err_flag, e, lane);
+                return false;
+            }
+        }
+    }
+    return true;
+}
+
+// descriptor over the source block
+template <typename T, int SRC>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t chain_source(const ChainArgs& a, uint64_t blk, unsigned w, uint64_t packed_at)
+{
+    using G = WaveBlock<T>;
+    const unsigned in_bytes = SRC == SRC_PACKED ? 128u * w : G::BLOCK_BYTES;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.in) + (SRC == SRC_PACKED ? packed_at : blk * (uint64_t)G::BLOCK_BYTES), 0,
+                                             in_bytes, 0x00020000);
+}
+
+// One block through the three stages, cut where the wavefront's LDS traffic must be fenced so that a wavefront that owns several
+// blocks (the narrow types) can take all of them through each stage before the next -- their dependent chains (LDS reads, the
+// scan's ds_bpermutes) then overlap instead of queueing behind one another's fences:
+//   chain_stage_source   source block -> LDS image (+ base)          [not used when the images were staged up front]
+//   chain_stage_rows     LDS image -> this lane's R rows, the body applied
+//   chain_stage_image    the rows -> the sink's LDS image
+//   chain_stage_out      the sink image -> HBM
+template <typename T, int SRC, int BODY, int RD>
+__device__ __forceinline__ void chain_stage_source(const ChainArgs& a, uint64_t blk, unsigned w, uint64_t packed_at, char* lds, unsigned lane,
+                                                   Cell<T>& base)
 {
     using G = WaveBlock<T>;
     constexpr int TB = G::TB;
-    constexpr int R = TB / 8;                                  // consecutive logical rows per lane
-    constexpr int N = 16 / (int)sizeof(T);                     // elements per cell = tile edge
-    constexpr unsigned WAVE_LDS = chain_wave_lds<T, SRC, SNK>();
-    extern __shared__ __attribute__((aligned(16))) char lds_all[];
-    const uint64_t n_tiles = (a.n_blocks + (WG / 64) - 1) / (WG / 64);
-    const uint64_t tile = xcd_tile(blockIdx.x, a.tiles_per_xcd, a.window_shift);
-    if (tile >= n_tiles) return;
-    const unsigned tid = threadIdx.x;
-    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
-    const uint64_t blk = tile * (WG / 64) + wave;
-    if (blk >= a.n_blocks) return;
-    char* lds = lds_all + wave * WAVE_LDS;
-    const unsigned i = lane >> 3, c = lane & 7u, c16 = c * 16u;
-    const unsigned w = (SRC == SRC_PACKED || SNK == SNK_PACKED) ? a.width : (unsigned)TB;
-    const unsigned r0 = R * i;
-
-    // ---- source block -> LDS image (1 KiB-contiguous loads) ----------------------------------------------------
-    const unsigned in_bytes = SRC == SRC_PACKED ? 128u * w : G::BLOCK_BYTES;
-    const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(a.in) + blk * (uint64_t)in_bytes, 0, in_bytes, 0x00020000);
+    const unsigned c16 = (lane & 7u) * 16u;
+    const __amdgpu_buffer_rsrc_t in_rs = chain_source<T, SRC>(a, blk, w, packed_at);
     const unsigned w_in = SRC == SRC_PACKED ? w : (unsigned)TB;
     // LDS-DMA writes lane-linear 1 KiB pieces: usable wherever the source image is linear (not the padded original-order one)
     constexpr bool DMA = rd_is_dma(RD) && !(SRC == SRC_ORIGINAL && sizeof(T) >= 4);
-    Cell<T> base = Cell<T>::zero();
     if constexpr (!DMA) {
         u32x4 img[G::GROUPS];
         static_for<G::GROUPS>([&](auto Gi) {
@@ -232,10 +270,18 @@ __global__ __launch_bounds__(WG) void k_chain(ChainArgs a)
             base = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(a.bases + blk * 128u + c16 + opaque_zero()));
         wait_lds_dma();
     }
-    wave_lds_fence();
+}
 
+template <typename T, int SRC, int BODY>
+__device__ __forceinline__ void chain_stage_rows(unsigned w, const char* lds, unsigned lane, const Cell<T>& base, Cell<T>* x)
+{
+    using G = WaveBlock<T>;
+    constexpr int TB = G::TB;
+    constexpr int R = TB / 8;                                  // consecutive logical rows per lane
+    constexpr int N = 16 / (int)sizeof(T);                     // elements per cell = tile edge
+    const unsigned i = lane >> 3, c = lane & 7u, c16 = c * 16u;
+    const unsigned r0 = R * i;
     // ---- this lane's R consecutive rows of cell column c --------------------------------------------------------
-    Cell<T> x[R];
     if constexpr (SRC == SRC_PACKED) {
         if (w == 0) {                                          // macros.rs:118-125: every elem is 0
             static_for<R>([&](auto J) { x[decltype(J)::value] = Cell<T>::zero(); });
@@ -298,22 +344,18 @@ __global__ __launch_bounds__(WG) void k_chain(ChainArgs a)
 #endif
         static_for<R>([&](auto J) { x[decltype(J)::value] = x[decltype(J)::value].add(excl); });
     }
-    // the source image is dead once every lane has taken its rows (lanes re-use other lanes' cells below, except ROWS -> ROWS)
-    if constexpr (!(SRC == SRC_ROWS && SNK == SNK_ROWS)) wave_lds_fence();
+}
 
-    // ---- sink -------------------------------------------------------------------------------------------------------
-    if constexpr (SNK == SNK_ORIGINAL && sizeof(T) < 4) {
-        static_for<R>([&](auto J) {
-            *reinterpret_cast<u32x4*>(lds + G::row_cell_rt(r0 + decltype(J)::value) * 16u + c16) = __builtin_bit_cast(u32x4, x[decltype(J)::value]);
-        });
-        wave_lds_fence();
-        const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(a.out + blk * G::BLOCK_BYTES, 0, G::BLOCK_BYTES, 0x00020000);
-        static_for<G::GROUPS>([&](auto K) {                    // transpose.rs:19-21, one original-order cell per lane per KiB
-            const Cell<T> v = gather_original_cell<T>(lds, lane + 64u * decltype(K)::value);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rs, lane * 16u + decltype(K)::value * 1024u, 0, STORE_AUX);
-        });
-        return;
-    } else if constexpr (SNK == SNK_ORIGINAL) {
+// the rows -> the sink's LDS image (transposed rows; for u32 / u64 with SNK_ORIGINAL the padded original-order image)
+template <typename T, int SNK>
+__device__ __forceinline__ void chain_stage_image(const Cell<T>* x, char* lds, unsigned lane)
+{
+    using G = WaveBlock<T>;
+    constexpr int R = G::TB / 8;
+    constexpr int N = 16 / (int)sizeof(T);
+    const unsigned i = lane >> 3, c = lane & 7u, c16 = c * 16u;
+    const unsigned r0 = R * i;
+    if constexpr (SNK == SNK_ORIGINAL && sizeof(T) >= 4) {
         static_for<R / N>([&](auto Tt) {
             constexpr int t = decltype(Tt)::value;
             Cell<T> o[N];
@@ -328,36 +370,157 @@ __global__ __launch_bounds__(WG) void k_chain(ChainArgs a)
             *reinterpret_cast<u32x4*>(lds + G::row_cell_rt(r0 + decltype(J)::value) * 16u + c16) = __builtin_bit_cast(u32x4, x[decltype(J)::value]);
         });
     }
-    wave_lds_fence();
+}
+
+template <typename T, int SNK>
+__device__ __forceinline__ void chain_stage_out(const ChainArgs& a, uint64_t blk, unsigned w, uint64_t packed_at, char* lds, unsigned lane)
+{
+    using G = WaveBlock<T>;
     if constexpr (SNK == SNK_PACKED) {
-        if (w != 0) pack_from_lds_image<T>(lds, w, a.out + blk * (uint64_t)(128u * w), lane);   // macros.rs:52-53: W == 0 writes nothing
+        if (w != 0) pack_from_lds_image<T>(lds, w, a.out + packed_at, lane);   // macros.rs:52-53: W == 0 writes nothing
     } else {
         const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(a.out + blk * G::BLOCK_BYTES, 0, G::BLOCK_BYTES, 0x00020000);
-        static_for<G::GROUPS>([&](auto K) {
-            unsigned at = lane * 16u + decltype(K)::value * 1024u;
-            const unsigned to = at;
-            if constexpr (SNK == SNK_ORIGINAL) at = OriginalImage<T>::pad(at);
-            const u32x4 v = *reinterpret_cast<const u32x4*>(lds + at);
-            __builtin_amdgcn_raw_buffer_store_b128(v, out_rs, to, 0, STORE_AUX);
+        if constexpr (SNK == SNK_ORIGINAL && sizeof(T) < 4) {
+            static_for<G::GROUPS>([&](auto K) {                // transpose.rs:19-21, one original-order cell per lane per KiB
+                const Cell<T> v = gather_original_cell<T>(lds, lane + 64u * decltype(K)::value);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rs, lane * 16u + decltype(K)::value * 1024u, 0, STORE_AUX);
+            });
+        } else {
+            static_for<G::GROUPS>([&](auto K) {
+                unsigned at = lane * 16u + decltype(K)::value * 1024u;
+                const unsigned to = at;
+                if constexpr (SNK == SNK_ORIGINAL) at = OriginalImage<T>::pad(at);
+                const u32x4 v = *reinterpret_cast<const u32x4*>(lds + at);
+                __builtin_amdgcn_raw_buffer_store_b128(v, out_rs, to, 0, STORE_AUX);
+            });
+        }
+    }
+}
+
+template <typename T, int SRC, int BODY, int SNK, int RD = RD_VGPR, unsigned BPW = 1>
+__global__ __launch_bounds__(WG) void k_chain(ChainArgs a)
+{
+    using G = WaveBlock<T>;
+    constexpr int R = G::TB / 8;
+    constexpr unsigned WAVE_LDS = chain_wave_lds<T, SRC, SNK>();
+    extern __shared__ __attribute__((aligned(16))) char lds_all[];
+    constexpr unsigned TILE_BLOCKS = BPW * (WG / 64);
+    const uint64_t n_tiles = (a.n_blocks + TILE_BLOCKS - 1) / TILE_BLOCKS;
+    const uint64_t tile = xcd_tile(blockIdx.x, a.tiles_per_xcd, a.window_shift);
+    if (tile >= n_tiles) return;
+    const unsigned tid = threadIdx.x;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
+    const uint64_t first = tile * TILE_BLOCKS + (uint64_t)wave * BPW;
+    if (first >= a.n_blocks) return;
+    char* lds = lds_all + wave * (WAVE_LDS * BPW);
+    // the source image is dead once every lane has taken its rows (lanes re-use other lanes' cells in the sink image, except ROWS -> ROWS)
+    constexpr bool FENCE_BEFORE_IMAGE = !(SRC == SRC_ROWS && SNK == SNK_ROWS);
+    if constexpr (BPW == 1) {
+        unsigned w;
+        uint64_t packed_at;
+        if (!chain_block_meta<T, SRC, SNK>(a, first, lane, w, packed_at)) return;
+        Cell<T> base = Cell<T>::zero();
+        chain_stage_source<T, SRC, BODY, RD>(a, first, w, packed_at, lds, lane, base);
+        wave_lds_fence();
+        Cell<T> x[R];
+        chain_stage_rows<T, SRC, BODY>(w, lds, lane, base, x);
+        if constexpr (FENCE_BEFORE_IMAGE) wave_lds_fence();
+        chain_stage_image<T, SNK>(x, lds, lane);
+        wave_lds_fence();
+        chain_stage_out<T, SNK>(a, first, w, packed_at, lds, lane);
+    } else {
+        // narrow types: all of the wavefront's blocks requested up front by LDS-DMA (their images are linear in every layout),
+        // the bases behind them; then every stage for all of them
+        static_assert(sizeof(T) < 4, "the padded original-order image of u32 / u64 cannot be filled by LDS-DMA");
+        const uint64_t left = a.n_blocks - first;
+        const unsigned count = left < BPW ? (unsigned)left : BPW;
+        unsigned w[BPW];
+        uint64_t packed_at[BPW];
+        bool ok[BPW];
+        Cell<T> base[BPW];
+        // mixed widths: lane j fetches block first+j's width and offset -- one round trip for all of them -- then broadcasts
+        constexpr bool PACKED_SIDE = SRC == SRC_PACKED || SNK == SNK_PACKED;
+        const bool mixed = PACKED_SIDE && a.widths;            // wave-uniform
+        unsigned wv = 0;
+        uint64_t ov = 0;
+        if (mixed) {
+            const uint64_t mine = first + (lane < count ? lane : 0u);
+            wv = a.widths[mine];
+            ov = a.offsets[mine];
+        }
+        static_for<BPW>([&](auto Jt) {
+            constexpr unsigned j = decltype(Jt)::value;
+            ok[j] = j < count;
+            w[j] = PACKED_SIDE ? a.width : (unsigned)G::TB;
+            packed_at[j] = (first + j) * (uint64_t)(128u * w[j]);
+            if (mixed && ok[j]) {
+                w[j] = (unsigned)__builtin_amdgcn_readlane((int)wv, (int)j);
+                packed_at[j] = readlane_elem<uint64_t>(ov, j);
+                if (const uint32_t e = block_precondition(true, a.packed_bytes, w[j], packed_at[j], G::TB)) {
+                    raise_device_error(a.err_flag, e, lane);
+                    ok[j] = false;
+                }
+            }
+        });
+        static_for<BPW>([&](auto Jt) {
+            constexpr unsigned j = decltype(Jt)::value;
+            if (ok[j]) {                                        // wave-uniform
+                const __amdgpu_buffer_rsrc_t in_rs = chain_source<T, SRC>(a, first + j, w[j], packed_at[j]);
+                const unsigned w_in = SRC == SRC_PACKED ? w[j] : (unsigned)G::TB;
+                static_for<G::GROUPS>([&](auto Gi) {
+                    constexpr int g = decltype(Gi)::value;
+                    if (8u * g < w_in) dma_1k_to_lds<RD_DMA_NT, g * 1024>(in_rs, lds + j * WAVE_LDS, lane);
+                });
+            }
+        });
+        static_for<BPW>([&](auto Jt) {
+            constexpr unsigned j = decltype(Jt)::value;
+            base[j] = Cell<T>::zero();
+            if constexpr (BODY != CHAIN_NONE) {
+                if (ok[j]) base[j] = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(a.bases + (first + j) * 128u + (lane & 7u) * 16u + opaque_zero()));
+            }
+        });
+        wait_lds_dma();
+        wave_lds_fence();
+        Cell<T> x[BPW][R];
+        static_for<BPW>([&](auto Jt) {
+            constexpr unsigned j = decltype(Jt)::value;
+            if (ok[j]) chain_stage_rows<T, SRC, BODY>(w[j], lds + j * WAVE_LDS, lane, base[j], x[j]);
+        });
+        if constexpr (FENCE_BEFORE_IMAGE) wave_lds_fence();
+        static_for<BPW>([&](auto Jt) {
+            constexpr unsigned j = decltype(Jt)::value;
+            if (ok[j]) chain_stage_image<T, SNK>(x[j], lds + j * WAVE_LDS, lane);
+        });
+        wave_lds_fence();
+        static_for<BPW>([&](auto Jt) {
+            constexpr unsigned j = decltype(Jt)::value;
+            if (ok[j]) chain_stage_out<T, SNK>(a, first + j, w[j], packed_at[j], lds + j * WAVE_LDS, lane);
         });
     }
 }
 
 typedef hipError_t (*chain_launch_t)(const ChainArgs&, int waves, hipStream_t);
 
-template <typename T, int SRC, int BODY, int SNK, int RD = RD_VGPR>
+template <typename T, int SRC, int BODY, int SNK, int RD = RD_VGPR, unsigned BPW = 1>
 hipError_t launch_chain(const ChainArgs& a0, int waves, hipStream_t s)
 {
     if (a0.n_blocks == 0) return hipSuccess;
     ChainArgs a = a0;
-    const uint64_t n_tiles = (a.n_blocks + (WG / 64) - 1) / (WG / 64);
+    constexpr unsigned TILE_BLOCKS = BPW * (WG / 64);
+    const uint64_t n_tiles = (a.n_blocks + TILE_BLOCKS - 1) / TILE_BLOCKS;
     a.tiles_per_xcd = (n_tiles + 7) / 8;
     if (a.tiles_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;
-    a.window_shift = tile_window_shift(SNK == SNK_PACKED ? TRAFFIC_READ : SRC == SRC_PACKED ? TRAFFIC_WRITE : TRAFFIC_BALANCED, WG / 64);
-    const unsigned need = (WG / 64) * chain_wave_lds<T, SRC, SNK>();
+    a.window_shift = tile_window_shift(SNK == SNK_PACKED ? TRAFFIC_READ : SRC == SRC_PACKED ? TRAFFIC_WRITE : TRAFFIC_BALANCED, TILE_BLOCKS);
+    if constexpr (SRC == SRC_PACKED || SNK == SNK_PACKED) {
+        if (a.widths) a.window_shift |= TILE_MAP_ROTATE;     // per-block widths may be periodic (fl_widths.hpp: launch_widths)
+    } else {
+        a.widths = nullptr;
+    }
+    const unsigned need = TILE_BLOCKS * chain_wave_lds<T, SRC, SNK>();
     if (waves < 3) waves = 3;
     const unsigned pad = (CU_LDS_BYTES / (unsigned)waves) & ~1023u;
-    FL_LAUNCH((k_chain<T, SRC, BODY, SNK, RD>), dim3((unsigned)(a.tiles_per_xcd * 8)), dim3(WG), pad > need ? pad : need, s, a);
+    FL_LAUNCH((k_chain<T, SRC, BODY, SNK, RD, BPW>), dim3((unsigned)(a.tiles_per_xcd * 8)), dim3(WG), pad > need ? pad : need, s, a);
     return hipGetLastError();
 }
 
@@ -365,5 +528,7 @@ hipError_t launch_chain(const ChainArgs& a0, int waves, hipStream_t s)
 enum ChainOp { OP_UNDELTA_PACK = 0, OP_UNDELTA = 1, OP_DELTA = 2, OP_UNTRANSPOSE = 3, OP_TRANSPOSE = 4,
                OP_UNDELTA_PACK_UNTRANSPOSE = 5, OP_TRANSPOSE_DELTA_PACK = 6 };
 template <typename T> chain_launch_t chain_launcher(int op);
+// the mixed-width form (ChainArgs.widths != nullptr) of the three ops with a packed side
+template <typename T> chain_launch_t chain_widths_launcher(int op);
 
 }  // namespace fl

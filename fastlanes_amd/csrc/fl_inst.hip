@@ -67,6 +67,16 @@ template <> chain_launch_t chain_launcher<T>(int op)
     default: return nullptr;
     }
 }
+template <> chain_launch_t chain_widths_launcher<T>(int op)
+{
+    constexpr unsigned B = chain_blocks_per_wave<T>();
+    switch (op) {
+    case OP_UNDELTA_PACK: return &launch_chain<T, SRC_PACKED, CHAIN_UNDELTA, SNK_ROWS, RD_VGPR, B>;
+    case OP_UNDELTA_PACK_UNTRANSPOSE: return &launch_chain<T, SRC_PACKED, CHAIN_UNDELTA, SNK_ORIGINAL, RD_VGPR, B>;
+    case OP_TRANSPOSE_DELTA_PACK: return &launch_chain<T, SRC_ORIGINAL, CHAIN_DELTA, SNK_PACKED, RD_VGPR, B>;
+    default: return nullptr;
+    }
+}
 #elif FL_FAMILY == 8
 static constexpr WidthTable<T> t_undelta_untr = make_unpack_table<T, BODY_UNDELTA_UNTRANSPOSE>(Ws{});
 template <> const WidthTable<T>& unpack_table_impl<T, BODY_UNDELTA_UNTRANSPOSE>() { return t_undelta_untr; }

@@ -1,6 +1,6 @@
 // fl_scan.hpp -- widths[] -> offsets[] on the device (the exclusive prefix sum a caller of
 // bitpacking.rs:109-129 keeps implicitly by advancing its packed slice by 128*W bytes per block).
-// Included by exactly one translation unit of the library (fl_capi.hip): the kernels are not templates.
+// Included by exactly one translation unit of the library (fl_capi.hip), which instantiates what it uses.
 #pragma once
 #include "fl_kernels.hpp"
 
@@ -109,6 +109,29 @@ inline hipError_t launch_widths_to_offsets(const ScanArgs& a, hipStream_t s)
     FL_LAUNCH(k_scan_local, dim3(n_chunks), dim3(WG), 0, s, a);
     FL_LAUNCH(k_scan_chunks, dim3(1), dim3(WG), 0, s, a);
     FL_LAUNCH(k_scan_add, dim3(n_chunks), dim3(WG), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// An encoder's width choice for FoR with reference = the block's minimum (ffor.rs:24-36 packs `in[idx] - reference`, masked to
+// W bits by macros.rs:73): widths[b] = number of bits of maxs[b] - mins[b] (0 when the block is constant) is the smallest W that
+// loses nothing.  The reference has no width selection (closing note); this is the arithmetic its callers do
+// between block_min_max and for_pack.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(WG) void k_for_widths(const T* mins, const T* maxs, uint64_t n_blocks, uint8_t* widths)
+{
+    const uint64_t b = (uint64_t)blockIdx.x * WG + threadIdx.x;
+    if (b >= n_blocks) return;
+    const T span = (T)(maxs[b] - mins[b]);                    // wrapping, like every subtraction on the path
+    widths[b] = (uint8_t)(span == 0 ? 0 : 64 - __builtin_clzll((unsigned long long)span));
+}
+
+template <typename T>
+hipError_t launch_for_widths(const T* mins, const T* maxs, uint64_t n_blocks, uint8_t* widths, hipStream_t s)
+{
+    if (n_blocks == 0) return hipSuccess;
+    FL_LAUNCH((k_for_widths<T>), dim3((unsigned)((n_blocks + WG - 1) / WG)), dim3(WG), 0, s, mins, maxs, n_blocks, widths);
     return hipGetLastError();
 }
 

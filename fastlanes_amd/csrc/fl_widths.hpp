@@ -126,20 +126,36 @@ __device__ __forceinline__ uint64_t wave_uniform_u64(uint64_t v)
     return ((uint64_t)hi << 32) | lo;
 }
 
+// lane j's value of a per-lane element (j wave-uniform), broadcast: v_readlane_b32 once or twice
+template <typename T> __device__ __forceinline__ T readlane_elem(T v, unsigned j)
+{
+    if constexpr (sizeof(T) == 8) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)j);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), (int)j);
+        return (T)(((uint64_t)hi << 32) | lo);
+    } else {
+        return (T)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)j);
+    }
+}
+
 // Device-side error bits (include/fastlanes_amd.h: FL_DEVERR_*).  A block that violates a precondition is SKIPPED and its
 // bit is ORed into *err_flag -- the device-side form of the reference's unreachable!() / debug_assert (bitpacking.rs:78-80,93,126).
 constexpr uint32_t DEVERR_WIDTH = 1u, DEVERR_INDEX = 2u, DEVERR_ALIGN = 4u, DEVERR_BOUNDS = 8u;
 
 // 0 if block `blk` of a mixed-width column may be processed, else its error bits (wave-uniform; uniform-width calls pass
 // widths == nullptr and are validated on the host side of the ABI)
-__device__ __forceinline__ uint32_t block_precondition(const WidthsArgs& a, unsigned w, uint64_t off, unsigned type_bits)
+__device__ __forceinline__ uint32_t block_precondition(bool mixed, uint64_t packed_bytes, unsigned w, uint64_t off, unsigned type_bits)
 {
     if (w > type_bits) return DEVERR_WIDTH;                                    // bitpacking.rs:93,126 unreachable!()
-    if (!a.widths) return 0u;
+    if (!mixed) return 0u;
     uint32_t e = 0u;
     if (off & 15u) e |= DEVERR_ALIGN;                                           // 16-byte cells: the header's precondition
-    if (off > a.packed_bytes || 128ull * w > a.packed_bytes - off) e |= DEVERR_BOUNDS;   // bitpacking.rs:78-80,111-113
+    if (off > packed_bytes || 128ull * w > packed_bytes - off) e |= DEVERR_BOUNDS;   // bitpacking.rs:78-80,111-113
     return e;
+}
+__device__ __forceinline__ uint32_t block_precondition(const WidthsArgs& a, unsigned w, uint64_t off, unsigned type_bits)
+{
+    return block_precondition(a.widths != nullptr, a.packed_bytes, w, off, type_bits);
 }
 
 __device__ __forceinline__ void raise_device_error(uint32_t* err_flag, uint32_t bits, unsigned lane)
@@ -323,6 +339,8 @@ __device__ __forceinline__ void unpack_blocks_wave_prefetched(const WidthsArgs& 
     if (a.widths) wv = a.widths[mine];
     uint64_t ov = mine * (uint64_t)(128u * wv);
     if (a.offsets) ov = a.offsets[mine];
+    T rv = 0;                                                 // FoR: lane j holds block first+j's reference, fetched with the metadata
+    if (a.refs) rv = static_cast<const T*>(a.refs)[mine * a.ref_stride];
     for (unsigned j = 0; j < count; ++j) {                    // wave-uniform loop
         const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)wv, (int)j);
         const uint64_t off = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ov >> 32), (int)j) << 32) |
@@ -350,7 +368,7 @@ __device__ __forceinline__ void unpack_blocks_wave_prefetched(const WidthsArgs& 
             unpack_zero_width_block<T>(a, blk, lane);
             continue;
         }
-        const Cell<T> ref = a.refs ? block_ref<T>(a, blk) : Cell<T>::zero();
+        const Cell<T> ref = Cell<T>::splat(readlane_elem<T>(rv, j));
         unpack_lds_image_to_global<T>(a, blk, w, lds + j * G::BLOCK_BYTES, lane, ref);
     }
 }
@@ -533,7 +551,8 @@ __device__ __forceinline__ void pack_block_wave(const WidthsArgs& a, uint64_t bl
 }
 
 // pack's counterpart of unpack_blocks_wave_prefetched: the `count` unpacked blocks of the wavefront arrive by LDS-DMA, one
-// image each, before the first one is packed (plain BitPacking only: FoR subtracts on the way into the image).
+// image each, before the first one is packed.  FoR's `input[idx] - reference` (ffor.rs:32-34) is applied to the image in
+// place -- every lane to the cells it would have written on the VGPR route -- before any lane reads another lane's cells.
 template <typename T>
 __device__ __forceinline__ void pack_blocks_wave_prefetched(const WidthsArgs& a, uint64_t first, unsigned count, char* lds, unsigned lane)
 {
@@ -544,6 +563,8 @@ __device__ __forceinline__ void pack_blocks_wave_prefetched(const WidthsArgs& a,
     if (a.widths) wv = a.widths[mine];
     uint64_t ov = mine * (uint64_t)(128u * wv);
     if (a.offsets) ov = a.offsets[mine];
+    T rv = 0;                                                 // FoR: lane j holds block first+j's reference
+    if (a.refs) rv = static_cast<const T*>(a.refs)[mine * a.ref_stride];
     for (unsigned j = 0; j < count; ++j) {                    // wave-uniform loop
         const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(
             a.unpacked + (first + j) * G::BLOCK_BYTES, 0, G::BLOCK_BYTES, 0x00020000);
@@ -551,6 +572,17 @@ __device__ __forceinline__ void pack_blocks_wave_prefetched(const WidthsArgs& a,
         static_for<G::GROUPS>([&](auto K) { dma_1k_to_lds<RD_DMA_NT, decltype(K)::value * 1024>(in_rs, img, lane); });
     }
     wait_lds_dma();
+    if (a.refs) {                                             // wave-uniform
+        wave_lds_fence();
+        for (unsigned j = 0; j < count; ++j) {
+            const Cell<T> ref = Cell<T>::splat(readlane_elem<T>(rv, j));
+            char* img = lds + j * G::BLOCK_BYTES;
+            static_for<G::GROUPS>([&](auto K) {
+                u32x4* at = reinterpret_cast<u32x4*>(img + lane * 16u + decltype(K)::value * 1024u);
+                *at = __builtin_bit_cast(u32x4, __builtin_bit_cast(Cell<T>, *at).sub(ref));
+            });
+        }
+    }
     wave_lds_fence();
     for (unsigned j = 0; j < count; ++j) {
         const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)wv, (int)j);
@@ -569,7 +601,7 @@ template <typename T, int RD = RD_VGPR>
 __global__ __launch_bounds__(WG) void k_pack_widths(WidthsArgs a)
 {
     for_each_block_of_wave<T>(a, [&](uint64_t first, unsigned count, char* lds, unsigned lane) {
-        if (a.prefetch && count > 1 && !a.refs) {
+        if (a.prefetch && count > 1) {
             pack_blocks_wave_prefetched<T>(a, first, count, lds, lane);
             return;
         }

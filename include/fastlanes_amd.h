@@ -225,6 +225,33 @@ const uint8_t *fl_mixed_plan_widths(const fl_mixed_plan *plan);
     int fl_##S##_pack_widths(const uint8_t *widths, const uint64_t *offsets, const T *in,        \
                              T *packed, size_t packed_bytes, size_t n_blocks, uint32_t *err_flag, \
                              void *stream);                                                      \
+    /* FoR's and Delta's bodies over such a column -- the reference's const-W methods called with block b's width, as its     \
+     * callers do per chunk:  unfor_pack::<widths[b]> / for_pack::<widths[b]> (ffor.rs:24-50) with references[b*reference_stride] \
+     * (stride 0 broadcasts references[0]);  undelta_pack::<widths[b]> (delta.rs:47-63) with bases[b][LANES], its output in   \
+     * transposed order, and the two fused transpose extensions above.  Same per-block checks, same *err_flag. */             \
+    int fl_##S##_unfor_pack_widths(const uint8_t *widths, const uint64_t *offsets, const T *packed,  \
+                                   size_t packed_bytes, const T *references, size_t reference_stride, \
+                                   T *out, size_t n_blocks, uint32_t *err_flag, void *stream);        \
+    int fl_##S##_for_pack_widths(const uint8_t *widths, const uint64_t *offsets, const T *in,         \
+                                 const T *references, size_t reference_stride, T *packed,             \
+                                 size_t packed_bytes, size_t n_blocks, uint32_t *err_flag,            \
+                                 void *stream);                                                       \
+    int fl_##S##_undelta_pack_widths(const uint8_t *widths, const uint64_t *offsets, const T *packed, \
+                                     size_t packed_bytes, const T *bases, T *out, size_t n_blocks,    \
+                                     uint32_t *err_flag, void *stream);                               \
+    int fl_##S##_undelta_pack_untranspose_widths(const uint8_t *widths, const uint64_t *offsets,      \
+                                                 const T *packed, size_t packed_bytes, const T *bases, \
+                                                 T *out, size_t n_blocks, uint32_t *err_flag,         \
+                                                 void *stream);                                       \
+    int fl_##S##_transpose_delta_pack_widths(const uint8_t *widths, const uint64_t *offsets,          \
+                                             const T *in, const T *bases, T *packed,                  \
+                                             size_t packed_bytes, size_t n_blocks, uint32_t *err_flag, \
+                                             void *stream);                                           \
+    /* EXTENSION, the step between block_min_max and for_pack_widths in an encoder:  widths[b] = number of  \
+     * bits of maxs[b] - mins[b] (0 for a constant block) -- the smallest W for which for_pack::<W>(block b, mins[b])         \
+     * (ffor.rs:24-36; masked to W bits by macros.rs:73) loses nothing.  The reference itself selects no widths. */           \
+    int fl_##S##_for_widths(const T *mins, const T *maxs, size_t n_blocks, uint8_t *widths,          \
+                            void *stream);                                                            \
     /* unchecked_unpack_single (bitpacking.rs:58,181-200) over such a column, batched: out[k] = element  \
      * indices[k] (= block*1024 + index_in_block) of the column; an index past the column, a width  \
      * > T or a block outside the packed column writes 0 and ORs its FL_DEVERR_* bit into *err_flag */ \

@@ -64,6 +64,12 @@ template <typename T> struct Abi;
         static constexpr auto unpack_widths = fl_##S##_unpack_widths;                                \
         static constexpr auto pack_widths = fl_##S##_pack_widths;                                    \
         static constexpr auto unpack_single_widths = fl_##S##_unpack_single_widths;                  \
+        static constexpr auto unfor_pack_widths = fl_##S##_unfor_pack_widths;                        \
+        static constexpr auto for_pack_widths = fl_##S##_for_pack_widths;                            \
+        static constexpr auto undelta_pack_widths = fl_##S##_undelta_pack_widths;                    \
+        static constexpr auto undelta_pack_untranspose_widths = fl_##S##_undelta_pack_untranspose_widths; \
+        static constexpr auto transpose_delta_pack_widths = fl_##S##_transpose_delta_pack_widths;    \
+        static constexpr auto for_widths = fl_##S##_for_widths;                                      \
         static constexpr auto unpack_batch = fl_##S##_unpack_batch;                                  \
         static constexpr auto pack_batch = fl_##S##_pack_batch;                                      \
         static constexpr auto unfor_pack_batch = fl_##S##_unfor_pack_batch;                          \
@@ -357,6 +363,36 @@ inline void unpack_single_widths_device(const std::uint8_t* d_widths, const std:
                                         std::size_t n_blocks, const std::uint64_t* d_indices, std::size_t n_indices, T* d_out,
                                         std::uint32_t* d_err_flag = nullptr, void* stream = nullptr)
 { detail::check(detail::Abi<T>::unpack_single_widths(d_widths, d_offsets, d_packed, packed_bytes, n_blocks, d_indices, n_indices, d_out, d_err_flag, stream), "unpack_single_widths"); }
+// ... with FoR's / Delta's bodies: `for b { FoR::unfor_pack::<widths[b]>(.., d_references[b * reference_stride], ..) }` (ffor.rs:24-50),
+// `for b { Delta::undelta_pack::<widths[b]>(.., &d_bases[b], ..) }` (delta.rs:47-63; `untranspose`: straight to original order), and the
+// fused encode `pack::<widths[b]>(delta(transpose(..), &d_bases[b]))`.
+template <typename T>
+inline void unfor_pack_widths_device(const std::uint8_t* d_widths, const std::uint64_t* d_offsets, const T* d_packed, std::size_t packed_bytes,
+                                     const T* d_references, std::size_t reference_stride, T* d_out, std::size_t n_blocks,
+                                     std::uint32_t* d_err_flag = nullptr, void* stream = nullptr)
+{ detail::check(detail::Abi<T>::unfor_pack_widths(d_widths, d_offsets, d_packed, packed_bytes, d_references, reference_stride, d_out, n_blocks, d_err_flag, stream), "unfor_pack_widths"); }
+template <typename T>
+inline void for_pack_widths_device(const std::uint8_t* d_widths, const std::uint64_t* d_offsets, const T* d_in, const T* d_references,
+                                   std::size_t reference_stride, T* d_packed, std::size_t packed_bytes, std::size_t n_blocks,
+                                   std::uint32_t* d_err_flag = nullptr, void* stream = nullptr)
+{ detail::check(detail::Abi<T>::for_pack_widths(d_widths, d_offsets, d_in, d_references, reference_stride, d_packed, packed_bytes, n_blocks, d_err_flag, stream), "for_pack_widths"); }
+template <typename T>
+inline void undelta_pack_widths_device(const std::uint8_t* d_widths, const std::uint64_t* d_offsets, const T* d_packed, std::size_t packed_bytes,
+                                       const T* d_bases, T* d_out, std::size_t n_blocks, bool untranspose = false,
+                                       std::uint32_t* d_err_flag = nullptr, void* stream = nullptr)
+{
+    detail::check((untranspose ? detail::Abi<T>::undelta_pack_untranspose_widths : detail::Abi<T>::undelta_pack_widths)(
+                      d_widths, d_offsets, d_packed, packed_bytes, d_bases, d_out, n_blocks, d_err_flag, stream), "undelta_pack_widths");
+}
+template <typename T>
+inline void transpose_delta_pack_widths_device(const std::uint8_t* d_widths, const std::uint64_t* d_offsets, const T* d_in, const T* d_bases,
+                                               T* d_packed, std::size_t packed_bytes, std::size_t n_blocks,
+                                               std::uint32_t* d_err_flag = nullptr, void* stream = nullptr)
+{ detail::check(detail::Abi<T>::transpose_delta_pack_widths(d_widths, d_offsets, d_in, d_bases, d_packed, packed_bytes, n_blocks, d_err_flag, stream), "transpose_delta_pack_widths"); }
+// An encoder's width choice between block_min_max and for_pack_widths: widths[b] = bit length of maxs[b] - mins[b] (extension).
+template <typename T>
+inline void for_widths_device(const T* d_mins, const T* d_maxs, std::size_t n_blocks, std::uint8_t* d_widths, void* stream = nullptr)
+{ detail::check(detail::Abi<T>::for_widths(d_mins, d_maxs, n_blocks, d_widths, stream), "for_widths"); }
 template <typename T>
 inline void widths_to_offsets_device(const std::uint8_t* d_widths, std::size_t n_blocks, std::uint64_t* d_offsets,
                                      std::uint64_t* d_total_bytes = nullptr, std::uint32_t* d_err_flag = nullptr, void* stream = nullptr)

@@ -145,10 +145,12 @@ template <typename T> __global__ void k_per_lane(Args g)
     if (t >= g.n_blocks * L) return;
     const uint64_t b = t / L;
     const unsigned lane = (unsigned)(t % L);
-    const unsigned w = g.width;
+    unsigned w = g.width;
+    uint64_t pk_off = b * (uint64_t)(1024 * w / TB);
+    if (g.widths) { w = g.widths[b]; pk_off = g.offsets[b] / sizeof(T); }
     const T* a = static_cast<const T*>(g.a);
     const T* got = static_cast<const T*>(g.got);
-    const T* pk = a + b * (uint64_t)(1024 * w / TB);
+    const T* pk = a + pk_off;
     T run = static_cast<const T*>(g.aux)[b * L + lane];
     unsigned bad = 0;
     for (unsigned row = 0; row < TB; ++row) {

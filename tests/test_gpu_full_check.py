@@ -146,6 +146,10 @@ def test_the_checker_itself_against_the_oracle(checker, oracle, ty):
     dcol, dw_, doff = to_dev(col), to_dev(widths), to_dev(off[:-1])
     assert checker.mismatches(ty, "unpack", 0, dcol, to_dev(want), n, widths=dw_, offsets=doff) == 0
     assert checker.mismatches(ty, "unpack", 0, dcol, corrupt(to_dev(want), at), n, widths=dw_, offsets=doff) == 1
+    want = np.concatenate([oracle.undelta_pack(ty, int(w), col[int(off[b]) // (T // 8):int(off[b + 1]) // (T // 8)], bases[b * L:(b + 1) * L])
+                           for b, w in enumerate(widths)])
+    assert checker.mismatches(ty, "undelta_pack", 0, dcol, to_dev(want), n, aux=to_dev(bases), widths=dw_, offsets=doff) == 0
+    assert checker.mismatches(ty, "undelta_pack", 0, dcol, corrupt(to_dev(want), at), n, aux=to_dev(bases), widths=dw_, offsets=doff) == 1
 
 
 class BackgroundLoad:
@@ -244,6 +248,24 @@ def test_every_element_of_every_family_under_load(fl, checker, ty, policy):
         under_load(lambda: fl.pack_widths(widths, offsets, un, back, check=True))
         differing = checker.mismatches(ty, "pack", 0, un, back, n, widths=widths, offsets=offsets)
         assert differing == 0, (ty, policy, "pack_widths", f"{differing} elements differ")
+        # ... with FoR's and Delta's bodies (fl_<ty>_unfor_pack_widths, ..): the same checker ops with per-block widths
+        for name, op, src, call, kw in (
+                ("unfor_pack_widths", "unpack", col, lambda: fl.unfor_pack_widths(widths, offsets, col, refs), dict(aux=refs, aux_stride=1)),
+                ("undelta_pack_widths", "undelta_pack", col, lambda: fl.undelta_pack_widths(widths, offsets, col, bases), dict(aux=bases)),
+                ("undelta_pack_untranspose_widths", "undelta_pack_untranspose", col,
+                 lambda: fl.undelta_pack_widths(widths, offsets, col, bases, untranspose=True), dict(aux=bases))):
+            got = under_load(call)
+            differing = checker.mismatches(ty, op, 0, src, got, n, widths=widths, offsets=offsets, **kw)
+            assert differing == 0, (ty, policy, name, f"{differing} elements differ")
+            del got
+        for name, op, call, kw in (
+                ("for_pack_widths", "pack", lambda o: fl.for_pack_widths(widths, offsets, un, refs, o), dict(aux=refs, aux_stride=1)),
+                ("transpose_delta_pack_widths", "transpose_delta_pack", lambda o: fl.transpose_delta_pack_widths(widths, offsets, un, bases, o),
+                 dict(aux=bases))):
+            back.zero_()
+            under_load(lambda: call(back))
+            differing = checker.mismatches(ty, op, 0, un, back, n, widths=widths, offsets=offsets, **kw)
+            assert differing == 0, (ty, policy, name, f"{differing} elements differ")
         load.drain()
     finally:
         lib.fl_internal_set_kernel_policy(0)

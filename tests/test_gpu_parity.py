@@ -501,6 +501,139 @@ def test_unpack_pack_widths_device_resident(fl, oracle, ty):
     assert fl.unpack_widths(e8, o0, torch.empty(0, dtype=tdt, device="cuda:0")).numel() == 0
 
 
+@pytest.mark.parametrize("waves", [0, 4, 8])
+@pytest.mark.parametrize("ty", TYS)
+def test_for_and_delta_over_mixed_width_columns(fl, oracle, kernel_policy, ty, waves):
+    """FoR's and Delta's bodies over a device-resident mixed-width column: the reference's const-W methods called with block
+    b's width (ffor.rs:24-50, delta.rs:47-63) -- per block against the oracle, every width 0..T, ragged counts, references
+    per block and broadcast, the fused transpose extensions, the per-block device checks, and the encoder chain
+    block_min_max -> for_widths -> widths_to_offsets -> for_pack_widths -> unfor_pack_widths as a lossless round trip."""
+    import torch
+    kernel_policy(2 + 256 * waves if waves else 0)
+    T = tbits(ty)
+    esz = T // 8
+    L = lanes(ty)
+    tdt = {"u8": torch.uint8, "u16": torch.uint16, "u32": torch.uint32, "u64": torch.uint64}[ty]
+    rng = np.random.default_rng(777 + T + waves)
+    for n, widths in ((T + 1, np.arange(T + 1)), (1, np.array([T // 2])), (263, rng.integers(0, T + 1, size=263))):
+        widths = widths.astype(np.uint8)
+        dw = torch.from_numpy(widths).cuda()
+        doff, dtotal = fl.widths_to_offsets(ty, dw)
+        off = np.concatenate([[0], np.cumsum(widths.astype(np.int64) * 128)]) // esz
+        col = values(ty, int(off[-1]), 6100 + n)
+        refs = values(ty, n, 6101 + n)
+        bases = values(ty, n * L, 6102 + n)
+        v = values(ty, n * 1024, 6103 + n)
+        blocks = [(b, int(w), col[off[b]:off[b + 1]]) for b, w in enumerate(widths)]
+        # FoR decode, references per block and one for all (reference_stride 0)
+        got = to_np(fl.unfor_pack_widths(dw, doff, to_dev(col), to_dev(refs)), ty)
+        want = np.concatenate([oracle.unfor_pack(ty, w, pk, refs[b]) for b, w, pk in blocks])
+        assert np.array_equal(got, want), (ty, n, "unfor_pack_widths")
+        if n > 1:
+            got = to_np(fl.unfor_pack_widths(dw, doff, to_dev(col), to_dev(refs[:1])), ty)
+            want = np.concatenate([oracle.unfor_pack(ty, w, pk, refs[0]) for b, w, pk in blocks])
+            assert np.array_equal(got, want), (ty, n, "unfor_pack_widths, one reference")
+        # FoR encode: over-wide differences are truncated like for_pack::<W> does (macros.rs:73)
+        dpk = torch.zeros(int(off[-1]), dtype=tdt, device="cuda:0")
+        fl.for_pack_widths(dw, doff, to_dev(v), to_dev(refs), dpk)
+        wantp = np.concatenate([oracle.for_pack(ty, w, v[b * 1024:(b + 1) * 1024], refs[b]) for b, w, _ in blocks]
+                               + [np.zeros(0, dtype=TYPES[ty][0])])
+        assert np.array_equal(to_np(dpk, ty), wantp), (ty, n, "for_pack_widths")
+        # Delta decode (transposed order, as the reference returns it) and straight to original order
+        got = to_np(fl.undelta_pack_widths(dw, doff, to_dev(col), to_dev(bases)), ty)
+        want = np.concatenate([oracle.undelta_pack(ty, w, pk, bases[b * L:(b + 1) * L]) for b, w, pk in blocks])
+        assert np.array_equal(got, want), (ty, n, "undelta_pack_widths")
+        got = to_np(fl.undelta_pack_widths(dw, doff, to_dev(col), to_dev(bases), untranspose=True), ty)
+        assert np.array_equal(got, oracle.batch("untranspose", ty, None, want)), (ty, n, "undelta_pack_untranspose_widths")
+        # Delta encode from original order
+        dpk = torch.zeros(int(off[-1]), dtype=tdt, device="cuda:0")
+        fl.transpose_delta_pack_widths(dw, doff, to_dev(v), to_dev(bases), dpk)
+        dl = oracle.batch("delta", ty, None, oracle.batch("transpose", ty, None, v), aux=bases)
+        wantp = np.concatenate([oracle.pack(ty, w, dl[b * 1024:(b + 1) * 1024]) for b, w, _ in blocks] + [np.zeros(0, dtype=TYPES[ty][0])])
+        assert np.array_equal(to_np(dpk, ty), wantp), (ty, n, "transpose_delta_pack_widths")
+    # the encoder chain: values whose blocks span different ranges -> min / max -> widths -> offsets -> for_pack -> unfor_pack
+    n = 150
+    span_bits = rng.integers(0, T + 1, size=n)
+    lo = values(ty, n, 6200)
+    v = np.empty(n * 1024, dtype=TYPES[ty][0])
+    raw = values(ty, n * 1024, 6201)
+    for b in range(n):
+        m = np.array((1 << int(span_bits[b])) - 1, dtype=np.uint64).astype(TYPES[ty][0])
+        blk = raw[b * 1024:(b + 1) * 1024] & m
+        room = np.array(np.iinfo(TYPES[ty][0]).max, dtype=TYPES[ty][0]) - m     # keep min + span inside the type: no wrap
+        v[b * 1024:(b + 1) * 1024] = blk + np.minimum(lo[b], room)
+    dv = to_dev(v)
+    mins, maxs = fl.BitPacking.block_min_max(dv)
+    dw = fl.for_widths(mins, maxs)
+    vb = v.reshape(n, 1024)
+    want_w = np.array([int(int(vb[b].max()) - int(vb[b].min())).bit_length() for b in range(n)], dtype=np.uint8)
+    assert np.array_equal(dw.cpu().numpy(), want_w), (ty, "for_widths")
+    doff, dtotal = fl.widths_to_offsets(ty, dw)
+    dpk = torch.zeros(int(dtotal.item()) // esz, dtype=tdt, device="cuda:0")
+    fl.for_pack_widths(dw, doff, dv, mins, dpk)
+    back = fl.unfor_pack_widths(dw, doff, dpk, mins)
+    assert np.array_equal(to_np(back, ty), v), (ty, "FoR encoder chain is lossless")
+    assert int(dtotal.item()) == int(want_w.astype(np.int64).sum()) * 128
+    # for_widths on arbitrary pairs: wrapping difference, bit length
+    a, b2 = values(ty, 1000, 6300), values(ty, 1000, 6301)
+    gw = fl.for_widths(to_dev(a), to_dev(b2)).cpu().numpy()
+    ww = np.array([int((int(y) - int(x)) % (1 << T)).bit_length() for x, y in zip(a, b2)], dtype=np.uint8)
+    assert np.array_equal(gw, ww)
+    # per-block device checks: the block is skipped, everything else is done, the flag says why
+    n = 40
+    widths = rng.integers(1, T + 1, size=n).astype(np.uint8)
+    off = np.concatenate([[0], np.cumsum(widths.astype(np.int64) * 128)])
+    total = int(off[-1])
+    col = values(ty, total // esz, 6400)
+    refs, bases = values(ty, n, 6401), values(ty, n * L, 6402)
+    dw, doff = torch.from_numpy(widths).cuda(), torch.from_numpy(off[:-1].copy()).cuda()
+    good_for = to_np(fl.unfor_pack_widths(dw, doff, to_dev(col), to_dev(refs)), ty)
+    good_delta = to_np(fl.undelta_pack_widths(dw, doff, to_dev(col), to_dev(bases)), ty)
+    bad_w = widths.copy()
+    bad_w[7] = T + 1
+    cases = [("width", 1, torch.from_numpy(bad_w).cuda(), doff, 7)]
+    for what, status, delta_off in (("misaligned", 4, 8), ("outside", 6, 1 << 40)):
+        boff = off[:-1].copy()
+        boff[5] += delta_off
+        cases.append((what, status, dw, torch.from_numpy(boff).cuda(), 5))
+    for what, status, w_, o_, skipped in cases:
+        for name, call, good in (("unfor_pack_widths", lambda **k: fl.unfor_pack_widths(w_, o_, to_dev(col), to_dev(refs), **k), good_for),
+                                 ("undelta_pack_widths", lambda **k: fl.undelta_pack_widths(w_, o_, to_dev(col), to_dev(bases), **k), good_delta)):
+            with pytest.raises(fl.FastLanesError) as ei:
+                call()
+            assert ei.value.status == status, (what, name)
+            out = torch.zeros(n * 1024, dtype=tdt, device="cuda:0")
+            call(output=out, check=False)
+            g = to_np(out, ty)
+            keep = np.ones(n * 1024, dtype=bool)
+            keep[skipped * 1024:(skipped + 1) * 1024] = False
+            assert np.array_equal(g[keep], good[keep]) and not g[~keep].any(), (what, name)
+        v = values(ty, n * 1024, 6403)
+        for name, call in (("for_pack_widths", lambda o: fl.for_pack_widths(w_, o_, to_dev(v), to_dev(refs), o)),
+                           ("transpose_delta_pack_widths", lambda o: fl.transpose_delta_pack_widths(w_, o_, to_dev(v), to_dev(bases), o))):
+            guard = torch.full((total // esz,), 0x5A, dtype=tdt, device="cuda:0")
+            with pytest.raises(fl.FastLanesError) as ei:
+                call(guard)
+            assert ei.value.status == status, (what, name)
+            lo5, k5 = int(off[skipped]) // esz, packed_len(ty, int(widths[skipped]))
+            assert (to_np(guard, ty)[lo5:lo5 + k5] == 0x5A).all(), (what, name, "the skipped block was written")
+    # a column of width-0 blocks has no packed bytes: FoR yields the references, Delta the bases repeated down every lane
+    z = torch.zeros(3, dtype=torch.uint8, device="cuda:0")
+    zoff, _ = fl.widths_to_offsets(ty, z)
+    empty = torch.empty(0, dtype=tdt, device="cuda:0")
+    r3, b3 = values(ty, 3, 6500), values(ty, 3 * L, 6501)
+    assert np.array_equal(to_np(fl.unfor_pack_widths(z, zoff, empty, to_dev(r3)), ty), np.repeat(r3, 1024))
+    want = np.concatenate([oracle.undelta_pack(ty, 0, np.zeros(0, dtype=TYPES[ty][0]), b3[b * L:(b + 1) * L]) for b in range(3)])
+    assert np.array_equal(to_np(fl.undelta_pack_widths(z, zoff, empty, to_dev(b3)), ty), want)
+    fl.for_pack_widths(z, zoff, to_dev(values(ty, 3 * 1024, 1)), to_dev(r3), empty)
+    fl.transpose_delta_pack_widths(z, zoff, to_dev(values(ty, 3 * 1024, 1)), to_dev(b3), empty)
+    # argument checks of the mirror
+    with pytest.raises(ValueError):
+        fl.unfor_pack_widths(dw, doff, to_dev(col), to_dev(refs[:3]))
+    with pytest.raises(ValueError):
+        fl.undelta_pack_widths(dw, doff, to_dev(col), to_dev(bases[:L]))
+
+
 @pytest.mark.parametrize("ty", TYS)
 def test_batch_of_small_arrays_vs_oracle(fl, oracle, ty):
     """fl_<ty>_unpack_batch / _pack_batch: many small arrays (a columnar engine's chunks), each with its own width and block

@@ -23,6 +23,9 @@ GB = 12
 if ALL:
     cases = [(ty, w) for ty in ("u32", "u64", "u16", "u8") for w in range(TD[ty][1] + 1)]
     GB = 6
+if "--types" in sys.argv:          # e.g. --types u16,u8: re-sweep some element types only (round 4: the narrow types' chain kernels
+    keep = sys.argv[sys.argv.index("--types") + 1].split(",")   # now keep several blocks in flight per wavefront)
+    cases = [c for c in cases if c[0] in keep]
 if "--gb" in sys.argv:             # bytes moved per launch; BASELINE's config 4 is a 57.6 GB launch
     GB = int(sys.argv[sys.argv.index("--gb") + 1])
 print("GB/s, median of %d; cc = cell-column, then wave-per-block at %s waves/SIMD" % (ROUNDS, " ".join(map(str, WAVES))))

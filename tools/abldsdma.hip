@@ -125,7 +125,11 @@ template <typename T, int SRC, int BODY, int SNK> void chain_case(const char* na
     const bool pin = SRC == SRC_PACKED, pout = SNK == SNK_PACKED;
     const uint64_t bpb = (pin ? 128ull * W : 128ull * TB) + (pout ? 128ull * W : 128ull * TB) + (BODY != CHAIN_NONE ? 128 : 0);
     const uint64_t n = (12ull << 30) / bpb;
-    ChainArgs a{g_in, nullptr, g_aux, n, 0, W};
+    ChainArgs a{};
+    a.in = g_in;
+    a.bases = g_aux;
+    a.n_blocks = n;
+    a.width = W;
     std::vector<Variant> vs;
     for (int wv : waves) {
         auto nm = [&](int rd) { return std::string(RDN(rd)) + ", " + std::to_string(wv) + " waves/SIMD"; };

@@ -17,6 +17,7 @@ TDT = {"u8": torch.uint8, "u16": torch.uint16, "u32": torch.uint32, "u64": torch
 ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=9)
 ap.add_argument("--gb", type=float, default=16.0)
+ap.add_argument("--for", dest="ffor", action="store_true", help="FoR's bodies (for_pack / unfor_pack with a reference per block) instead of pack / unpack")
 ap.add_argument("--wide", action="store_true", help="u32 W=7 / 20 and u64 W=17 instead of the narrow types (does the headline want more blocks in flight?)")
 args = ap.parse_args()
 POL = {"table": 0, "wpb 8x1": 2 + 256 * 8, "wpb 8x2 pf": 2 + 256 * 8 + 65536 * 2 + (1 << 24), "wpb 8x4 pf": 2 + 256 * 8 + 65536 * 4 + (1 << 24),
@@ -35,7 +36,13 @@ for ty, T in ((("u32", 32), ("u64", 64)) if args.wide else (("u8", 8), ("u16", 1
         pk = torch.empty(n * 128 * w, dtype=torch.uint8, device=dev)
         assert lib.fl_fill_random(un.data_ptr(), un.numel() & ~7, 1, None) == 0 and lib.fl_fill_random(pk.data_ptr(), pk.numel() & ~7, 2, None) == 0
         unv, pkv = un.view(TDT[ty]), pk.view(TDT[ty])
-        for op, f in (("unpack", lambda: fl.BitPacking.unpack(w, pkv, output=unv)), ("pack", lambda: fl.BitPacking.pack(w, unv, output=pkv))):
+        ops = (("unpack", lambda: fl.BitPacking.unpack(w, pkv, output=unv)), ("pack", lambda: fl.BitPacking.pack(w, unv, output=pkv)))
+        if args.ffor:
+            refs = torch.empty(n * (T // 8), dtype=torch.uint8, device=dev)
+            assert lib.fl_fill_random(refs.data_ptr(), refs.numel() & ~7, 3, None) == 0
+            refv = refs.view(TDT[ty])
+            ops = (("unfor", lambda: fl.FoR.unfor_pack(w, pkv, refv, output=unv)), ("for", lambda: fl.FoR.for_pack(w, unv, refv, output=pkv)))
+        for op, f in ops:
             ms = {k: [] for k in POL}
             for k, p in POL.items():
                 lib.fl_internal_set_kernel_policy(p); f()

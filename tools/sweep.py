@@ -409,6 +409,63 @@ def main():
                 print(f"benches/transpose.rs shape, {name} {ty}: {n} blocks {ms:8.4f} ms ({n * 2 * 128 * T / ms / 1e6:7.1f} GB/s, "
                       f"{n * 1024 / ms / 1e6:7.1f} Gint/s); one block, device tier: {us:6.2f} us per call", flush=True)
         return
+    if args.cases == "mixed":
+        # FoR's and Delta's bodies over device-resident mixed-width columns (fl_<ty>_unfor_pack_widths, ..) next to plain
+        # unpack_widths / pack_widths of the same column, and an encoder's whole chain: block_min_max -> for_widths ->
+        # widths_to_offsets -> for_pack_widths (two passes over the values).  Widths seeded-random in 1..T-1, separate tensors.
+        lib = fl.load()
+        for ty in ("u32", "u64", "u16", "u8"):
+            T, esz = ESZ[ty] * 8, ESZ[ty]
+            L = 1024 // T
+            n = max(64, int(args.gb * 1e9 / (128 * T * 1.5)))
+            g = torch.Generator(device=dev); g.manual_seed(31 + T)
+            widths = torch.randint(1, T, (n,), dtype=torch.int64, device=dev, generator=g).to(torch.uint8)
+            offsets, total = fl.widths_to_offsets(ty, widths)
+            pbytes = int(total.item())
+            col = rnd(pbytes, 1).view(TDT[ty])
+            # references with the top bit clear: reference + field never wraps, so the encoder below finds widths <= the decoder's
+            refs = (rnd(n * 8, 2).view(torch.int64) & ((1 << (T - 1)) - 1)).view(torch.uint8).view(-1, 8)[:, :esz].contiguous().view(TDT[ty]).reshape(-1)
+            bases = rnd(n * 128, 3).view(TDT[ty])
+            un = torch.empty(n * 1024, dtype=TDT[ty], device=dev)
+            back = torch.empty_like(col)
+            mm = (torch.empty(n, dtype=TDT[ty], device=dev), torch.empty(n, dtype=TDT[ty], device=dev))
+            fl.unfor_pack_widths(widths, offsets, col, refs, output=un)       # the values every encoder row below reads
+
+            def encoder_chain():
+                lo, hi = fl.BitPacking.block_min_max(un, output=mm)
+                w2 = fl.for_widths(lo, hi)
+                o2, _ = fl.widths_to_offsets(ty, w2)
+                fl.for_pack_widths(w2, o2, un, lo, back, check=False)
+
+            two_sided = pbytes + n * 128 * T
+            rows = (
+                ("unpack_widths", two_sided, lambda: fl.unpack_widths(widths, offsets, col, output=un, check=False)),
+                ("unfor_pack_widths", two_sided, lambda: fl.unfor_pack_widths(widths, offsets, col, refs, output=un, check=False)),
+                ("undelta_pack_widths", two_sided + n * 128, lambda: fl.undelta_pack_widths(widths, offsets, col, bases, output=un, check=False)),
+                ("undelta_pack_untranspose_widths", two_sided + n * 128,
+                 lambda: fl.undelta_pack_widths(widths, offsets, col, bases, output=un, check=False, untranspose=True)),
+                ("restore", 0, lambda: fl.unfor_pack_widths(widths, offsets, col, refs, output=un, check=False)),
+                ("pack_widths", two_sided, lambda: fl.pack_widths(widths, offsets, un, back, check=False)),
+                ("for_pack_widths", two_sided, lambda: fl.for_pack_widths(widths, offsets, un, refs, back, check=False)),
+                ("transpose_delta_pack_widths", two_sided + n * 128, lambda: fl.transpose_delta_pack_widths(widths, offsets, un, bases, back, check=False)),
+                ("FoR encoder chain (4 launches)", 2 * n * 128 * T + pbytes, encoder_chain),
+            )
+            for name, nbytes, f in rows:
+                f(); f()
+                torch.cuda.synchronize()
+                if not nbytes:
+                    continue
+                ms = []
+                for _ in range(args.reps):
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(); f(); b.record(); b.synchronize()
+                    ms.append(a.elapsed_time(b))
+                med = sorted(ms)[len(ms) // 2]
+                print(f"{name:32s} {ty:4s} n={n:>9d} {med:9.4f} ms {nbytes / med / 1e6:8.1f} GB/s {nbytes / med / 8e9:.3f} "
+                      f"{n * 1024 / med / 1e6:8.1f} Gint/s", flush=True)
+            del col, un, back, refs, bases, mm
+            torch.cuda.empty_cache()
+        return
     if args.cases == "single":
         # batched unpack_single (random access): 64 M random indices into a 1 M-block u32 W=7 column
         n, k = 1_000_000, 64_000_000
