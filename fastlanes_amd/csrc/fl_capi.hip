@@ -38,7 +38,7 @@ inline int chosen_waves(unsigned type_bits, unsigned w, fl::WaveOp op, bool with
     const int p = g_kernel_policy.load(std::memory_order_relaxed);
     int table = fl::wave_policy(type_bits, w, op);
     // the one exception to the generated table (fl_dispatch.hpp: u8_two_blocks_in_flight)
-    if ((op == fl::WAVE_PACK || op == fl::WAVE_UNPACK) && fl::u8_two_blocks_in_flight(type_bits, w, op == fl::WAVE_PACK, op == fl::WAVE_PACK && with_refs))
+    if ((op == fl::WAVE_PACK || op == fl::WAVE_UNPACK) && fl::u8_two_blocks_in_flight(type_bits, w, op == fl::WAVE_PACK, with_refs))
         table = 8;
     const bool per_type = op == fl::WAVE_UNDELTA || op == fl::WAVE_DELTA || op == fl::WAVE_TRANSPOSE || op == fl::WAVE_UNTRANSPOSE;
     if ((p & 0xff) == 1) return (per_type || fl::cell_column_built(type_bits, w, op)) ? 0 : table;
@@ -210,7 +210,7 @@ template <typename T>
 int dev_unfor_pack(unsigned w, const T* in, const T* refs, size_t stride, T* out, size_t n, void* s)
 {
     if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
-    if (const int waves = chosen_waves(Elem<T>::BITS, w, WAVE_UNPACK)) {
+    if (const int waves = chosen_waves(Elem<T>::BITS, w, WAVE_UNPACK, true)) {
         if (n && !refs) return FL_ERR_NULL;
         return run_wave_uniform<T>(false, waves, w, in, out, refs, stride, n, s);
     }

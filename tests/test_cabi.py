@@ -65,6 +65,39 @@ def test_width_validation_needs_no_gpu(lib):
         assert getattr(lib, f"fl_{ty}_unpack_single_host")(3, p, 1, 1024, v) == 2  # bitpacking.rs:152
 
 
+def test_mixed_width_for_delta_validation_needs_no_gpu(lib):
+    """fl_<ty>_*_widths (FoR / Delta over mixed-width columns) and fl_<ty>_for_widths: the argument checks that precede any launch."""
+    buf = np.zeros(4096, dtype=np.uint64)
+    p = buf.ctypes.data
+    for ty in ("u8", "u16", "u32", "u64"):
+        f = lambda m: getattr(lib, f"fl_{ty}_{m}")
+        # empty column: nothing to do, whatever the pointers
+        assert f("unfor_pack_widths")(None, None, None, 0, None, 1, None, 0, None, None) == 0
+        assert f("for_pack_widths")(None, None, None, None, 1, None, 0, 0, None, None) == 0
+        assert f("undelta_pack_widths")(None, None, None, 0, None, None, 0, None, None) == 0
+        assert f("undelta_pack_untranspose_widths")(None, None, None, 0, None, None, 0, None, None) == 0
+        assert f("transpose_delta_pack_widths")(None, None, None, None, None, 0, 0, None, None) == 0
+        assert f("for_widths")(None, None, 0, None, None) == 0
+        # FL_ERR_NULL: widths / offsets / references / bases / the data
+        assert f("unfor_pack_widths")(None, p, p, 128, p, 1, p, 1, None, None) == 3
+        assert f("unfor_pack_widths")(p, None, p, 128, p, 1, p, 1, None, None) == 3
+        assert f("unfor_pack_widths")(p, p, p, 128, None, 1, p, 1, None, None) == 3
+        assert f("unfor_pack_widths")(p, p, p, 128, p, 1, None, 1, None, None) == 3
+        assert f("for_pack_widths")(p, p, None, p, 1, p, 128, 1, None, None) == 3
+        assert f("for_pack_widths")(p, p, p, None, 1, p, 128, 1, None, None) == 3
+        assert f("undelta_pack_widths")(p, p, p, 128, None, p, 1, None, None) == 3
+        assert f("undelta_pack_widths")(p, None, p, 128, p, p, 1, None, None) == 3
+        assert f("undelta_pack_widths")(p, p, None, 128, p, p, 1, None, None) == 3
+        assert f("transpose_delta_pack_widths")(p, p, None, p, p, 128, 1, None, None) == 3
+        assert f("transpose_delta_pack_widths")(p, p, p, p, None, 128, 1, None, None) == 3
+        assert f("for_widths")(None, p, 1, p, None) == 3
+        assert f("for_widths")(p, p, 1, None, None) == 3
+        # FL_ERR_ALIGN: 16-byte columns and bases
+        assert f("unfor_pack_widths")(p, p, p + 8, 128, p, 1, p, 1, None, None) == 4
+        assert f("undelta_pack_widths")(p, p, p, 128, p + 8, p, 1, None, None) == 4
+        assert f("transpose_delta_pack_widths")(p, p, p + 8, p, p, 128, 1, None, None) == 4
+
+
 def test_internal_kernel_policy_is_validated(lib):
     """include/fastlanes_amd_internal.h: mode 0..2, waves 0 or 3..8 and blocks-per-wave 0..16 (mode 2 only), tile-map window 0 or
     8..31 (any mode); anything else resets to 0 -- a stray value must not select a kernel shape that was never tested."""
