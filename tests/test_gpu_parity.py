@@ -1007,7 +1007,11 @@ def test_results_do_not_depend_on_the_tile_map(fl, oracle, ty):
              fl.Delta.delta(dv, db), fl.Delta.undelta(dv, db), fl.Delta.undelta_pack(w, dpk, db), fl.Transpose.transpose(dv),
              fl.Transpose.untranspose(dv), fl.Delta.undelta_pack_untranspose(w, dpk, db), fl.Delta.transpose_delta_pack(w, dv, db),
              fl.BitPacking.unpack_compare(w, dpk, "<=", (1 << w) // 3), fl.BitPacking.unpack_block_sums(w, dpk),
-             *fl.BitPacking.block_min_max(dv), fl.unpack_widths(widths, offsets, col), torch.cat(outs)]
+             *fl.BitPacking.block_min_max(dv), fl.unpack_widths(widths, offsets, col), torch.cat(outs),
+             fl.unfor_pack_widths(widths, offsets, col, dr), fl.undelta_pack_widths(widths, offsets, col, db),
+             fl.undelta_pack_widths(widths, offsets, col, db, untranspose=True),
+             fl.for_pack_widths(widths, offsets, dv, dr, torch.zeros_like(col)),
+             fl.transpose_delta_pack_widths(widths, offsets, dv, db, torch.zeros_like(col))]
         torch.cuda.synchronize()
         return [t.view(torch.uint8).clone() for t in r]
 
