@@ -258,6 +258,41 @@ def main():
             us = a.elapsed_time(b) * 1e3 / reps
             print(f"unpack u32 W=7 n_blocks={nb:>7d}: {us:9.2f} us per call (back-to-back on one stream)  "
                   f"{nb * 1024 / us / 1e3:9.2f} Gint/s  {nb * 4992 / us / 1e3:8.1f} GB/s", flush=True)
+        # the same loop as a HIP GRAPH (1000 chunks of 64 blocks, one captured launch each, replayed) next to the batch entry that
+        # decodes the same 1000 chunks in ONE launch: what capturing a launch-bound caller loop buys, and what the batch entry buys
+        n_arr, nb = 1000, 64
+        pk_all = rnd(n_arr * nb * 896, 1).view(torch.uint32)
+        un_all = torch.empty(n_arr * nb * 1024, dtype=torch.uint32, device=dev)
+        chunks = [pk_all[a * nb * 224:(a + 1) * nb * 224] for a in range(n_arr)]
+        outs = [un_all[a * nb * 1024:(a + 1) * nb * 1024] for a in range(n_arr)]
+        lib = fl.load()
+        side = torch.cuda.Stream()
+
+        def loop(stream_handle):
+            for c, o in zip(chunks, outs):
+                assert lib.fl_u32_unpack(7, c.data_ptr(), o.data_ptr(), nb, stream_handle) == 0
+
+        def timed(f, reps=20):
+            f(); torch.cuda.synchronize()
+            ms = []
+            for _ in range(reps):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); f(); b.record(); b.synchronize()
+                ms.append(a.elapsed_time(b))
+            return sorted(ms)[len(ms) // 2]
+
+        import ctypes
+        with torch.cuda.stream(side):
+            direct = timed(lambda: loop(ctypes.c_void_p(side.cuda_stream)))
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                loop(ctypes.c_void_p(side.cuda_stream))
+            graph = timed(g.replay)
+            batch = fl.Batch(chunks, outs, [7] * n_arr)
+            one = timed(lambda: batch.unpack())
+        for name, ms in (("one C-ABI call per chunk", direct), ("the same 1000 calls captured in a HIP graph, replayed", graph), ("fl_u32_unpack_batch: ONE launch", one)):
+            print(f"1000 chunks x 64 blocks, unpack u32 W=7, {name:56s}: {ms * 1e3:9.1f} us  {ms * 1e3 / n_arr:7.3f} us per chunk  "
+                  f"{n_arr * nb * 1024 / ms / 1e6:8.1f} Gint/s", flush=True)
         return
     if args.cases == "batch":
         # many small arrays per launch (fl_<ty>_unpack_batch / _pack_batch) next to one device-tier call per array: 10 000 chunks of
