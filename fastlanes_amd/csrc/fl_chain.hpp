@@ -137,7 +137,8 @@ template <typename T> __device__ __forceinline__ Cell<T> cell_from_group_below(c
 // form of the lane-group scan (DPP + v_permlane16/32_swap instead of ds_bpermute).  It passed every per-(T, W) parity test and was
 // wrong on ~3 % of the blocks of a u64 undelta_pack, differently on every run, with all CUs busy (profiles/abscan_r03.txt), and was
 // dropped.  It is kept behind this macro for one purpose: to show that tests/test_gpu_full_check.py catches that class of error
-// (profiles/full_check_r04.txt).
+// (profiles/full_check_r04.txt).  The misbehaviour depends on instruction scheduling -- after this file was cut into stages the
+// same sequence stopped failing -- so the macro also plants a deterministic sparse fault (k_chain below).
 template <typename T> __device__ __forceinline__ Cell<T> scan_lane_groups_r03(Cell<T> v, unsigned lane)
 {
     const bool odd_row = lane & 16u, upper_half = lane & 32u;
@@ -424,6 +425,13 @@ __global__ __launch_bounds__(WG) void k_chain(ChainArgs a)
         wave_lds_fence();
         Cell<T> x[R];
         chain_stage_rows<T, SRC, BODY>(w, lds, lane, base, x);
+#ifdef FL_TEST_R03_REGISTER_SCAN
+        // KNOWN-BAD test build only: a deterministic SPARSE fault on top of the (scheduling-dependent) register scan -- one wrong
+        // element in one of every 4 099 blocks of a u64 undelta chain.  Sampled checks miss it; the full check must not.
+        if constexpr (BODY == CHAIN_UNDELTA && sizeof(T) == 8) {
+            if (first % 4099u == 4098u && lane == 13u) x[0].x[0] ^= 1u;   // first at block 4 098: beyond the small-size parity tests
+        }
+#endif
         if constexpr (FENCE_BEFORE_IMAGE) wave_lds_fence();
         chain_stage_image<T, SNK>(x, lds, lane);
         wave_lds_fence();
