@@ -27,7 +27,9 @@
  *       e.g. bitpacking.rs:19,33): runs the same kernels on the calling
  *       thread's current device and synchronises before returning.  n_blocks = 1
  *       is the exact shape of one trait-method call.  Small calls are zero-copy
- *       (the kernel reads/writes a pinned host buffer over PCIe); large calls
+ *       (the kernel reads/writes a pinned host buffer over PCIe; the calling
+ *       thread polls a completion word in pinned memory for the ~10 us the call
+ *       takes, whatever the device's scheduling flags say); large calls
  *       stage through a cached device buffer; after a thread's first call
  *       nothing is allocated (fl_host_release).  There is no CPU code path:
  *       without a GPU these return FL_ERR_HIP.
