@@ -55,6 +55,8 @@ def _signatures(ty):
         "pack_batch": [_P, _P, _P, _P, _Z, ctypes.c_uint32, _P, _P],
         "unfor_pack_batch": [_P, _P, _P, _P, _P, _Z, ctypes.c_uint32, _P, _P],
         "for_pack_batch": [_P, _P, _P, _P, _P, _Z, ctypes.c_uint32, _P, _P],
+        "undelta_pack_batch": [_P, _P, _P, _P, _P, _Z, ctypes.c_uint32, ctypes.c_int, _P, _P],
+        "transpose_delta_pack_batch": [_P, _P, _P, _P, _P, _Z, ctypes.c_uint32, _P, _P],
     }
     host = {
         "pack_host": [_U, _P, _P, _Z],

@@ -668,9 +668,11 @@ class Batch:
     element type on one device (array a: n_blocks[a] blocks of width widths[a]); the constructor uploads the four per-array
     device arrays (pointers, widths, block counts) once, unpack() / pack() are then one asynchronous launch each."""
 
-    def __init__(self, packed, unpacked, widths, references=None):
+    def __init__(self, packed, unpacked, widths, references=None, bases=None):
         """`references` (optional): one FoR reference per array -- unpack() / pack() then run unfor_pack::<W> / for_pack::<W>
-        (ffor.rs:24-50) on every block of array a with references[a]."""
+        (ffor.rs:24-50) on every block of array a with references[a].
+        `bases` (optional): one CUDA tensor per array holding its Delta bases, LANES elements per block (delta.rs:7) -- for
+        undelta_pack() / transpose_delta_pack()."""
         import torch
         if not (len(packed) == len(unpacked) == len(widths)):
             raise ValueError("packed, unpacked and widths must have one entry per array")
@@ -715,6 +717,44 @@ class Batch:
             self.d_refs = up(np.array(r, dtype=np.uint64).astype(_NP_DTYPE[self.ty]).view(np.uint8), np.uint8)
         self.unpacked = list(unpacked)
         self.packed = list(packed)
+        self.d_bases = None
+        if bases is not None:
+            if len(bases) != self.n:
+                raise ValueError("bases must hold one tensor per array")
+            args_b = [_Arg(t, self.ty) for t in bases]
+            for a, bb in enumerate(args_b):
+                _same_tier(args_u[0], bb)
+                if bb.n != nb[a] * (1024 // T):
+                    raise ValueError(f"array {a}: bases must hold LANES elements per block")
+                if nb[a] and bb.ptr % 16:
+                    raise FastLanesError(4, f"fl_{self.ty}_undelta_pack_batch (array {a}: device pointers must be 16-byte aligned)")
+            self._keep += (list(bases),)
+            self.d_bases = up([a.ptr for a in args_b], np.int64)
+
+    def _run_delta(self, method, extra, check):
+        import torch
+        if self.d_bases is None:
+            raise ValueError("this batch was built without bases")
+        err = torch.zeros(1, dtype=torch.int32, device=self.device) if check else None
+        first, last = (self.d_packed, self.d_unpacked) if method == "undelta_pack_batch" else (self.d_unpacked, self.d_packed)
+        with torch.cuda.device(self.device):
+            st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            _check(getattr(_lib.load(), f"fl_{self.ty}_{method}")(first.data_ptr(), self.d_bases.data_ptr(), last.data_ptr(), self.d_widths.data_ptr(),
+                                                                  self.d_n_blocks.data_ptr(), self.n, self.max_blocks, *extra,
+                                                                  err.data_ptr() if check else None, st), f"fl_{self.ty}_{method}")
+        if check:
+            _check_flag(err, f"fl_{self.ty}_{method}")
+
+    def undelta_pack(self, untranspose=False, check=False):
+        """Delta::undelta_pack::<widths[a]> (delta.rs:47-63) on every block of every array with its bases; the output is in
+        transposed order like the reference's, or in ORIGINAL order with `untranspose=True` (the fused extension)."""
+        self._run_delta("undelta_pack_batch", (1 if untranspose else 0,), check)
+        return self.unpacked
+
+    def transpose_delta_pack(self, check=False):
+        """The fused encode pack::<widths[a]>(delta(transpose(unpacked[a]), bases[a])) for every array."""
+        self._run_delta("transpose_delta_pack_batch", (), check)
+        return self.packed
 
     def _run(self, method, first, second, check):
         import torch

@@ -9,7 +9,7 @@
 // past an array's end leave at once.  The block kernel is the runtime-width wave-per-block one (fl_widths.hpp), fed a
 // per-array argument block.
 #pragma once
-#include "fl_widths.hpp"
+#include "fl_chain.hpp"
 
 namespace fl {
 
@@ -27,6 +27,7 @@ struct BatchArgs {
     unsigned max_blocks;         // the caller's bound on n_blocks[a]
     unsigned bpw;                // consecutive blocks of the array per wavefront (>= 1); a workgroup takes 4 * bpw
     unsigned prefetch;           // bpw > 1: all of a wavefront's blocks are requested up front by LDS-DMA (one image per block)
+    const char* const* bases;    // Delta's entries only: [n_arrays] device pointers to the arrays' bases, [n_blocks[a]][LANES] each
 };
 
 // Array `arr`'s descriptor -- block count, width, the two pointers -- as four INDEPENDENT loads through the vector memory
@@ -103,7 +104,87 @@ __global__ __launch_bounds__(WG) void k_batch(BatchArgs b)
     }
 }
 
+// Delta over many small arrays: `for b in 0..chunk.blocks { Delta::undelta_pack::<W>(&chunk.packed[b*..], &chunk.bases[b], ..) }`
+// (delta.rs:47-63) -- and the two fused transpose extensions -- with the pipeline kernel's stages (fl_chain.hpp), one wavefront per
+// block, the per-array argument block built from the descriptor (five independent loads: the bases pointer rides along).
+// blocks per wavefront: the narrow types keep several in flight (fl_chain.hpp: chain_blocks_lockstep) -- except u16's encode, whose
+// unpacked blocks are better read through VGPRs than by LDS-DMA (profiles/abchain_narrow_r04.txt)
+template <typename T, int SRC> constexpr unsigned batch_chain_blocks_per_wave()
+{
+    return sizeof(T) == 1 ? 4u : (sizeof(T) == 2 && SRC == SRC_PACKED) ? 2u : 1u;
+}
+
+template <typename T, int SRC, int BODY, int SNK>
+__global__ __launch_bounds__(WG) void k_batch_chain(BatchArgs b)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_all[];
+    constexpr unsigned BPW = batch_chain_blocks_per_wave<T, SRC>();
+    constexpr unsigned WAVE_LDS = chain_wave_lds<T, SRC, SNK>() * BPW;
+    const uint64_t n_tiles = b.n_arrays * b.tiles_per_array;
+    const uint64_t tile = xcd_tile(blockIdx.x, b.tiles_per_xcd, b.window_shift);
+    if (tile >= n_tiles) return;
+    const unsigned arr = (unsigned)tile / b.tiles_per_array;
+    const unsigned tile_in_arr = (unsigned)tile - arr * b.tiles_per_array;
+    const unsigned tid = threadIdx.x;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
+    const unsigned blk = (tile_in_arr * (WG / 64) + wave) * BPW;
+    const uint64_t bases_v = reinterpret_cast<const uint64_t*>(b.bases)[arr + opaque_zero()];   // in flight with the descriptor's loads
+    const ArrayDesc d = array_desc(b, arr);
+    const uint64_t bases = wave_uniform_u64(bases_v);
+    if (blk >= d.n_blocks) return;
+    if (blk == 0 && d.n_blocks > b.max_blocks) raise_device_error(b.err_flag, DEVERR_BOUNDS, lane);
+    if (d.width > (unsigned)WaveBlock<T>::TB) {                                // delta.rs:11-16: W <= T is a type-level bound there
+        raise_device_error(b.err_flag, DEVERR_WIDTH, lane);
+        return;
+    }
+    if (((d.packed | d.unpacked | bases) & 15u) != 0 || !d.unpacked || !bases || (!d.packed && d.width != 0)) {
+        raise_device_error(b.err_flag, DEVERR_ALIGN, lane);
+        return;
+    }
+    ChainArgs a;
+    a.in = reinterpret_cast<const char*>(SRC == SRC_PACKED ? d.packed : d.unpacked);
+    a.out = reinterpret_cast<char*>(SNK == SNK_PACKED ? d.packed : d.unpacked);
+    a.bases = reinterpret_cast<const char*>(bases);
+    a.n_blocks = d.n_blocks;
+    a.tiles_per_xcd = 0;
+    a.window_shift = 63;
+    a.width = d.width;
+    a.widths = nullptr;
+    a.offsets = nullptr;
+    a.err_flag = b.err_flag;
+    a.packed_bytes = 0;
+    if constexpr (BPW == 1) {
+        chain_one_block<T, SRC, BODY, SNK, RD_VGPR>(a, blk, lds_all + wave * WAVE_LDS, lane);
+    } else {
+        const unsigned left = d.n_blocks - blk;
+        chain_blocks_lockstep<T, SRC, BODY, SNK, BPW>(a, blk, left < BPW ? left : BPW, lds_all + wave * WAVE_LDS, lane);
+    }
+}
+
+template <typename T, int SRC, int BODY, int SNK>
+hipError_t launch_batch_chain(const BatchArgs& b0, uint32_t max_blocks, int waves, hipStream_t s)
+{
+    if (b0.n_arrays == 0 || max_blocks == 0) return hipSuccess;
+    BatchArgs b = b0;
+    constexpr unsigned TILE_BLOCKS = batch_chain_blocks_per_wave<T, SRC>() * (WG / 64);
+    b.bpw = batch_chain_blocks_per_wave<T, SRC>();
+    b.prefetch = 0;
+    b.tiles_per_array = (unsigned)(((uint64_t)max_blocks + TILE_BLOCKS - 1) / TILE_BLOCKS);
+    b.max_blocks = max_blocks;
+    const uint64_t n_tiles = b.n_arrays * b.tiles_per_array;
+    b.tiles_per_xcd = (n_tiles + 7) / 8;
+    if (b.tiles_per_array == 0 || b.tiles_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;
+    b.window_shift = tile_window_shift(SNK == SNK_PACKED ? TRAFFIC_READ : TRAFFIC_WRITE, TILE_BLOCKS);
+    const unsigned need = TILE_BLOCKS * chain_wave_lds<T, SRC, SNK>();
+    if (waves < 3) waves = 3;
+    const unsigned pad = (CU_LDS_BYTES / (unsigned)waves) & ~1023u;
+    FL_LAUNCH((k_batch_chain<T, SRC, BODY, SNK>), dim3((unsigned)(b.tiles_per_xcd * 8)), dim3(WG), pad > need ? pad : need, s, b);
+    return hipGetLastError();
+}
+
 typedef hipError_t (*batch_launch_t)(const BatchArgs&, uint32_t max_blocks, int waves, hipStream_t);
+// op: OP_UNDELTA_PACK / OP_UNDELTA_PACK_UNTRANSPOSE / OP_TRANSPOSE_DELTA_PACK (fl_chain.hpp)
+template <typename T> batch_launch_t batch_chain_launcher(int op);
 
 template <typename T, bool PACK>
 hipError_t launch_batch(const BatchArgs& b0, uint32_t max_blocks, int waves, hipStream_t s)

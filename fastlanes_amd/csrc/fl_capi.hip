@@ -626,6 +626,7 @@ int run_batch(bool pack, const void* const* packed, void* const* unpacked, const
     b.n_blocks = n_blocks;
     b.err_flag = err_flag;
     b.refs = with_refs ? refs : nullptr;
+    b.bases = nullptr;
     b.n_arrays = n_arrays;
     b.tiles_per_xcd = 0;
     b.window_shift = 63;
@@ -638,6 +639,38 @@ int run_batch(bool pack, const void* const* packed, void* const* unpacked, const
     if ((pol & 0xff) == 2 && ((pol >> 8) & 0xff)) waves = (pol >> 8) & 0xff;
     if ((pol & 0xff) == 2 && ((pol >> 16) & 0xff)) { b.bpw = (pol >> 16) & 0xff; b.prefetch = (pol >> 24) & 1; }
     hipError_t e = batch_launcher<T>(pack)(b, max_blocks, waves, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? FL_OK : hip_fail(e);
+}
+
+// Delta over many small arrays (fl_batch.hpp: k_batch_chain)
+template <typename T>
+int run_batch_chain(int op, const void* const* packed, const void* const* bases, void* const* unpacked, const uint8_t* widths,
+                    const uint32_t* n_blocks, size_t n_arrays, uint32_t max_blocks, uint32_t* err_flag, void* stream)
+{
+    if (n_arrays == 0 || max_blocks == 0) return FL_OK;
+    if (!packed || !bases || !unpacked || !widths || !n_blocks) return FL_ERR_NULL;
+    if (max_blocks > BATCH_MAX_BLOCKS) return FL_ERR_INDEX;
+    const batch_launch_t fn = batch_chain_launcher<T>(op);
+    if (!fn) return hip_fail(hipErrorInvalidDeviceFunction);
+    BatchArgs b;
+    b.packed = reinterpret_cast<const char* const*>(packed);
+    b.unpacked = reinterpret_cast<char* const*>(unpacked);
+    b.widths = widths;
+    b.n_blocks = n_blocks;
+    b.err_flag = err_flag;
+    b.refs = nullptr;
+    b.bases = reinterpret_cast<const char* const*>(bases);
+    b.n_arrays = n_arrays;
+    b.tiles_per_xcd = 0;
+    b.window_shift = 63;
+    b.tiles_per_array = 0;
+    b.max_blocks = max_blocks;
+    b.bpw = 1;
+    b.prefetch = 0;
+    int waves = mixed_waves(Elem<T>::BITS, op == OP_TRANSPOSE_DELTA_PACK);
+    const int pol = g_kernel_policy.load(std::memory_order_relaxed);       // A/B tools: 2 + 256 * waves
+    if ((pol & 0xff) == 2 && ((pol >> 8) & 0xff)) waves = (pol >> 8) & 0xff;
+    hipError_t e = fn(b, max_blocks, waves, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
 
@@ -898,6 +931,12 @@ size_t fl_packed_len(unsigned type_bits, unsigned width)
     int fl_##S##_pack_batch(const T* const* in, T* const* pk, const uint8_t* w, const uint32_t* nb, size_t na, uint32_t mb, \
                             uint32_t* ef, void* s)                                                        \
     { FL_DEVICE_TIER(s, pk, in, w, nb, ef); return run_batch<T>(true, reinterpret_cast<const void* const*>(pk), (void* const*)in, w, nullptr, false, nb, na, mb, ef, s); } \
+    int fl_##S##_undelta_pack_batch(const T* const* pk, const T* const* bs, T* const* out, const uint8_t* w, const uint32_t* nb, \
+                                    size_t na, uint32_t mb, int untranspose, uint32_t* ef, void* s)        \
+    { FL_DEVICE_TIER(s, pk, bs, out, w, nb, ef); return run_batch_chain<T>(untranspose ? OP_UNDELTA_PACK_UNTRANSPOSE : OP_UNDELTA_PACK, reinterpret_cast<const void* const*>(pk), reinterpret_cast<const void* const*>(bs), reinterpret_cast<void* const*>(out), w, nb, na, mb, ef, s); } \
+    int fl_##S##_transpose_delta_pack_batch(const T* const* in, const T* const* bs, T* const* pk, const uint8_t* w, const uint32_t* nb, \
+                                            size_t na, uint32_t mb, uint32_t* ef, void* s)                 \
+    { FL_DEVICE_TIER(s, in, bs, pk, w, nb, ef); return run_batch_chain<T>(OP_TRANSPOSE_DELTA_PACK, reinterpret_cast<const void* const*>(pk), reinterpret_cast<const void* const*>(bs), (void* const*)in, w, nb, na, mb, ef, s); } \
     int fl_##S##_unpack_single_widths(const uint8_t* w, const uint64_t* o, const T* pk, size_t pb, size_t n, const uint64_t* idx, \
                                       size_t ni, T* out, uint32_t* ef, void* s)                           \
     { FL_DEVICE_TIER(s, w, o, pk, idx, out, ef); return dev_unpack_single_widths<T>(w, o, pk, pb, n, idx, ni, out, ef, s); }                         \

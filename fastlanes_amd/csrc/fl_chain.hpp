@@ -398,6 +398,111 @@ __device__ __forceinline__ void chain_stage_out(const ChainArgs& a, uint64_t blk
     }
 }
 
+// One block, every stage in turn (the uniform-width kernels, the small-array batch): the wavefront's LDS image is `lds`.
+template <typename T, int SRC, int BODY, int SNK, int RD>
+__device__ __forceinline__ void chain_one_block(const ChainArgs& a, uint64_t blk, char* lds, unsigned lane)
+{
+    constexpr int R = WaveBlock<T>::TB / 8;
+    // the source image is dead once every lane has taken its rows (lanes re-use other lanes' cells in the sink image, except ROWS -> ROWS)
+    constexpr bool FENCE_BEFORE_IMAGE = !(SRC == SRC_ROWS && SNK == SNK_ROWS);
+    unsigned w;
+    uint64_t packed_at;
+    if (!chain_block_meta<T, SRC, SNK>(a, blk, lane, w, packed_at)) return;
+    Cell<T> base = Cell<T>::zero();
+    chain_stage_source<T, SRC, BODY, RD>(a, blk, w, packed_at, lds, lane, base);
+    wave_lds_fence();
+    Cell<T> x[R];
+    chain_stage_rows<T, SRC, BODY>(w, lds, lane, base, x);
+#ifdef FL_TEST_R03_REGISTER_SCAN
+    // KNOWN-BAD test build only: a deterministic SPARSE fault on top of the (scheduling-dependent) register scan -- one wrong
+    // element in one of every 4 099 blocks of a u64 undelta chain.  Sampled checks miss it; the full check must not.
+    if constexpr (BODY == CHAIN_UNDELTA && sizeof(T) == 8) {
+        if (blk % 4099u == 4098u && lane == 13u) x[0].x[0] ^= 1u;   // first at block 4 098: beyond the small-size parity tests
+    }
+#endif
+    if constexpr (FENCE_BEFORE_IMAGE) wave_lds_fence();
+    chain_stage_image<T, SNK>(x, lds, lane);
+    wave_lds_fence();
+    chain_stage_out<T, SNK>(a, blk, w, packed_at, lds, lane);
+}
+
+// Several CONSECUTIVE blocks of one wavefront (the narrow types), every stage for all of them before the next: all requested up
+// front by LDS-DMA (their images are linear in every layout), the bases behind them.  `lds` holds BPW images of the wavefront.
+template <typename T, int SRC, int BODY, int SNK, unsigned BPW>
+__device__ __forceinline__ void chain_blocks_lockstep(const ChainArgs& a, uint64_t first, unsigned count, char* lds, unsigned lane)
+{
+    using G = WaveBlock<T>;
+    constexpr int R = G::TB / 8;
+    constexpr unsigned WAVE_LDS = chain_wave_lds<T, SRC, SNK>();
+    // narrow types: all of the wavefront's blocks requested up front by LDS-DMA (their images are linear in every layout),
+    // the bases behind them; then every stage for all of them
+    static_assert(sizeof(T) < 4, "the padded original-order image of u32 / u64 cannot be filled by LDS-DMA");
+    constexpr bool FENCE_BEFORE_IMAGE = !(SRC == SRC_ROWS && SNK == SNK_ROWS);
+    unsigned w[BPW];
+    uint64_t packed_at[BPW];
+    bool ok[BPW];
+    Cell<T> base[BPW];
+    // mixed widths: lane j fetches block first+j's width and offset -- one round trip for all of them -- then broadcasts
+    constexpr bool PACKED_SIDE = SRC == SRC_PACKED || SNK == SNK_PACKED;
+    const bool mixed = PACKED_SIDE && a.widths;            // wave-uniform
+    unsigned wv = 0;
+    uint64_t ov = 0;
+    if (mixed) {
+        const uint64_t mine = first + (lane < count ? lane : 0u);
+        wv = a.widths[mine];
+        ov = a.offsets[mine];
+    }
+    static_for<BPW>([&](auto Jt) {
+        constexpr unsigned j = decltype(Jt)::value;
+        ok[j] = j < count;
+        w[j] = PACKED_SIDE ? a.width : (unsigned)G::TB;
+        packed_at[j] = (first + j) * (uint64_t)(128u * w[j]);
+        if (mixed && ok[j]) {
+            w[j] = (unsigned)__builtin_amdgcn_readlane((int)wv, (int)j);
+            packed_at[j] = readlane_elem<uint64_t>(ov, j);
+            if (const uint32_t e = block_precondition(true, a.packed_bytes, w[j], packed_at[j], G::TB)) {
+                raise_device_error(a.err_flag, e, lane);
+                ok[j] = false;
+            }
+        }
+    });
+    static_for<BPW>([&](auto Jt) {
+        constexpr unsigned j = decltype(Jt)::value;
+        if (ok[j]) {                                        // wave-uniform
+            const __amdgpu_buffer_rsrc_t in_rs = chain_source<T, SRC>(a, first + j, w[j], packed_at[j]);
+            const unsigned w_in = SRC == SRC_PACKED ? w[j] : (unsigned)G::TB;
+            static_for<G::GROUPS>([&](auto Gi) {
+                constexpr int g = decltype(Gi)::value;
+                if (8u * g < w_in) dma_1k_to_lds<RD_DMA_NT, g * 1024>(in_rs, lds + j * WAVE_LDS, lane);
+            });
+        }
+    });
+    static_for<BPW>([&](auto Jt) {
+        constexpr unsigned j = decltype(Jt)::value;
+        base[j] = Cell<T>::zero();
+        if constexpr (BODY != CHAIN_NONE) {
+            if (ok[j]) base[j] = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(a.bases + (first + j) * 128u + (lane & 7u) * 16u + opaque_zero()));
+        }
+    });
+    wait_lds_dma();
+    wave_lds_fence();
+    Cell<T> x[BPW][R];
+    static_for<BPW>([&](auto Jt) {
+        constexpr unsigned j = decltype(Jt)::value;
+        if (ok[j]) chain_stage_rows<T, SRC, BODY>(w[j], lds + j * WAVE_LDS, lane, base[j], x[j]);
+    });
+    if constexpr (FENCE_BEFORE_IMAGE) wave_lds_fence();
+    static_for<BPW>([&](auto Jt) {
+        constexpr unsigned j = decltype(Jt)::value;
+        if (ok[j]) chain_stage_image<T, SNK>(x[j], lds + j * WAVE_LDS, lane);
+    });
+    wave_lds_fence();
+    static_for<BPW>([&](auto Jt) {
+        constexpr unsigned j = decltype(Jt)::value;
+        if (ok[j]) chain_stage_out<T, SNK>(a, first + j, w[j], packed_at[j], lds + j * WAVE_LDS, lane);
+    });
+}
+
 template <typename T, int SRC, int BODY, int SNK, int RD = RD_VGPR, unsigned BPW = 1>
 __global__ __launch_bounds__(WG) void k_chain(ChainArgs a)
 {
@@ -414,97 +519,11 @@ __global__ __launch_bounds__(WG) void k_chain(ChainArgs a)
     const uint64_t first = tile * TILE_BLOCKS + (uint64_t)wave * BPW;
     if (first >= a.n_blocks) return;
     char* lds = lds_all + wave * (WAVE_LDS * BPW);
-    // the source image is dead once every lane has taken its rows (lanes re-use other lanes' cells in the sink image, except ROWS -> ROWS)
-    constexpr bool FENCE_BEFORE_IMAGE = !(SRC == SRC_ROWS && SNK == SNK_ROWS);
     if constexpr (BPW == 1) {
-        unsigned w;
-        uint64_t packed_at;
-        if (!chain_block_meta<T, SRC, SNK>(a, first, lane, w, packed_at)) return;
-        Cell<T> base = Cell<T>::zero();
-        chain_stage_source<T, SRC, BODY, RD>(a, first, w, packed_at, lds, lane, base);
-        wave_lds_fence();
-        Cell<T> x[R];
-        chain_stage_rows<T, SRC, BODY>(w, lds, lane, base, x);
-#ifdef FL_TEST_R03_REGISTER_SCAN
-        // KNOWN-BAD test build only: a deterministic SPARSE fault on top of the (scheduling-dependent) register scan -- one wrong
-        // element in one of every 4 099 blocks of a u64 undelta chain.  Sampled checks miss it; the full check must not.
-        if constexpr (BODY == CHAIN_UNDELTA && sizeof(T) == 8) {
-            if (first % 4099u == 4098u && lane == 13u) x[0].x[0] ^= 1u;   // first at block 4 098: beyond the small-size parity tests
-        }
-#endif
-        if constexpr (FENCE_BEFORE_IMAGE) wave_lds_fence();
-        chain_stage_image<T, SNK>(x, lds, lane);
-        wave_lds_fence();
-        chain_stage_out<T, SNK>(a, first, w, packed_at, lds, lane);
+        chain_one_block<T, SRC, BODY, SNK, RD>(a, first, lds, lane);
     } else {
-        // narrow types: all of the wavefront's blocks requested up front by LDS-DMA (their images are linear in every layout),
-        // the bases behind them; then every stage for all of them
-        static_assert(sizeof(T) < 4, "the padded original-order image of u32 / u64 cannot be filled by LDS-DMA");
         const uint64_t left = a.n_blocks - first;
-        const unsigned count = left < BPW ? (unsigned)left : BPW;
-        unsigned w[BPW];
-        uint64_t packed_at[BPW];
-        bool ok[BPW];
-        Cell<T> base[BPW];
-        // mixed widths: lane j fetches block first+j's width and offset -- one round trip for all of them -- then broadcasts
-        constexpr bool PACKED_SIDE = SRC == SRC_PACKED || SNK == SNK_PACKED;
-        const bool mixed = PACKED_SIDE && a.widths;            // wave-uniform
-        unsigned wv = 0;
-        uint64_t ov = 0;
-        if (mixed) {
-            const uint64_t mine = first + (lane < count ? lane : 0u);
-            wv = a.widths[mine];
-            ov = a.offsets[mine];
-        }
-        static_for<BPW>([&](auto Jt) {
-            constexpr unsigned j = decltype(Jt)::value;
-            ok[j] = j < count;
-            w[j] = PACKED_SIDE ? a.width : (unsigned)G::TB;
-            packed_at[j] = (first + j) * (uint64_t)(128u * w[j]);
-            if (mixed && ok[j]) {
-                w[j] = (unsigned)__builtin_amdgcn_readlane((int)wv, (int)j);
-                packed_at[j] = readlane_elem<uint64_t>(ov, j);
-                if (const uint32_t e = block_precondition(true, a.packed_bytes, w[j], packed_at[j], G::TB)) {
-                    raise_device_error(a.err_flag, e, lane);
-                    ok[j] = false;
-                }
-            }
-        });
-        static_for<BPW>([&](auto Jt) {
-            constexpr unsigned j = decltype(Jt)::value;
-            if (ok[j]) {                                        // wave-uniform
-                const __amdgpu_buffer_rsrc_t in_rs = chain_source<T, SRC>(a, first + j, w[j], packed_at[j]);
-                const unsigned w_in = SRC == SRC_PACKED ? w[j] : (unsigned)G::TB;
-                static_for<G::GROUPS>([&](auto Gi) {
-                    constexpr int g = decltype(Gi)::value;
-                    if (8u * g < w_in) dma_1k_to_lds<RD_DMA_NT, g * 1024>(in_rs, lds + j * WAVE_LDS, lane);
-                });
-            }
-        });
-        static_for<BPW>([&](auto Jt) {
-            constexpr unsigned j = decltype(Jt)::value;
-            base[j] = Cell<T>::zero();
-            if constexpr (BODY != CHAIN_NONE) {
-                if (ok[j]) base[j] = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(a.bases + (first + j) * 128u + (lane & 7u) * 16u + opaque_zero()));
-            }
-        });
-        wait_lds_dma();
-        wave_lds_fence();
-        Cell<T> x[BPW][R];
-        static_for<BPW>([&](auto Jt) {
-            constexpr unsigned j = decltype(Jt)::value;
-            if (ok[j]) chain_stage_rows<T, SRC, BODY>(w[j], lds + j * WAVE_LDS, lane, base[j], x[j]);
-        });
-        if constexpr (FENCE_BEFORE_IMAGE) wave_lds_fence();
-        static_for<BPW>([&](auto Jt) {
-            constexpr unsigned j = decltype(Jt)::value;
-            if (ok[j]) chain_stage_image<T, SNK>(x[j], lds + j * WAVE_LDS, lane);
-        });
-        wave_lds_fence();
-        static_for<BPW>([&](auto Jt) {
-            constexpr unsigned j = decltype(Jt)::value;
-            if (ok[j]) chain_stage_out<T, SNK>(a, first + j, w[j], packed_at[j], lds + j * WAVE_LDS, lane);
-        });
+        chain_blocks_lockstep<T, SRC, BODY, SNK, BPW>(a, first, left < BPW ? (unsigned)left : BPW, lds, lane);
     }
 }
 

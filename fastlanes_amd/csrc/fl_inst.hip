@@ -54,6 +54,15 @@ template <> batch_launch_t batch_launcher<T>(bool pack)
 {
     return pack ? &launch_batch<T, true> : &launch_batch<T, false>;
 }
+template <> batch_launch_t batch_chain_launcher<T>(int op)
+{
+    switch (op) {
+    case OP_UNDELTA_PACK: return &launch_batch_chain<T, SRC_PACKED, CHAIN_UNDELTA, SNK_ROWS>;
+    case OP_UNDELTA_PACK_UNTRANSPOSE: return &launch_batch_chain<T, SRC_PACKED, CHAIN_UNDELTA, SNK_ORIGINAL>;
+    case OP_TRANSPOSE_DELTA_PACK: return &launch_batch_chain<T, SRC_ORIGINAL, CHAIN_DELTA, SNK_PACKED>;
+    default: return nullptr;
+    }
+}
 template <> chain_launch_t chain_launcher<T>(int op)
 {
     switch (op) {

@@ -283,6 +283,17 @@ const uint8_t *fl_mixed_plan_widths(const fl_mixed_plan *plan);
     int fl_##S##_for_pack_batch(const T *const *in, T *const *packed, const uint8_t *widths,      \
                                 const T *references, const uint32_t *n_blocks, size_t n_arrays,   \
                                 uint32_t max_blocks, uint32_t *err_flag, void *stream);           \
+    /* ... with Delta's bodies: bases[a] is a device pointer to array a's bases, [n_blocks[a]][LANES] (128 bytes per block):   \
+     * undelta_pack::<W> per block (delta.rs:47-63; output in transposed order, or -- untranspose != 0 -- straight in original  \
+     * order: the fused extension above), and the fused encode pack::<W>(delta(transpose(in), bases)). */                       \
+    int fl_##S##_undelta_pack_batch(const T *const *packed, const T *const *bases, T *const *out,  \
+                                    const uint8_t *widths, const uint32_t *n_blocks, size_t n_arrays, \
+                                    uint32_t max_blocks, int untranspose, uint32_t *err_flag,       \
+                                    void *stream);                                                  \
+    int fl_##S##_transpose_delta_pack_batch(const T *const *in, const T *const *bases,             \
+                                            T *const *packed, const uint8_t *widths,                \
+                                            const uint32_t *n_blocks, size_t n_arrays,              \
+                                            uint32_t max_blocks, uint32_t *err_flag, void *stream); \
     /* the same over a mixed-width plan (see fl_mixed_plan) */                                     \
     int fl_##S##_unpack_mixed(const fl_mixed_plan *plan, const T *packed, T *out, void *stream); \
     int fl_##S##_pack_mixed(const fl_mixed_plan *plan, const T *in, T *packed, void *stream);    \

@@ -74,6 +74,8 @@ template <typename T> struct Abi;
         static constexpr auto pack_batch = fl_##S##_pack_batch;                                      \
         static constexpr auto unfor_pack_batch = fl_##S##_unfor_pack_batch;                          \
         static constexpr auto for_pack_batch = fl_##S##_for_pack_batch;                              \
+        static constexpr auto undelta_pack_batch = fl_##S##_undelta_pack_batch;                      \
+        static constexpr auto transpose_delta_pack_batch = fl_##S##_transpose_delta_pack_batch;      \
         static constexpr auto pack_host = fl_##S##_pack_host;                                        \
         static constexpr auto unpack_host = fl_##S##_unpack_host;                                    \
         static constexpr auto unpack_single_host = fl_##S##_unpack_single_host;                      \

@@ -635,6 +635,61 @@ def test_for_and_delta_over_mixed_width_columns(fl, oracle, kernel_policy, ty, w
 
 
 @pytest.mark.parametrize("ty", TYS)
+def test_delta_over_a_batch_of_small_arrays(fl, oracle, ty):
+    """fl_<ty>_undelta_pack_batch / _transpose_delta_pack_batch: Delta's fused decode (delta.rs:47-63), its original-order form and the
+    fused encode over many small arrays in ONE launch -- every array against the oracle's per-block calls; ragged counts incl. 0,
+    widths incl. 0 and T, guard elements behind every output, the device-side checks of the per-array pointers and widths."""
+    import torch
+    T, L = tbits(ty), lanes(ty)
+    tdt = {"u8": torch.uint8, "u16": torch.uint16, "u32": torch.uint32, "u64": torch.uint64}[ty]
+    rng = np.random.default_rng(199 + T)
+    counts = [64, 1, 0, 5, 64, 33, 7, 2, 130] + [int(x) for x in rng.integers(0, 70, size=30)]
+    widths = [int(x) for x in rng.integers(0, T + 1, size=len(counts))]
+    widths[0], widths[1], widths[4] = T, 0, 7 % (T + 1)
+    packed_np = [values(ty, n * packed_len(ty, w), 9000 + a) for a, (n, w) in enumerate(zip(counts, widths))]
+    bases_np = [values(ty, n * L, 9100 + a) for a, n in enumerate(counts)]
+    empty = lambda: torch.empty(0, dtype=tdt, device="cuda:0")
+    packed = [to_dev(p) if p.size else empty() for p in packed_np]
+    bases = [to_dev(b) if b.size else empty() for b in bases_np]
+    guard = 0xA5
+    for untranspose in (False, True):
+        outs = [torch.full((n * 1024 + 64,), guard, dtype=tdt, device="cuda:0") for n in counts]
+        fl.Batch(packed, [o[:n * 1024] for o, n in zip(outs, counts)], widths, bases=bases).undelta_pack(untranspose=untranspose, check=True)
+        for a, (n, w) in enumerate(zip(counts, widths)):
+            got = to_np(outs[a], ty)
+            want = oracle.batch("undelta_pack", ty, w, packed_np[a], aux=bases_np[a], n_blocks=n) if n else np.zeros(0, dtype=TYPES[ty][0])
+            if untranspose and n:
+                want = oracle.batch("untranspose", ty, None, want)
+            assert np.array_equal(got[:n * 1024], want), (ty, a, n, w, untranspose)
+            assert (got[n * 1024:] == guard).all(), "wrote past the end of an array"
+    # encode from original order: pack::<W>(delta(transpose(v), bases)), truncated like pack::<W> does
+    vals_np = [values(ty, n * 1024, 9200 + a) for a, n in enumerate(counts)]
+    vals = [to_dev(v) if v.size else empty() for v in vals_np]
+    pouts = [torch.full((n * packed_len(ty, w) + 64,), guard, dtype=tdt, device="cuda:0") for n, w in zip(counts, widths)]
+    fl.Batch([p[:n * packed_len(ty, w)] for p, n, w in zip(pouts, counts, widths)], vals, widths, bases=bases).transpose_delta_pack(check=True)
+    for a, (n, w) in enumerate(zip(counts, widths)):
+        got = to_np(pouts[a], ty)
+        k = n * packed_len(ty, w)
+        if k:
+            want = oracle.batch("pack", ty, w, oracle.batch("delta", ty, None, oracle.batch("transpose", ty, None, vals_np[a]), aux=bases_np[a]))
+            assert np.array_equal(got[:k], want), (ty, a, n, w, "transpose_delta_pack_batch")
+        assert (got[k:] == guard).all(), "wrote past the end of a packed array"
+    # a width > T arriving in HBM: that array is skipped and flagged, the others are decoded
+    b = fl.Batch(packed[:4], [torch.zeros(n * 1024, dtype=tdt, device="cuda:0") for n in counts[:4]], widths[:4], bases=bases[:4])
+    b.d_widths[3] = T + 1
+    with pytest.raises(fl.FastLanesError) as ei:
+        b.undelta_pack(check=True)
+    assert ei.value.status == 1
+    assert np.array_equal(to_np(b.unpacked[0], ty), oracle.batch("undelta_pack", ty, widths[0], packed_np[0], aux=bases_np[0], n_blocks=counts[0]))
+    assert not to_np(b.unpacked[3], ty).any()
+    # the mirror's own checks
+    with pytest.raises(ValueError):
+        fl.Batch(packed[:2], [torch.zeros(n * 1024, dtype=tdt, device="cuda:0") for n in counts[:2]], widths[:2]).undelta_pack()
+    with pytest.raises(ValueError):
+        fl.Batch(packed[:2], [torch.zeros(n * 1024, dtype=tdt, device="cuda:0") for n in counts[:2]], widths[:2], bases=[bases[0], bases[0][:L - 1]])
+
+
+@pytest.mark.parametrize("ty", TYS)
 def test_batch_of_small_arrays_vs_oracle(fl, oracle, ty):
     """fl_<ty>_unpack_batch / _pack_batch: many small arrays (a columnar engine's chunks), each with its own width and block
     count, given as device arrays of pointers -- ONE launch; every array against the oracle's per-block loop

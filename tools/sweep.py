@@ -373,6 +373,33 @@ def main():
                   f"the same blocks as one contiguous column, one call: {tc:8.4f} ms ({(t / tc - 1) * 100:+.1f} %) | one call per array: {t1:8.3f} ms  "
                   f"{n_arr * nb * 1024 / t1 / 1e6:7.1f} Gint/s  (x{t1 / t:.1f})", flush=True)
             del batch, pk_all, un_all, want, packed, outs
+        if args.batch_all:
+            # Delta's fused decode over the same shape (fl_<ty>_undelta_pack_batch), against the same blocks as one contiguous call
+            for ty, w in (("u32", 12), ("u16", 9), ("u64", 20)):
+                n_arr, nb = 10000, 64
+                esz, T = ESZ[ty], ESZ[ty] * 8
+                L = 1024 // T
+                ppb, opb = nb * 1024 * w // T, nb * 1024
+                pk_all = rnd(n_arr * ppb * esz, 1).view(TDT[ty])
+                bs_all = rnd(n_arr * nb * 128, 3).view(TDT[ty])
+                un_all = torch.empty(n_arr * opb, dtype=TDT[ty], device=dev)
+                packed = [pk_all[a * ppb:(a + 1) * ppb] for a in range(n_arr)]
+                bases = [bs_all[a * nb * L:(a + 1) * nb * L] for a in range(n_arr)]
+                outs = [un_all[a * opb:(a + 1) * opb] for a in range(n_arr)]
+                batch = fl.Batch(packed, outs, [w] * n_arr, bases=bases)
+                one = lambda: fl.Delta.undelta_pack(w, pk_all, bs_all, output=un_all)
+                med = interleaved({"batch": lambda: batch.undelta_pack(), "contiguous": one}, max(args.reps, 15))
+                one()
+                want = un_all.clone()
+                un_all.zero_()
+                batch.undelta_pack()
+                same = torch.equal(want.view(torch.uint8), un_all.view(torch.uint8))
+                t, tc = med["batch"], med["contiguous"]
+                nbytes = n_arr * nb * (128 * w + 128 + 128 * T)
+                print(f"undelta_pack_batch {ty} W={w}: {n_arr} arrays x {nb} blocks in one launch {t:8.4f} ms  {n_arr * nb * 1024 / t / 1e6:7.1f} Gint/s  "
+                      f"{nbytes / t / 1e6:7.1f} GB/s ({nbytes / t / 8e9:.3f} of peak)  {'== one big undelta_pack' if same else 'MISMATCH'} | "
+                      f"the same blocks as one contiguous column, one call: {tc:8.4f} ms ({(t / tc - 1) * 100:+.1f} %)", flush=True)
+                del batch, pk_all, bs_all, un_all, want, packed, bases, outs
         return
     if args.cases == "refbench":
         # What the reference's own criterion benches time (besides benches/bitpacking.rs, which bench.py's headline and
