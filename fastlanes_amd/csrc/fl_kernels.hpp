@@ -50,21 +50,23 @@ struct StreamArgs {
 // narrow ones.  Rotated, every CU walks through all phases: the ramp 0.798 -> 0.812 (what seeded-random widths get), random widths
 // -0.2 %.  Uniform-width kernels have nothing to decorrelate and lose 0.2-1 % to it, so only the mixed-width kernels set it.
 constexpr unsigned TILE_MAP_ROTATE = 0x80u;
-__device__ __forceinline__ uint64_t rotate_rows_of_32(uint64_t r, uint64_t run, bool rotate)
+// (U = the integer type the map is computed in: uint64_t in general; a kernel whose slot count is known to fit 31 bits may ask for
+// uint32_t -- the same code in scalar registers half as wide)
+template <typename U> __device__ __forceinline__ U rotate_rows_of_32(U r, U run, bool rotate)
 {
-    const uint64_t row = r >> 5;
+    const U row = r >> 5;
     return (rotate && ((row + 1) << 5) <= run) ? ((row << 5) | ((r + row) & 31u)) : r;      // a short last row stays as it is
 }
-__device__ __forceinline__ uint64_t xcd_tile(unsigned b, uint64_t tiles_per_xcd, unsigned window_shift_and_flags)
+template <typename U = uint64_t> __device__ __forceinline__ U xcd_tile(unsigned b, U tiles_per_xcd, unsigned window_shift_and_flags)
 {
     const unsigned window_shift = window_shift_and_flags & 0x7fu;
     const bool rotate = (window_shift_and_flags & TILE_MAP_ROTATE) != 0;
-    if (window_shift >= 32) return (uint64_t)(b & 7u) * tiles_per_xcd + rotate_rows_of_32(b >> 3, tiles_per_xcd, rotate);
+    if (window_shift >= 32) return (U)(b & 7u) * tiles_per_xcd + rotate_rows_of_32<U>((U)(b >> 3), tiles_per_xcd, rotate);
     const unsigned first = (b >> window_shift) << window_shift;
     const unsigned r = b - first;
-    const uint64_t left = tiles_per_xcd * 8 - first, full = 1ull << window_shift;
-    const uint64_t span = left < full ? left : full;
-    return first + (uint64_t)(r & 7u) * (span >> 3) + rotate_rows_of_32(r >> 3, span >> 3, rotate);
+    const U left = tiles_per_xcd * 8 - first, full = (U)1 << window_shift;
+    const U span = left < full ? left : full;
+    return first + (U)(r & 7u) * (span >> 3) + rotate_rows_of_32<U>((U)(r >> 3), span >> 3, rotate);
 }
 
 // A/B tools (fl_internal_set_kernel_policy bits 25-29): log2 of the window in blocks for EVERY kernel; 0 = each kernel's default

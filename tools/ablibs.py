@@ -5,7 +5,9 @@ consumers, occupancy of the narrow types' cell-column kernels).
     python tools/ablibs.py <rounds> <ops> <cases> lib_a.so lib_b.so ...
       ops    comma list of: unpack pack undelta_pack undelta_pack_untranspose undelta compare sums   (undelta ignores the width)
       cases  comma list of type:width, e.g. u8:3,u8:6,u16:3   (or "consumers" = round 3's consumer sweep)
-GB/s of algorithmic bytes, median."""
+      ops    also: unpack_widths (the width of the case is ignored: width[b] = 1 + b mod T, BASELINE config 5's ramp)
+    FL_AB_BLOCKS=<n> in the environment: that many blocks per case instead of ~8 GB of traffic (BASELINE sizes: 10000000).
+GB/s of algorithmic bytes, median and best."""
 import ctypes
 import os
 import sys
@@ -34,8 +36,14 @@ for ty, W in cases:
     for op in OPS:
         bpb = {"compare": 128 * W + 128, "sums": 128 * W + 8, "undelta_pack": 128 * W + 128 + 128 * T,
                "undelta_pack_untranspose": 128 * W + 128 + 128 * T, "undelta": 2 * 128 * T + 128}.get(op, 128 * W + 128 * T)
-        n = int(8e9 / bpb)
-        pk = rand_u8(n * 128 * W, 2, dev).view(tdt)
+        n = int(os.environ.get("FL_AB_BLOCKS", 0)) or int(8e9 / bpb)
+        widths = offsets = None
+        if op == "unpack_widths":
+            widths = (1 + torch.arange(n, dtype=torch.int64, device=dev) % T).to(torch.uint8)
+            offsets = torch.cumsum(widths.to(torch.int64) * 128, 0) - widths.to(torch.int64) * 128
+            pbytes = int(offsets[-1].item()) + 128 * int(widths[-1].item())
+            bpb = (pbytes + n * 128 * T) / n
+        pk = rand_u8(pbytes if op == "unpack_widths" else n * 128 * W, 2, dev).view(tdt)
         un = rand_u8(n * 128 * T, 3, dev).view(tdt) if op in ("pack", "undelta") else None
         bases = rand_u8(n * 128, 4, dev).view(tdt) if op.startswith("undelta") else None
         out_bytes = {"compare": n * 128, "sums": n * 8, "pack": n * 128 * W}.get(op, n * 128 * T)
@@ -48,6 +56,9 @@ for ty, W in cases:
             elif op == "sums":
                 f = getattr(lib, f"fl_{ty}_unpack_block_sums"); f.argtypes = [U, P, Z, P, P]
                 fns.append(lambda f=f: f(W, pk.data_ptr(), n, out.data_ptr(), None))
+            elif op == "unpack_widths":
+                f = getattr(lib, f"fl_{ty}_unpack_widths"); f.argtypes = [P, P, P, Z, P, Z, P, P]
+                fns.append(lambda f=f: f(widths.data_ptr(), offsets.data_ptr(), pk.data_ptr(), pbytes, out.data_ptr(), n, None, None))
             elif op == "unpack":
                 f = getattr(lib, f"fl_{ty}_unpack"); f.argtypes = [U, P, P, Z, P]
                 fns.append(lambda f=f: f(W, pk.data_ptr(), out.data_ptr(), n, None))
@@ -76,5 +87,9 @@ for ty, W in cases:
                 a.record(); f(); b.record(); b.synchronize()
                 ms[k].append(a.elapsed_time(b))
         g = [n * bpb / sorted(m)[len(m) // 2] / 1e6 for m in ms]
-        print(f"{ty:3s} W={W:<2d} {op:12s}{'' if same else ' MISMATCH'} | " + " ".join(f"{x:6.0f}" for x in g), flush=True)
-        del pk, out, ref, un, bases
+        best = [n * bpb / min(m) / 1e6 for m in ms]
+        delta = "" if len(g) != 2 else f" | {(g[1] / g[0] - 1) * 100:+5.1f} %"
+        print(f"{ty:3s} W={W:<2d} {op:24s} n={n:<9d}{'' if same else ' MISMATCH'} | " + " ".join(f"{x:6.0f}" for x in g) +
+              " | best " + " ".join(f"{x:6.0f}" for x in best) + delta, flush=True)
+        del pk, out, ref, un, bases, widths, offsets
+        torch.cuda.empty_cache()

@@ -87,7 +87,8 @@ def main():
     cases = [("unpack", "u32", 7), ("pack", "u32", 7), ("unpack", "u64", 17), ("pack", "u64", 17), ("undelta_pack", "u32", 12),
              ("unpack_mixed", "u32", 0), ("unpack", "u16", 3), ("pack", "u16", 3), ("unpack", "u8", 3), ("pack", "u8", 3),
              ("delta", "u32", 0), ("undelta", "u32", 0), ("transpose", "u32", 0), ("untranspose", "u64", 0),
-             ("transpose_delta_pack", "u32", 12), ("undelta_pack_untranspose", "u32", 12),
+             ("transpose_delta_pack", "u32", 12), ("transpose_delta_pack", "u64", 20), ("transpose_delta_pack", "u16", 9),
+             ("transpose_delta_pack", "u8", 4), ("undelta_pack_untranspose", "u32", 12),
              ("unpack_compare", "u16", 3), ("unpack_compare", "u32", 7), ("unpack_compare", "u64", 17),
              ("unpack_block_sums", "u32", 7), ("unpack_block_sums", "u16", 3), ("block_min_max", "u32", 0)]
     if args.cases != "all":
