@@ -27,9 +27,14 @@ counter-based stream regenerated on the host (`per_rank[i].correct`,
 `per_rank[i].verified_blocks`); any mismatch makes every rank exit non-zero.
 
 Where a workload's buffers live in HBM moves the kernel by a few per cent (DESIGN.md
-section 4): --placement auto (default) allocates and fills both layouts it knows, times a
-few launches on each BEFORE the timed region, keeps the faster buffers and prints both
-figures (`roofline.placement_probe_GBps`).
+section 4): the buffers come from the C ABI's own optional helper, fl_column_pair_alloc
+(include/fastlanes_amd.h), and --placement auto (default) is its FL_LAYOUT_PROBE: the LIBRARY
+allocates both layouts it knows, times a bare stream of the pair's read : write proportion on
+each before anything is filled, keeps the faster pair and reports both figures
+(`roofline.placement_probe_GBps`) -- a figure any user of the header can reproduce.  After
+the checks a BARE STREAM of the workload's exact read : write mix is timed on the workload's
+own buffers (`roofline.bare_stream_GBps`, `roofline.frac_of_bare_stream`): box and
+placement cancel in that ratio, the kernel stays.
 
 After the headline leg the same processes time BASELINE.json configs[4] --
 u32, width[b] = 1 + b mod 32, the 10 B-integer column (9 765 625 blocks) sharded
@@ -103,11 +108,11 @@ def parse():
     ap.add_argument("--no-check", action="store_true", help="skip the per-rank oracle check of the timed output")
     ap.add_argument("--placement", default="auto", choices=("auto", "zoned", "separate"),
                     help="where a workload's buffers live in HBM moves every streaming kernel by a few per cent (DESIGN.md section 4). "
-                         "auto (default): both layouts below are allocated, filled and timed for a few launches before the timed region, "
-                         "the faster one is kept, both figures are reported (roofline.placement_probe); "
-                         "separate: one allocation per buffer, wherever the driver puts it; "
-                         "zoned: input and output carved from one allocation, the output centred on a 64-GiB multiple "
-                         "(fastlanes_amd/placement.py)")
+                         "The buffers come from fl_column_pair_alloc (include/fastlanes_amd.h).  auto (default) = FL_LAYOUT_PROBE: the library "
+                         "allocates both layouts below, times a bare stream on each before anything is filled and keeps the faster pair, "
+                         "both figures are reported (roofline.placement_probe_GBps); "
+                         "separate: one hipMalloc per buffer, wherever the driver puts it; "
+                         "zoned: input and output carved from one allocation, the output centred on a 64-GiB multiple")
     ap.add_argument("--verify", default="auto", choices=("auto", "full", "sample"),
                     help="what every rank checks of what it just timed, outside the timed region: sample = the first / last / sampled "
                          "blocks of its slice against the oracle; full = that, plus two 64-bit content hashes per block of its WHOLE "
@@ -271,9 +276,10 @@ class Workload:
     """One rank's share of a workload: device buffers + step()."""
 
     def __init__(self, name, n, first_block, rank, dev, placement="separate"):
-        """placement: "separate" = one torch allocation per buffer, wherever the driver puts them; "zoned" = input and output
-        carved from ONE allocation, the input at offset 0, the output centred on a 64-GiB multiple (fastlanes_amd/placement.py;
-        falls back to "separate" when the slab does not fit).  main() picks by measurement (placed_workload)."""
+        """placement: the layout asked of fl_column_pair_alloc (include/fastlanes_amd.h) -- "separate" = one hipMalloc per buffer,
+        wherever the driver puts them; "zoned" = input and output carved from ONE allocation, the input at offset 0, the output
+        centred on a 64-GiB multiple; "auto" = the library tries both, times a bare stream of in_bytes : out_bytes on each and keeps
+        the faster pair (self.probe = both figures) -- or "torch" = plain torch tensors (several ranks on one device)."""
         import torch
         import fastlanes_amd as fl
         from fastlanes_amd import placement as pl
@@ -285,19 +291,23 @@ class Workload:
         esz = ESZ[ty]
         un_bytes = 1024 * esz
         self.bases = None
-        self.slab = None
+        self.pair = None
+        self.probe = None
         lib = fl.load()
 
         def buffers(in_bytes, out_bytes, aux_bytes=0):
             """(input, aux, output) as uint8 tensors; the input (and aux) filled with counter-based random bytes on the device"""
-            if placement == "zoned" and pl.fits(in_bytes, out_bytes, dev, aux_bytes):
-                self.slab, src, aux, dst = pl.column_pair(in_bytes, out_bytes, dev, aux_bytes)
-                self.placement = "zoned"
-            else:
+            if placement == "torch":
                 src = torch.empty(in_bytes, dtype=torch.uint8, device=dev)
                 aux = torch.empty(aux_bytes, dtype=torch.uint8, device=dev)
                 dst = torch.empty(out_bytes, dtype=torch.uint8, device=dev)
-                self.placement = "separate"
+                self.placement = "torch"
+            else:
+                # through the C ABI's own helper (include/fastlanes_amd.h: fl_column_pair_alloc): "auto" = both layouts probed with a
+                # bare stream INSIDE the library, the faster pair kept -- before the buffers are filled
+                self.pair = pl.ColumnPair(in_bytes, out_bytes, dev, aux_bytes, layout=placement)
+                src, aux, dst = self.pair.input, self.pair.aux, self.pair.output
+                self.placement, self.probe = self.pair.layout, self.pair.probe_GBps
             st = ctypes_stream(dev)
             self.src_seed, self.aux_seed = 1234 + rank, 99 + rank
             for t, seed in ((src, self.src_seed), (aux, self.aux_seed)):
@@ -707,10 +717,19 @@ def live_pmc_traffic(args, workload=None):
         return None
 
 
-def roofline(w, kern_ms, traffic=None, traffic_source=None):
+def roofline(w, kern_ms, traffic=None, traffic_source=None, bare=None):
     avg_s = sum(kern_ms) / len(kern_ms) / 1e3
+    med_ms = sorted(kern_ms)[len(kern_ms) // 2]
     achieved = w.bytes / avg_s / 1e9
-    return {
+    extra = {}
+    if bare:
+        # the kernel against a bare stream of its own bytes on its own buffers in this run: box and placement cancel, the kernel stays
+        extra = {"bare_stream_GBps": bare["GBps"], "bare_stream_best_GBps": bare["best_GBps"],
+                 "frac_of_bare_stream": round(w.bytes / med_ms / 1e6 / bare["GBps"], 4),
+                 "bare_stream_frac_of_peak": round(bare["GBps"] / HBM_PEAK_GBPS, 4),
+                 "bare_stream": bare["shape"] + "; median / best of 9 launches after the timed region, same buffers; "
+                                "frac_of_bare_stream = median kernel rate / median stream rate"}
+    return dict({
         "bound": "hbm",
         "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBPS,
@@ -721,11 +740,13 @@ def roofline(w, kern_ms, traffic=None, traffic_source=None):
         "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBPS, 4),
         "algorithmic_bytes_per_launch": int(w.bytes),
         "kernel_ms_avg": round(avg_s * 1e3, 4),
+        "kernel_ms_median": round(med_ms, 4),
         "kernel_ms_min": round(min(kern_ms), 4),
         "read_GBps": round(w.in_bytes / avg_s / 1e9, 1),
         "write_GBps": round(w.out_bytes / avg_s / 1e9, 1),
-        "timing": "HIP events on the launch stream around each of the K launches (rank 0)",
-    }
+        "timing": "HIP events on the launch stream around each of the K launches (rank 0); achieved / frac from the average, "
+                  "median and min beside it",
+    }, **extra)
 
 
 def run_check(w, args, ctl):
@@ -747,17 +768,19 @@ def run_check(w, args, ctl):
 
 
 PLACEMENT_TEXT = {
-    "zoned": "input and output carved from ONE allocation: the input at offset 0, the output centred on the 64-GiB multiple behind "
-             "it (fastlanes_amd/placement.py, DESIGN.md section 4)",
-    "separate": "one torch allocation per buffer, wherever the driver puts it",
+    "zoned": "fl_column_pair_alloc(FL_LAYOUT_ZONED): input and output carved from ONE allocation, the input at offset 0, the output centred "
+             "on the 64-GiB multiple behind it (include/fastlanes_amd.h, DESIGN.md section 4)",
+    "separate": "fl_column_pair_alloc(FL_LAYOUT_SEPARATE): one hipMalloc per buffer, wherever the driver puts it",
+    "torch": "one torch allocation per buffer (several ranks share one device)",
 }
 
 
 def placement_text(placed, probe):
     t = PLACEMENT_TEXT[placed]
     if probe:
-        t += ("; chosen by measurement (--placement auto): a few launches on each layout before the timed region, GB/s " +
-              ", ".join(f"{k} {v:.0f}" for k, v in probe.items()))
+        t += ("; chosen by fl_column_pair_alloc(FL_LAYOUT_PROBE) -- the library's own measurement, reproducible through the header alone: a "
+              "bare stream of the pair's read : write proportion on each layout before the buffers were filled, GB/s " +
+              ", ".join(f"{k} {v}" for k, v in probe.items()))
     return t
 
 
@@ -766,56 +789,62 @@ def release(w):
     import gc
     import torch
     if w is not None:
-        w.step = w.src = w.dst = w.bases = w.slab = None
+        w.step = w.src = w.dst = w.bases = None
+        if w.pair is not None:
+            w.pair.free()
+            w.pair = None
     gc.collect()
     torch.cuda.empty_cache()
 
 
-def probe_rate(w, launches=5):
-    """GB/s (median of a few launches) of a workload's kernel on the buffers it holds"""
+def bare_stream(w, launches=9):
+    """A BARE STREAM of the workload's read : write mix on the workload's OWN buffers, in the same run (fl_internal_bare_stream with the
+    launch shape the library's kernel for this call has: fastlanes_amd_internal.h): what the memory gives these bytes at these addresses
+    on this box, with no codec work at all.  Overwrites the output: only after the checks.  {"GBps": median, "best_GBps": .., ...}"""
+    import ctypes
     import torch
+    import fastlanes_amd as fl
+    lib = fl.load()
+    op = {"unpack": 0, "pack": 1, "undelta_pack": 2, "unpack_mixed": 3}[w.op]
+    Z, I = ctypes.c_size_t, ctypes.c_int
+    iu, au, ou, nt, wv, wn = Z(), Z(), Z(), I(), I(), I()
+    if lib.fl_internal_bare_stream_shape(op, 8 * ESZ[w.ty], 33 if op == 3 else w.width, *[ctypes.byref(x) for x in (iu, au, ou, nt, wv, wn)]) != 0:
+        return None
+    n = w.n
+    in_unit = iu.value
+    if op == 3:                      # a mixed-width column: units of the column's mean packed block, rounded down to a cell
+        in_unit = (w.in_bytes // n) & ~15
+    aux = w.bases.data_ptr() if au.value else None
+    st = ctypes_stream(w.dst.device)
+
+    def launch():
+        return lib.fl_internal_bare_stream(w.src.data_ptr(), in_unit, aux, au.value, w.dst.data_ptr(), ou.value, n, nt.value, wv.value, wn.value, st)
     for _ in range(2):
-        w.step()
+        if launch() != 0:
+            return None
     torch.cuda.synchronize()
     ms = []
     for _ in range(launches):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); w.step(); b.record(); b.synchronize()
+        a.record(); launch(); b.record(); b.synchronize()
         ms.append(a.elapsed_time(b))
-    return w.bytes / (sorted(ms)[len(ms) // 2] / 1e3) / 1e9
+    ms.sort()
+    nbytes = n * (in_unit + au.value + ou.value)
+    return {"GBps": round(nbytes / ms[len(ms) // 2] / 1e6, 1), "best_GBps": round(nbytes / ms[0] / 1e6, 1), "bytes": nbytes,
+            "shape": f"{in_unit} B read{' + %d B aux' % au.value if au.value else ''} : {ou.value} B written per wavefront, "
+                     f"{'non-temporal' if nt.value else 'default'} loads, {wv.value} waves/SIMD, "
+                     f"{'whole-column tile map' if wn.value >= 31 else '2^%d-block windows' % wn.value} (the shape of the library's kernel for this call)"}
 
 
 def placed_workload(name, n, first, rank, dev, args, single_device=False):
-    """(workload, {"layout": GB/s of the probe, ...} or None).  --placement auto: where a column lives in HBM moves the same kernel
-    by a few per cent, differently per workload and per box, and nothing in an address tells: so both layouts
-    are allocated and filled, each is timed for a few launches, the slower one is freed and the faster one -- the very buffers that
-    were probed -- goes into the timed region.  The choice is a measurement made before the timed region; both figures go into the
-    line.  A layout that does not fit next to the other one is skipped."""
-    if single_device:               # several ranks on one device: no room for a slab each
-        return Workload(name, n, first, rank, dev, "separate"), None
-    if args.placement != "auto":
-        return Workload(name, n, first, rank, dev, args.placement), None
-    best, probe = None, {}
-    for layout in ("separate", "zoned"):
-        w = None
-        try:
-            w = Workload(name, n, first, rank, dev, layout)
-            if w.placement != layout:          # the zoned slab did not fit: Workload fell back to separate buffers
-                raise MemoryError(layout)
-            rate = probe_rate(w)
-        except Exception as e:                 # a candidate that cannot be built (out of memory next to the other one) is no candidate
-            if best is None and layout == "zoned":
-                raise
-            print(f"rank {rank}: placement candidate '{layout}' skipped: {e!r}"[:300], file=sys.stderr)
-            release(w)
-            continue
-        probe[layout] = round(rate, 1)
-        if best is None or rate > probe[best.placement]:
-            release(best)
-            best = w
-        else:
-            release(w)
-    return best, probe
+    """(workload, the placement probe's figures or None).  Where a column lives in HBM moves the same kernel by a few per cent,
+    differently per workload and per box, and nothing in an address tells: --placement auto asks the LIBRARY
+    (fl_column_pair_alloc, FL_LAYOUT_PROBE) to allocate both layouts it knows, time a bare stream on each and keep the faster pair --
+    a measurement made before the buffers are filled, by a call any user of the header can make; both figures go into the line."""
+    if single_device:               # several ranks on one device: no room for a probe each
+        return Workload(name, n, first, rank, dev, "torch"), None
+    w = Workload(name, n, first, rank, dev, args.placement)
+    return w, w.probe
 
 
 def config5_leg(args, world, rank, dev, ctl):
@@ -834,12 +863,12 @@ def config5_leg(args, world, rank, dev, ctl):
     per_rank = ctl.gather([float(n), avg_ms, float(w.bytes)])
     flags, n_checked, verified = run_check(w, args, ctl)
     if rank != 0:
+        release(w)
         return {"flags": flags}
     traffic = source = None
     placed = w.placement
-    import torch
-    w.src = w.dst = w.slab = None            # measured and checked (the PMC child builds its own copy of the column)
-    torch.cuda.empty_cache()
+    bare = bare_stream(w)                    # after the checks (it overwrites the output), same buffers, same run
+    release(w)                               # measured and checked (the PMC child builds its own copy of the column)
     if world == 1 and not args.no_pmc:
         live = live_pmc_traffic(args, "u32_mixed_unpack")
         if live is not None:
@@ -865,7 +894,7 @@ def config5_leg(args, world, rank, dev, ctl):
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "aggregate_GBps": round(sum(v[2] for v in per_rank) * args.steps / elapsed / 1e9, 1),
         "per_rank": ranks,
-        "roofline_rank0": dict(roofline(w, kern_ms, traffic, source), **({"placement_probe_GBps": probe} if probe else {})),
+        "roofline_rank0": dict(roofline(w, kern_ms, traffic, source, bare), **({"placement_probe_GBps": probe} if probe else {})),
         "placement": placement_text(placed, probe),
         "correctness": check_text(flags, n_checked, verified),
         "flags": flags,
@@ -940,8 +969,8 @@ def main():
     per_rank = ctl.gather([float(n), avg_ms, float(w.bytes)])
     flags, n_checked, verified = run_check(w, args, ctl)       # every rank, its own slice, outside the timed region
     placed = w.placement
-    w.src = w.dst = w.bases = w.slab = None          # leg 1 is measured and checked: its column can go
-    torch.cuda.empty_cache()
+    bare = bare_stream(w) if rank == 0 else None     # after the checks (it overwrites the output), same buffers, same run
+    release(w)                                       # leg 1 is measured and checked: its column can go
 
     # ---- rank 0, N=1: the cpu_baseline leg (with the checks, the only place bench.py touches oracle/)
     cpu = None
@@ -1000,7 +1029,7 @@ def main():
             "dtype": ty,
             "data": "synthetic (uniform random packed bits, generated on device; inputs resident in HBM)",
             "config": {"workload": workload, "blocks_per_gpu": n, "sharding": "contiguous block range per GPU, no collective"},
-            "roofline": roofline(w, kern_ms, traffic, traffic_source),
+            "roofline": roofline(w, kern_ms, traffic, traffic_source, bare),
             "per_rank": ranks,
             "correctness": check_text(flags, n_checked, verified),
         }

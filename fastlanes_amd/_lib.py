@@ -75,7 +75,8 @@ def _signatures(ty):
 
 
 # include/fastlanes_amd_internal.h: test / measurement hooks, not part of the stable ABI
-INTERNAL_SYMBOLS = ["fl_internal_set_kernel_policy", "fl_internal_get_kernel_policy", "fl_internal_probe_memory_classes"]
+INTERNAL_SYMBOLS = ["fl_internal_set_kernel_policy", "fl_internal_get_kernel_policy", "fl_internal_probe_memory_classes",
+                    "fl_internal_bare_stream", "fl_internal_bare_stream_shape"]
 
 
 def exported_symbols():
@@ -83,7 +84,7 @@ def exported_symbols():
     names = ["fl_version", "fl_status_string", "fl_last_hip_error", "fl_packed_len",
              "fl_mixed_plan_create", "fl_mixed_plan_destroy", "fl_mixed_plan_n_blocks",
              "fl_mixed_plan_packed_bytes", "fl_mixed_plan_offsets", "fl_mixed_plan_widths",
-             "fl_widths_to_offsets", "fl_fill_random", "fl_host_release"]
+             "fl_widths_to_offsets", "fl_fill_random", "fl_host_release", "fl_column_pair_alloc", "fl_column_pair_free"]
     names += INTERNAL_SYMBOLS
     for ty in TYPES:
         names += [f"fl_{ty}_{m}" for m in _signatures(ty)]
@@ -139,6 +140,14 @@ def load():
     lib.fl_fill_random.argtypes = [_P, _Z, _Q, _P]
     lib.fl_internal_probe_memory_classes.restype = ctypes.c_int
     lib.fl_internal_probe_memory_classes.argtypes = [_P, _Z, ctypes.POINTER(ctypes.c_int), _P]
+    lib.fl_internal_bare_stream.restype = ctypes.c_int
+    lib.fl_internal_bare_stream.argtypes = [_P, _Z, _P, _Z, _P, _Z, _Z, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]
+    lib.fl_internal_bare_stream_shape.restype = ctypes.c_int
+    lib.fl_internal_bare_stream_shape.argtypes = [ctypes.c_int, _U, _U] + [ctypes.POINTER(ctypes.c_size_t)] * 3 + [ctypes.POINTER(ctypes.c_int)] * 3
+    lib.fl_column_pair_alloc.restype = ctypes.c_int
+    lib.fl_column_pair_alloc.argtypes = [_Z, _Z, _Z, ctypes.c_int, _P] + [ctypes.POINTER(_P)] * 4 + [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint32)]
+    lib.fl_column_pair_free.restype = ctypes.c_int
+    lib.fl_column_pair_free.argtypes = [_P]
     lib.fl_widths_to_offsets.restype = ctypes.c_int
     lib.fl_widths_to_offsets.argtypes = [_U, _P, _Z, _P, _P, _P, _P]
     for ty in TYPES:

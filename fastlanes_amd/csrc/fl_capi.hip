@@ -8,6 +8,7 @@
 #include "fl_misc.hpp"
 #include "fl_widths.hpp"
 #include "fl_chain.hpp"
+#include "fl_stream.hpp"
 #include "fl_batch.hpp"
 #include "fl_scan.hpp"
 #include "fl_consume.hpp"
@@ -597,6 +598,7 @@ int run_chain_widths(int op, const uint8_t* widths, const uint64_t* offsets, con
     if (n_blocks == 0) return FL_OK;
     if (!widths || !offsets) return FL_ERR_NULL;
     int waves = mixed_waves(Elem<T>::BITS, op == OP_TRANSPOSE_DELTA_PACK);
+    if (sizeof(T) == 1 && op != OP_TRANSPOSE_DELTA_PACK) waves = 0;       // u8's decode is the persistent pipelined kernel: 0 = its own grid
     const int pol = g_kernel_policy.load(std::memory_order_relaxed);       // A/B tools: 2 + 256 * waves
     if ((pol & 0xff) == 2 && ((pol >> 8) & 0xff)) waves = (pol >> 8) & 0xff;
     const int rc = run_chain<T>(op, waves, 0, in, bases, out, n_blocks, stream, widths, offsets, packed_bytes, err_flag);
@@ -741,6 +743,167 @@ int fl_fill_random(void* dst, size_t n_bytes, uint64_t seed, void* stream)
     FL_DEVICE_TIER(stream, dst);
     hipError_t e = launch_fill_random(static_cast<uint64_t*>(dst), n_bytes / 8, seed, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? FL_OK : hip_fail(e);
+}
+
+// ---- the bare stream (fl_stream.hpp) and the launch shape the library gives an op -----------------------------------------------
+int fl_internal_bare_stream(const void* in, size_t in_unit, const void* aux, size_t aux_unit, void* out, size_t out_unit, size_t n_units,
+                            int nt_loads, int waves, int window_log2_units, void* stream)
+{
+    if (n_units == 0) return FL_OK;
+    if ((in_unit && !in) || (aux_unit && !aux) || !out) return FL_ERR_NULL;
+    if (misaligned(in) || misaligned(aux) || misaligned(out)) return FL_ERR_ALIGN;
+    if (in_unit > BARE_MAX_UNIT || out_unit > BARE_MAX_UNIT || aux_unit > 1024 || ((in_unit | out_unit | aux_unit) & 15u)) return FL_ERR_INDEX;
+    FL_DEVICE_TIER(stream, in, aux, out);
+    BareArgs a{static_cast<const char*>(in), static_cast<const char*>(aux), static_cast<char*>(out), n_units, 0,
+               (unsigned)in_unit, (unsigned)aux_unit, (unsigned)out_unit, 63u};
+    hipError_t e = launch_bare_stream(a, nt_loads != 0, waves, window_log2_units, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? FL_OK : hip_fail(e);
+}
+
+// op: 0 unpack / unfor_pack, 1 pack / for_pack, 2 undelta_pack, 3 unpack over a mixed-width column (width = the column's mean width
+// times 2, so that 16.5 can be said).  The shape a bare stream must have to shadow that call: bytes per block on either side, the
+// cache policy of the loads, waves per SIMD and tile-map window the library's own kernel for that (T, W) runs with.
+int fl_internal_bare_stream_shape(int op, unsigned type_bits, unsigned width, size_t* in_unit, size_t* aux_unit, size_t* out_unit,
+                                  int* nt_loads, int* waves, int* window_log2_units)
+{
+    if (type_bits != 8 && type_bits != 16 && type_bits != 32 && type_bits != 64) return FL_ERR_INDEX;
+    if (op < 0 || op > 3) return FL_ERR_INDEX;
+    if (width > (op == 3 ? 2 * type_bits : type_bits)) return FL_ERR_WIDTH;
+    if (!in_unit || !aux_unit || !out_unit || !nt_loads || !waves || !window_log2_units) return FL_ERR_NULL;
+    const size_t packed = op == 3 ? 64u * width : 128u * width, unpacked = 128u * type_bits;
+    *in_unit = op == 1 ? unpacked : packed;
+    *out_unit = op == 1 ? packed : unpacked;
+    *aux_unit = op == 2 ? 128 : 0;
+    const WaveOp wop = op == 1 ? WAVE_PACK : op == 2 ? WAVE_UNDELTA_PACK : WAVE_UNPACK;
+    int w = op == 3 ? mixed_waves(type_bits, false) : chosen_waves(type_bits, width, wop);
+    if (w == 0) w = op == 1 ? (type_bits >= 32 ? 1 : 2) : 3;       // a cell-column kernel: its waves_per_eu cap (fl_kernels.hpp)
+    *waves = w < 3 ? 3 : w;
+    *nt_loads = op == 1 || op == 3 || 2 * width >= type_bits;       // fl_widths.hpp: RD_AUTO; pack reads non-temporally
+    *window_log2_units = window_log2_blocks_default(op == 1 ? TRAFFIC_READ : TRAFFIC_WRITE);
+    return FL_OK;
+}
+
+// ---- fl_column_pair_alloc / _free: the OPTIONAL allocation helper of fastlanes_amd.h ------------------------------------------------
+namespace {
+struct ColumnPair {
+    void* bufs[3] = {nullptr, nullptr, nullptr};       // separate: in, aux, out; zoned: the slab only
+    void *in = nullptr, *aux = nullptr, *out = nullptr;
+    void release()
+    {
+        for (void*& b : bufs) {
+            if (b) (void)hipFree(b);
+            b = nullptr;
+        }
+    }
+};
+constexpr size_t PAIR_ALIGN = 256, PAIR_ZONE = (size_t)64 << 30;
+inline size_t pair_pad(size_t b) { return (b + PAIR_ALIGN - 1) & ~(PAIR_ALIGN - 1); }
+
+hipError_t pair_alloc(int layout, size_t in_bytes, size_t aux_bytes, size_t out_bytes, ColumnPair& p)
+{
+    if (layout == FL_LAYOUT_SEPARATE) {
+        hipError_t e = hipMalloc(&p.bufs[0], in_bytes ? in_bytes : PAIR_ALIGN);
+        if (e == hipSuccess && aux_bytes) e = hipMalloc(&p.bufs[1], aux_bytes);
+        if (e == hipSuccess) e = hipMalloc(&p.bufs[2], out_bytes ? out_bytes : PAIR_ALIGN);
+        if (e != hipSuccess) { p.release(); return e; }
+        p.in = p.bufs[0]; p.aux = p.bufs[1]; p.out = p.bufs[2];
+        return hipSuccess;
+    }
+    // ONE allocation: the input (then aux) at offset 0, the output centred on the first 64-GiB multiple that leaves room for them
+    const size_t in_end = pair_pad(in_bytes) + pair_pad(aux_bytes), half = pair_pad(out_bytes) / 2;
+    size_t k = 1;
+    while (k * PAIR_ZONE < half + in_end) {
+        if (++k > 8) return hipErrorOutOfMemory;
+    }
+    const size_t out_off = (k * PAIR_ZONE - half) & ~(PAIR_ALIGN - 1);
+    hipError_t e = hipMalloc(&p.bufs[0], out_off + pair_pad(out_bytes));
+    if (e != hipSuccess) return e;
+    char* base = static_cast<char*>(p.bufs[0]);
+    p.in = base;
+    p.aux = aux_bytes ? base + pair_pad(in_bytes) : nullptr;
+    p.out = base + out_off;
+    return hipSuccess;
+}
+
+// GB/s of a bare stream in -> out over the pair (median of 5 after 2 untimed), in the proportion of the two sizes
+int pair_probe(const ColumnPair& p, size_t in_bytes, size_t aux_bytes, size_t out_bytes, hipStream_t s, double& gbps)
+{
+    const size_t big = in_bytes > out_bytes ? in_bytes : out_bytes;
+    const size_t n_units = big / 4096;
+    gbps = 0.0;
+    if (n_units < 1024) return FL_OK;                           // too small to say anything
+    auto unit = [&](size_t bytes) { size_t u = bytes / n_units & ~(size_t)15; return u > 4096 ? 4096 : u; };
+    BareArgs a{static_cast<const char*>(p.in), static_cast<const char*>(p.aux), static_cast<char*>(p.out), n_units, 0,
+               (unsigned)unit(in_bytes), aux_bytes >= n_units * 128 ? 128u : 0u, (unsigned)unit(out_bytes), 63u};
+    if (a.out_unit == 0) return FL_OK;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    hipError_t e = hipEventCreate(&t0);
+    if (e == hipSuccess) e = hipEventCreate(&t1);
+    float ms[5] = {0, 0, 0, 0, 0};
+    for (int i = -2; i < 5 && e == hipSuccess; ++i) {
+        e = hipEventRecord(t0, s);
+        if (e == hipSuccess) e = launch_bare_stream(a, true, a.in_unit > a.out_unit ? 8 : 6, WINDOW_WHOLE, s);
+        if (e == hipSuccess) e = hipEventRecord(t1, s);
+        if (e == hipSuccess) e = hipEventSynchronize(t1);
+        float x = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&x, t0, t1);
+        if (i >= 0) ms[i] = x;
+    }
+    if (t0) (void)hipEventDestroy(t0);
+    if (t1) (void)hipEventDestroy(t1);
+    if (e != hipSuccess) return hip_fail(e);
+    std::sort(ms, ms + 5);
+    gbps = (double)n_units * (a.in_unit + a.aux_unit + a.out_unit) / (ms[2] * 1e6);
+    return FL_OK;
+}
+}  // namespace
+
+int fl_column_pair_alloc(size_t in_bytes, size_t aux_bytes, size_t out_bytes, int layout, void* stream, void** in, void** aux, void** out,
+                         void** handle, int* layout_kept, uint32_t* probe_gbps)
+{
+    if (!in || !out || !handle || (aux_bytes && !aux)) return FL_ERR_NULL;
+    if (layout != FL_LAYOUT_SEPARATE && layout != FL_LAYOUT_ZONED && layout != FL_LAYOUT_PROBE) return FL_ERR_INDEX;
+    *in = *out = *handle = nullptr;
+    if (aux) *aux = nullptr;
+    if (probe_gbps) probe_gbps[0] = probe_gbps[1] = 0;
+    ColumnPair* kept = new (std::nothrow) ColumnPair;
+    if (!kept) return hip_fail(hipErrorOutOfMemory);
+    int kept_layout = layout;
+    if (layout != FL_LAYOUT_PROBE) {
+        if (hipError_t e = pair_alloc(layout, in_bytes, aux_bytes, out_bytes, *kept); e != hipSuccess) { delete kept; return hip_fail(e); }
+    } else {
+        // both layouts, one after the other where both do not fit together: a bare stream of the pair's read : write proportion is
+        // timed on each, the faster one is kept.  The contents of the buffers are whatever the stream left there.
+        double best = -1.0;
+        kept_layout = -1;
+        for (int cand = FL_LAYOUT_SEPARATE; cand <= FL_LAYOUT_ZONED; ++cand) {
+            ColumnPair p;
+            if (pair_alloc(cand, in_bytes, aux_bytes, out_bytes, p) != hipSuccess) { (void)hipGetLastError(); continue; }
+            double gbps = 0.0;
+            if (const int rc = pair_probe(p, in_bytes, aux_bytes, out_bytes, static_cast<hipStream_t>(stream), gbps); rc != FL_OK) {
+                p.release(); kept->release(); delete kept; return rc;
+            }
+            if (probe_gbps) probe_gbps[cand] = (uint32_t)(gbps + 0.5);
+            if (gbps > best) { kept->release(); *kept = p; best = gbps; kept_layout = cand; }
+            else p.release();
+        }
+        if (kept_layout < 0) { delete kept; return hip_fail(hipErrorOutOfMemory); }
+    }
+    *in = kept->in;
+    if (aux) *aux = kept->aux;
+    *out = kept->out;
+    *handle = kept;
+    if (layout_kept) *layout_kept = kept_layout;
+    return FL_OK;
+}
+
+int fl_column_pair_free(void* handle)
+{
+    if (!handle) return FL_OK;
+    ColumnPair* p = static_cast<ColumnPair*>(handle);
+    p->release();
+    delete p;
+    return FL_OK;
 }
 
 int fl_internal_probe_memory_classes(void* slab, size_t slab_bytes, int* classes, void* stream)

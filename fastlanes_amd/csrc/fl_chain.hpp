@@ -31,9 +31,6 @@
 // LDS is wave-local: no s_barrier.
 #pragma once
 #include "fl_widths.hpp"
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
 
 namespace fl {
 
@@ -514,18 +511,22 @@ __device__ __forceinline__ void chain_blocks_lockstep(const ChainArgs& a, uint64
     });
 }
 
-// ---- COLUMN LANES (round 5): Delta's decode for the narrow types, EIGHT consecutive blocks per wavefront ----------------------------
-// The lockstep form above gives a lane R = T/8 rows of a block (u8: ONE row), so the running sum of delta.rs:56-61 runs ACROSS lanes:
-// base into group 0, a 3-step Hillis-Steele scan of the 8 lane groups by ds_bpermute (16 of them per block) with a SWAR byte add
-// (6 VALU per word) at every step -- 370 instructions per 1-KiB u8 block, the VALU ceiling VERDICT r04 weak #4 names (0.56 of the peak).
+// ---- COLUMN LANES (round 5): Delta's decode over a mixed-width u8 column, EIGHT consecutive blocks per wavefront --------------------
+// The lockstep form above gives a lane R = T/8 rows of a block -- for u8 ONE row -- so the running sum of delta.rs:56-61 runs ACROSS
+// lanes: base into group 0, a 3-step Hillis-Steele scan of the 8 lane groups by ds_bpermute (16 of them per block) with a SWAR byte
+// add (6 VALU per word) at every step: ~200 VALU instructions per 1-KiB block, VALU issue 0.75-0.81 of nominal, 0.56-0.60 of the HBM
+// peak (profiles/r05_sq_mixed_lockstep.txt).
 // Here lane (j = lane/8, c = lane%8) owns cell column c of block first+j for ALL T rows -- the ownership of the per-(T,W) cell-column
-// kernels (fl_device.hpp), but with the block's width in a VGPR: the packed rows of the wavefront's 8 blocks arrive by LDS-DMA (one
-// image per block), the lane funnel-shifts its T fields out of ITS image (macros.rs:144-164 with per-lane shift and mask), and the
-// chain is a thread-local running value: no cross-lane traffic, no scan.  The decoded rows go back into the same image IN PLACE (a
-// lane only ever touches its own 16-byte column of its own block), and every block leaves 1 KiB-contiguously as before.
-// u8 keeps the running value SPLIT -- even bytes and odd bytes in the low bytes of two u16x2 registers, exactly what the funnel's two
+// kernels (fl_device.hpp), but with the block's width in a VGPR: the lane funnel-shifts its T fields out of its block's LDS image
+// (macros.rs:144-164 with per-lane shift and mask) and the chain is a thread-local running value: no cross-lane traffic, no scan
+// (58 VALU per block).  The decoded rows go back into the same image IN PLACE (a lane only ever touches its own 16-byte column of
+// its own block), and every block leaves 1 KiB-contiguously as before.
+// The running value is kept SPLIT -- even bytes and odd bytes in the low bytes of two u16x2 registers, exactly what the funnel's two
 // v_perm produce anyway -- so an add is two v_pk_add_u16 (carries run into the unused high bytes) instead of the 6-op SWAR form,
 // and one v_perm per word merges them for the store.
+// That alone bought nothing (profiles/exp_columns_r05.txt, step 1): with a tile = a fresh workgroup the kernel is bound by the
+// wavefront's serial life, not by instructions.  The kernel below is therefore PIPELINED (k_chain_columns_pipelined).
+// Tried for u16 as well (16 rows per lane, 162 VGPRs) and not adopted: u16's lockstep kernel is not instruction-bound and stays ahead.
 template <typename T> struct ColumnSum;        // running value of one cell column, += one row's fields, -> the row's cell
 template <> struct ColumnSum<uint8_t> {
     uint32_t ev[4], od[4];
@@ -547,16 +548,6 @@ template <> struct ColumnSum<uint8_t> {
         return r;
     }
 };
-template <> struct ColumnSum<uint16_t> {
-    Cell<uint16_t> prev;
-    __device__ __forceinline__ void start(const Cell<uint16_t>& base) { prev = base; }
-    __device__ __forceinline__ Cell<uint16_t> step(const Cell<uint16_t>& cur, const Cell<uint16_t>& nxt, unsigned sh, uint32_t m)
-    {
-        prev = WaveBlock<uint16_t>::funnel(cur, nxt, sh, m).add(prev);                                // delta.rs:58-60
-        return prev;
-    }
-};
-
 constexpr unsigned COLUMN_LANES_BPW = 8;       // 64 lanes = 8 blocks x 8 cell columns
 
 // width and packed-side byte offset of block first+j in lane j (j < count), as loaded -- possibly still in flight
@@ -570,130 +561,6 @@ __device__ __forceinline__ ColumnMeta columns_meta_load(const ChainArgs& a, uint
         m.ov = a.offsets[mine];
     }
     return m;
-}
-
-template <typename T, int SNK>
-__device__ __forceinline__ void chain_blocks_columns(const ChainArgs& a, uint64_t first, unsigned count, const ColumnMeta& meta, char* lds, unsigned lane)
-{
-    using G = WaveBlock<T>;
-    constexpr int TB = G::TB;
-    constexpr unsigned BPW = COLUMN_LANES_BPW;
-    static_assert(sizeof(T) < 4, "column lanes: T x 4 VGPRs of rows per lane, and images filled by LDS-DMA (linear layouts only)");
-    static_assert(SNK == SNK_ROWS || SNK == SNK_ORIGINAL, "a decode: the sink is an unpacked block");
-    constexpr unsigned IMG = G::BLOCK_BYTES;               // one image per block: packed rows in, decoded rows out (in place)
-    const unsigned jm = lane >> 3, c16 = (lane & 7u) * 16u;
-    // per-block metadata: lane j holds block first+j's width and offset; broadcast per block for the descriptors and handed to the
-    // 8 lanes of the block's group for the decode
-    const bool mixed = a.widths != nullptr;                 // wave-uniform
-    unsigned w[BPW];
-    bool ok[BPW];
-    static_for<BPW>([&](auto Jt) {
-        constexpr unsigned j = decltype(Jt)::value;
-        ok[j] = j < count;
-        w[j] = a.width;
-        uint64_t packed_at = (first + j) * (uint64_t)(128u * a.width);
-        if (mixed && ok[j]) {
-            w[j] = (unsigned)__builtin_amdgcn_readlane((int)meta.wv, (int)j);
-            packed_at = readlane_elem<uint64_t>(meta.ov, j);
-            if (const uint32_t e = block_precondition(true, a.packed_bytes, w[j], packed_at, TB)) {   // bitpacking.rs:126, :111-113
-                raise_device_error(a.err_flag, e, lane);
-                ok[j] = false;
-            }
-        }
-        if (ok[j]) {                                        // wave-uniform
-            const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.in) + packed_at, 0, 128u * w[j], 0x00020000);
-            static_for<G::GROUPS>([&](auto Gi) {
-                constexpr int g = decltype(Gi)::value;
-                if (8u * g < w[j]) dma_1k_to_lds<RD_DMA_NT, g * 1024>(in_rs, lds + j * IMG, lane);
-            });
-        }
-    });
-    // this lane's block: its width (the group's lane j holds it) and whether it is decoded at all
-    unsigned wm = mixed ? (unsigned)__builtin_amdgcn_ds_bpermute((int)(jm * 4u), (int)meta.wv) : a.width;
-    bool okm = false;
-    static_for<BPW>([&](auto Jt) { if (jm == decltype(Jt)::value) okm = ok[decltype(Jt)::value]; });
-    if (!okm) wm = 0;
-    // base[lane] of this cell column (delta.rs:56): the wavefront's 8 blocks' bases are 1 KiB contiguous
-    Cell<T> base = Cell<T>::zero();
-    if (okm) base = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(a.bases + (first + jm) * 128u + c16));
-    wait_lds_dma();
-    wave_lds_fence();
-    // ---- the T fields of this column, row by row, the running sum thread-local (delta.rs:56-61) ---------------------------------
-    char* img = lds + jm * IMG + c16;
-    const typename G::word_t m = G::field_mask(wm);         // 0 for W == 0: every elem is 0 (macros.rs:118-125)
-    const unsigned last = (wm ? wm - 1u : 0u) * 128u;
-    Cell<T> x[TB];
-    ColumnSum<T> sum;
-    sum.start(base);
-    static_for<TB>([&](auto R) {
-        constexpr unsigned r = decltype(R)::value;
-        const unsigned bit = r * wm;
-        const unsigned a0 = (bit >> G::LOG_TB) * 128u, sh = bit & (TB - 1u);
-        const unsigned a1 = a0 + 128u < last ? a0 + 128u : last;               // the last row never reads past the end (macros.rs:156)
-        const Cell<T> cur = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(img + a0));
-        const Cell<T> nxt = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(img + a1));
-        x[r] = sum.step(cur, nxt, sh, m);
-    });
-    // in place: every read above and every write below touches only this lane's own column of its own block
-    if (okm) {
-        static_for<TB>([&](auto R) {
-            constexpr unsigned r = decltype(R)::value;
-            *reinterpret_cast<u32x4*>(img + Elem<T>::row_cell(r) * 16) = __builtin_bit_cast(u32x4, x[r]);
-        });
-    }
-    wave_lds_fence();
-    static_for<BPW>([&](auto Jt) {
-        constexpr unsigned j = decltype(Jt)::value;
-        if (ok[j]) chain_stage_out<T, SNK>(a, first + j, w[j], 0, lds + j * IMG, lane);
-    });
-    wave_lds_fence();                                       // the images are reused by the wavefront's next tile
-}
-
-// The column-lanes kernel: WGS / 64 wavefronts, each with 8 consecutive blocks and its own 8 LDS images.  A workgroup is PERSISTENT when
-// the launcher gives it fewer workgroups than tiles: workgroup b then walks tiles-map slots b, b + grid, b + 2 grid, .. (grid is a multiple
-// of 8, so it stays on its XCD and inside that XCD's run of the column), and the NEXT tile's widths[] / offsets[] are requested before
-// this tile's packed rows: the metadata round trip -- half of a wavefront's life when every tile is a fresh workgroup -- disappears
-// behind the data of the tile before, and so does the gap between a workgroup's end and its successor's start.
-template <typename T, int SNK, int WGS>
-__global__ __launch_bounds__(WGS) void k_chain_columns(ChainArgs a)
-{
-    using G = WaveBlock<T>;
-    extern __shared__ __attribute__((aligned(16))) char lds_all[];
-    constexpr unsigned BPW = COLUMN_LANES_BPW, TILE_BLOCKS = BPW * (WGS / 64);
-    const uint64_t n_tiles = (a.n_blocks + TILE_BLOCKS - 1) / TILE_BLOCKS;
-    const unsigned slots = (unsigned)(a.tiles_per_xcd * 8);
-    const unsigned tid = threadIdx.x;
-    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
-    char* lds = lds_all + wave * (BPW * G::BLOCK_BYTES);
-    // slot t of the tile map -> this wavefront's blocks; count = 0 for a padding slot / a wavefront past the end
-    auto blocks_of = [&](unsigned t, uint64_t& first, unsigned& count) {
-        const uint64_t tile = xcd_tile(t, a.tiles_per_xcd, a.window_shift);
-        first = tile * TILE_BLOCKS + (uint64_t)wave * BPW;
-        count = 0;
-        if (tile < n_tiles && first < a.n_blocks) {
-            const uint64_t left = a.n_blocks - first;
-            count = left < BPW ? (unsigned)left : BPW;
-        }
-    };
-    unsigned t = blockIdx.x;
-    uint64_t first;
-    unsigned count;
-    blocks_of(t, first, count);
-    ColumnMeta m = columns_meta_load(a, first, count, lane);
-    for (;;) {
-        const unsigned tn = t + gridDim.x;
-        const bool more = tn < slots;                       // wave-uniform
-        uint64_t first_n = 0;
-        unsigned count_n = 0;
-        if (more) blocks_of(tn, first_n, count_n);
-        const ColumnMeta mn = columns_meta_load(a, first_n, count_n, lane);   // in flight in front of this tile's data
-        if (count) chain_blocks_columns<T, SNK>(a, first, count, m, lds, lane);
-        if (!more) break;
-        t = tn;
-        first = first_n;
-        count = count_n;
-        m = mn;
-    }
 }
 
 template <typename T, int SRC, int BODY, int SNK, int RD = RD_VGPR, unsigned BPW = 1>
@@ -906,9 +773,14 @@ __global__ __launch_bounds__(64) void k_chain_columns_pipelined(ChainArgs a)
     }
 }
 
+// Resident wavefronts per CU: 8 (two per SIMD) measured best or equal against 12 (what the 130 VGPRs allow) and 16
+// (profiles/exp_columns_r05.txt, step 3); `waves` (the A/B tools' occupancy knob: waves per SIMD) overrides it.
+constexpr int COLUMNS_WAVES_PER_CU = 8;
 template <typename T, int SNK>
-hipError_t launch_chain_columns_pipelined(const ChainArgs& a0, int per_cu_override, hipStream_t s)
+hipError_t launch_chain_columns_pipelined(const ChainArgs& a0, int waves, hipStream_t s)
 {
+    if (a0.n_blocks == 0) return hipSuccess;
+    const int per_cu_override = waves > 0 ? 4 * waves : COLUMNS_WAVES_PER_CU;
     ChainArgs a = a0;
     constexpr unsigned TILE_BLOCKS = COLUMN_LANES_BPW;
     const uint64_t n_tiles = (a.n_blocks + TILE_BLOCKS - 1) / TILE_BLOCKS;
@@ -918,67 +790,16 @@ hipError_t launch_chain_columns_pipelined(const ChainArgs& a0, int per_cu_overri
     if (a.widths) a.window_shift |= TILE_MAP_ROTATE;
     const unsigned lds = TILE_BLOCKS * WaveBlock<T>::BLOCK_BYTES;
     unsigned grid = (unsigned)(a.tiles_per_xcd * 8);
-    int per_cu = per_cu_override, cus = 0, dev = 0;
+    int per_cu = per_cu_override, fit = 0, cus = 0, dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e == hipSuccess && per_cu <= 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_columns_pipelined<T, SNK>, 64, lds);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_chain_columns_pipelined<T, SNK>, 64, lds);
     if (e != hipSuccess) return e;
+    if (fit > 0 && per_cu > fit) per_cu = fit;              // a persistent grid must be resident at once to be worth anything
     const uint64_t resident = ((uint64_t)cus * (unsigned)per_cu + 7) / 8 * 8;          // a multiple of 8: a workgroup stays on its XCD
     if (resident >= 8 && resident < grid) grid = (unsigned)resident;
     FL_LAUNCH((k_chain_columns_pipelined<T, SNK>), dim3(grid), dim3(64), lds, s, a);
     return hipGetLastError();
-}
-
-// Launch shape of the column-lanes kernel.  EXPERIMENT KNOBS (round 5, while the shape is being chosen): FL_EXP_COLUMNS="wgs=64|256,
-// persist=0|1,lds=<bytes per workgroup>,grid=<workgroups per CU>" in the environment.
-struct ColumnsShape { int wgs = 256, persist = 1, lds = 0, per_cu = 0, pipe = 0; };
-inline ColumnsShape columns_shape_from_env()
-{
-    ColumnsShape c;
-    if (const char* e = getenv("FL_EXP_COLUMNS")) {
-        int v;
-        if (const char* p = strstr(e, "wgs=")) if (sscanf(p + 4, "%d", &v) == 1 && (v == 64 || v == 256)) c.wgs = v;
-        if (const char* p = strstr(e, "persist=")) if (sscanf(p + 8, "%d", &v) == 1) c.persist = v;
-        if (const char* p = strstr(e, "lds=")) if (sscanf(p + 4, "%d", &v) == 1) c.lds = v;
-        if (const char* p = strstr(e, "grid=")) if (sscanf(p + 5, "%d", &v) == 1) c.per_cu = v;
-        if (const char* p = strstr(e, "pipe=")) if (sscanf(p + 5, "%d", &v) == 1) c.pipe = v;
-    }
-    return c;
-}
-
-template <typename T, int SNK, int WGS>
-hipError_t launch_chain_columns_wgs(const ChainArgs& a0, const ColumnsShape& shape, hipStream_t s)
-{
-    ChainArgs a = a0;
-    constexpr unsigned TILE_BLOCKS = COLUMN_LANES_BPW * (WGS / 64);
-    const uint64_t n_tiles = (a.n_blocks + TILE_BLOCKS - 1) / TILE_BLOCKS;
-    a.tiles_per_xcd = (n_tiles + 7) / 8;
-    if (a.tiles_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;
-    a.window_shift = tile_window_shift(TRAFFIC_WRITE, TILE_BLOCKS);
-    if (a.widths) a.window_shift |= TILE_MAP_ROTATE;
-    unsigned lds = TILE_BLOCKS * WaveBlock<T>::BLOCK_BYTES;
-    if (shape.lds > (int)lds) lds = (unsigned)shape.lds;
-    if (lds > 64u * 1024u) return hipErrorInvalidValue;
-    unsigned grid = (unsigned)(a.tiles_per_xcd * 8);
-    if (shape.persist) {
-        int per_cu = shape.per_cu, cus = 0, dev = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e == hipSuccess && per_cu <= 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_columns<T, SNK, WGS>, WGS, lds);
-        if (e != hipSuccess) return e;
-        const uint64_t resident = ((uint64_t)cus * (unsigned)per_cu + 7) / 8 * 8;      // a multiple of 8: a workgroup stays on its XCD
-        if (resident >= 8 && resident < grid) grid = (unsigned)resident;
-    }
-    FL_LAUNCH((k_chain_columns<T, SNK, WGS>), dim3(grid), dim3(WGS), lds, s, a);
-    return hipGetLastError();
-}
-template <typename T, int SNK>
-hipError_t launch_chain_columns(const ChainArgs& a0, int /*waves*/, hipStream_t s)
-{
-    if (a0.n_blocks == 0) return hipSuccess;
-    const ColumnsShape shape = columns_shape_from_env();
-    if (shape.pipe) return launch_chain_columns_pipelined<T, SNK>(a0, shape.per_cu, s);
-    return shape.wgs == 64 ? launch_chain_columns_wgs<T, SNK, 64>(a0, shape, s) : launch_chain_columns_wgs<T, SNK, 256>(a0, shape, s);
 }
 
 // what the C ABI asks for

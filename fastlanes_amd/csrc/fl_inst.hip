@@ -79,9 +79,9 @@ template <> chain_launch_t chain_launcher<T>(int op)
 template <> chain_launch_t chain_widths_launcher<T>(int op)
 {
     constexpr unsigned B = chain_blocks_per_wave<T>();
-    if constexpr (sizeof(T) < 4) {                          // the narrow types' decode: column lanes (fl_chain.hpp)
-        if (op == OP_UNDELTA_PACK && !getenv("FL_EXP_LOCKSTEP")) return &launch_chain_columns<T, SNK_ROWS>;
-        if (op == OP_UNDELTA_PACK_UNTRANSPOSE && !getenv("FL_EXP_LOCKSTEP")) return &launch_chain_columns<T, SNK_ORIGINAL>;
+    if constexpr (sizeof(T) == 1) {                         // u8's decode: column lanes, pipelined (fl_chain.hpp)
+        if (op == OP_UNDELTA_PACK) return &launch_chain_columns_pipelined<T, SNK_ROWS>;
+        if (op == OP_UNDELTA_PACK_UNTRANSPOSE) return &launch_chain_columns_pipelined<T, SNK_ORIGINAL>;
     }
     switch (op) {
     case OP_UNDELTA_PACK: return &launch_chain<T, SRC_PACKED, CHAIN_UNDELTA, SNK_ROWS, RD_VGPR, B>;

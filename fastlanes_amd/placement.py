@@ -185,3 +185,65 @@ def consumer_pair(in_bytes, out_bytes, device, slab_bytes=128 << 30):
     return slab, slab[i_off:i_off + in_bytes], slab[o_off:o_off + out_bytes], {
         "classes": "".join("." if c is None else "ABC"[c] for c in cls), "input_granule": start, "output_granule": best,
         "input_one_class": one_class}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The C ABI's optional allocation helper (include/fastlanes_amd.h: fl_column_pair_alloc / _free), mirrored: what bench.py's
+# --placement auto uses since round 5, so that the figure it prints is one the header alone reproduces.
+# ---------------------------------------------------------------------------------------------------------------------------
+LAYOUTS = {"separate": 0, "zoned": 1, "auto": 2}
+LAYOUT_NAMES = {0: "separate", 1: "zoned"}
+
+
+class _DeviceBytes:
+    """`nbytes` of device memory at `ptr` for torch.as_tensor (zero copy)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+class ColumnPair:
+    """An (input, aux, output) triple of device buffers from fl_column_pair_alloc: `layout` "separate" (one allocation each), "zoned"
+    (one allocation, the output centred on a 64-GiB multiple) or "auto" (both tried, a bare stream of in_bytes : out_bytes timed on
+    each, the faster kept -- synchronous, contents unspecified).  .input / .aux / .output are uint8 torch tensors over the memory
+    (zero copy; they do NOT own it), .layout the layout kept, .probe_GBps {"separate": .., "zoned": ..} (auto only).  The memory is
+    released by .free() or when this object dies: keep it for as long as the tensors are in use."""
+
+    def __init__(self, in_bytes, out_bytes, device, aux_bytes=0, layout="auto", stream=None):
+        import ctypes
+        import torch
+        from . import _lib
+        self._lib = _lib.load()
+        P = ctypes.c_void_p
+        i, a, o, h = P(), P(), P(), P()
+        kept = ctypes.c_int(-1)
+        gbps = (ctypes.c_uint32 * 2)(0, 0)
+        dev = torch.device(device)
+        with torch.cuda.device(dev):
+            st = P(torch.cuda.current_stream(dev).cuda_stream) if stream is None else stream
+            rc = self._lib.fl_column_pair_alloc(in_bytes, aux_bytes, out_bytes, LAYOUTS[layout], st, ctypes.byref(i), ctypes.byref(a),
+                                                ctypes.byref(o), ctypes.byref(h), ctypes.byref(kept), gbps)
+        if rc != 0:
+            from .codec import FastLanesError
+            raise FastLanesError(rc, "fl_column_pair_alloc")
+        self._handle = h
+        self.layout = LAYOUT_NAMES[kept.value]
+        self.probe_GBps = {LAYOUT_NAMES[k]: int(gbps[k]) for k in (0, 1) if gbps[k]} if layout == "auto" else None
+
+        def view(ptr, nbytes):
+            if not nbytes:
+                return torch.empty(0, dtype=torch.uint8, device=dev)
+            return torch.as_tensor(_DeviceBytes(ptr.value, nbytes), device=dev)
+        self.input, self.aux, self.output = view(i, in_bytes), view(a, aux_bytes), view(o, out_bytes)
+
+    def free(self):
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            self.input = self.aux = self.output = None
+            self._lib.fl_column_pair_free(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -45,7 +45,11 @@
  * unreachable!() on width > T (bitpacking.rs:93,126,197) and unpack_single
  * asserts index < 1024 (bitpacking.rs:152).  Here every function returns an
  * fl_status; a binding maps nonzero to panic! to match.
- * Nothing throws or aborts across the ABI.
+ * Nothing throws or aborts across the ABI.  Every launch first CLEARS the calling
+ * thread's pending HIP error (hipGetLastError) so that FL_ERR_HIP always means this
+ * call's launch failed, never an earlier benign failure of the application's own
+ * HIP calls: an application that relies on hipGetLastError across a call into this
+ * library must read it before the call.
  *
  * Threading and device selection.  Re-entrant and thread-safe; no global state
  * besides HIP's own, and no entry point ever calls hipSetDevice.  The device is
@@ -119,6 +123,30 @@ void fl_host_release(void);
  * output number i+1 of splitmix64 seeded with seed * 0x9E3779B97F4A7C15.  dst 8-byte aligned, n_bytes a multiple of 8
  * (FL_ERR_ALIGN otherwise).  Asynchronous on `stream`. */
 int fl_fill_random(void *dst, size_t n_bytes, uint64_t seed, void *stream);
+
+/*
+ * OPTIONAL allocation helper -- never needed to use the codec: every entry point takes any 16-byte aligned device pointers and
+ * allocates nothing.  It exists because WHERE a column's buffers live in HBM moves every streaming kernel by a few per cent on
+ * MI355X (the same kernel, the same bytes, another allocation: 0.78-0.86 of the peak), nothing in an address
+ * tells which, and a caller that allocates a (packed, unpacked) pair it is going to stream through many times can MEASURE it once:
+ *   FL_LAYOUT_SEPARATE  one hipMalloc per buffer, wherever the driver puts them
+ *   FL_LAYOUT_ZONED     one hipMalloc; `in` (then `aux`) at its start, `out` centred on the first 64-GiB multiple that leaves room
+ *                       for them (concurrent writes are fastest spread over two stretches of the device memory); costs the unused
+ *                       bytes in between
+ *   FL_LAYOUT_PROBE     both are allocated, a bare read/write stream of in_bytes : out_bytes (no codec work; fl_stream.hpp) is timed
+ *                       on each for a few launches on `stream`, the faster pair is kept, the other freed.  SYNCHRONOUS (about
+ *                       10 launches over the buffers), and the buffers' contents are unspecified afterwards.  A layout that does
+ *                       not fit next to the other one is skipped.
+ * in / aux / out receive in_bytes / aux_bytes / out_bytes bytes (256-byte aligned; aux_bytes may be 0: *aux = NULL, aux itself may then
+ * be NULL); *handle owns the memory: fl_column_pair_free(handle) releases it (NULL is a no-op).  layout_kept (may be NULL) receives
+ * the layout of the returned pair, probe_gbps (may be NULL; 2 entries, indexed by layout) the probe's GB/s (0 = not measured).
+ * This is what bench.py's --placement auto does: the figure it prints is one this header alone reproduces.
+ */
+enum { FL_LAYOUT_SEPARATE = 0, FL_LAYOUT_ZONED = 1, FL_LAYOUT_PROBE = 2 };
+int fl_column_pair_alloc(size_t in_bytes, size_t aux_bytes, size_t out_bytes, int layout, void *stream,
+                         void **in, void **aux, void **out, void **handle, int *layout_kept,
+                         uint32_t *probe_gbps);
+int fl_column_pair_free(void *handle);
 
 /*
  * Mixed-width columns (BASELINE.json config 5): block b has its own width widths[b].

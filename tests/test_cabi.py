@@ -33,10 +33,38 @@ def _header_symbols():
 def test_every_declared_symbol_is_exported(lib):
     import fastlanes_amd
     syms = _header_symbols()
-    assert len(syms) == 4 * 42 + 16
+    assert len(syms) == 4 * 42 + 20
     assert sorted(fastlanes_amd.exported_symbols()) == syms
     for s in syms:
         assert hasattr(lib, s), s
+
+
+def test_column_pair_and_bare_stream_argument_checks_need_no_gpu(lib):
+    """fl_column_pair_alloc / fl_internal_bare_stream(_shape): every refusal happens before the first HIP call"""
+    P = ctypes.c_void_p
+    i, a, o, h = P(), P(), P(), P()
+    kept = ctypes.c_int(-1)
+    assert lib.fl_column_pair_alloc(1 << 20, 0, 1 << 20, 0, None, None, None, ctypes.byref(o), ctypes.byref(h), None, None) == 3   # FL_ERR_NULL
+    assert lib.fl_column_pair_alloc(1 << 20, 128, 1 << 20, 0, None, ctypes.byref(i), None, ctypes.byref(o), ctypes.byref(h), None, None) == 3
+    assert lib.fl_column_pair_alloc(1 << 20, 0, 1 << 20, 3, None, ctypes.byref(i), None, ctypes.byref(o), ctypes.byref(h), ctypes.byref(kept), None) == 2
+    assert lib.fl_column_pair_free(None) == 0
+    Z, I = ctypes.c_size_t, ctypes.c_int
+    iu, au, ou, nt, wv, wn = Z(), Z(), Z(), I(), I(), I()
+    refs = [ctypes.byref(x) for x in (iu, au, ou, nt, wv, wn)]
+    assert lib.fl_internal_bare_stream_shape(0, 32, 7, *refs) == 0
+    assert (iu.value, au.value, ou.value, nt.value, wn.value) == (896, 0, 4096, 0, 31) and 3 <= wv.value <= 8
+    assert lib.fl_internal_bare_stream_shape(1, 64, 17, *refs) == 0
+    assert (iu.value, au.value, ou.value, nt.value, wn.value) == (8192, 0, 2176, 1, 16)
+    assert lib.fl_internal_bare_stream_shape(2, 32, 12, *refs) == 0 and (iu.value, au.value, ou.value) == (1536, 128, 4096)
+    assert lib.fl_internal_bare_stream_shape(3, 32, 33, *refs) == 0 and (iu.value, ou.value, nt.value) == (2112, 4096, 1)
+    assert lib.fl_internal_bare_stream_shape(0, 32, 33, *refs) == 1 and lib.fl_internal_bare_stream_shape(0, 12, 3, *refs) == 2
+    assert lib.fl_internal_bare_stream_shape(4, 32, 3, *refs) == 2 and lib.fl_internal_bare_stream_shape(0, 32, 3, None, *refs[1:]) == 3
+    p = ctypes.c_void_p(0x1000)
+    assert lib.fl_internal_bare_stream(p, 896, None, 0, p, 4096, 0, 0, 5, 31, None) == 0        # nothing to do
+    assert lib.fl_internal_bare_stream(None, 896, None, 0, p, 4096, 10, 0, 5, 31, None) == 3
+    assert lib.fl_internal_bare_stream(ctypes.c_void_p(0x1008), 896, None, 0, p, 4096, 10, 0, 5, 31, None) == 4
+    assert lib.fl_internal_bare_stream(p, 900, None, 0, p, 4096, 10, 0, 5, 31, None) == 2       # not a multiple of 16
+    assert lib.fl_internal_bare_stream(p, 896, None, 0, p, 8208, 10, 0, 5, 31, None) == 2
 
 
 def test_packed_len_and_strings(lib):

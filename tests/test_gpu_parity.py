@@ -1813,3 +1813,59 @@ def test_every_kernel_family_under_load(fl, oracle, ty):
         sums = twice(lambda: fl.BitPacking.unpack_block_sums(w, pk))
         assert np.array_equal(sums.cpu().numpy().view(np.uint64)[idx], unpacked_s.reshape(k, 1024).astype(np.uint64).sum(axis=1)), (ty, w, "sums")
         del pk
+
+
+def test_column_pair_alloc_and_the_bare_stream(fl, oracle):
+    """fl_column_pair_alloc (the C ABI's optional allocation helper): every layout hands out buffers the codec works in, the
+    zoned layout is what the header says, the probe reports what it measured; fl_internal_bare_stream (bench.py's yardstick)
+    touches exactly its units."""
+    import ctypes
+    import torch
+    from fastlanes_amd import placement as pl
+    lib = fl.load()
+    n, W = 20011, 7
+    pk = values("u32", n * packed_len("u32", W), 9100)
+    want = oracle.batch("unpack", "u32", W, pk)
+    for layout in ("separate", "zoned", "auto"):
+        pair = pl.ColumnPair(n * 128 * W, n * 4096, "cuda:0", aux_bytes=n * 128, layout=layout)
+        assert pair.layout in ("separate", "zoned") and (layout == "auto" or pair.layout == layout)
+        for t, nb in ((pair.input, n * 128 * W), (pair.aux, n * 128), (pair.output, n * 4096)):
+            assert t.numel() == nb and t.data_ptr() % 256 == 0 and t.device.index == 0
+        if pair.layout == "zoned":       # input at the start, aux behind it, the output centred on the 64-GiB multiple
+            assert pair.aux.data_ptr() - pair.input.data_ptr() == (n * 128 * W + 255) // 256 * 256
+            half = ((n * 4096 + 255) // 256 * 256) // 2
+            assert pair.output.data_ptr() - pair.input.data_ptr() == ((64 << 30) - half) // 256 * 256
+        if layout == "auto":
+            assert pair.probe_GBps and set(pair.probe_GBps) <= {"separate", "zoned"} and all(v > 50 for v in pair.probe_GBps.values())
+            assert pair.layout == max(pair.probe_GBps, key=pair.probe_GBps.get)
+        else:
+            assert pair.probe_GBps is None
+        pair.input.view(torch.uint32).copy_(to_dev(pk))
+        got = fl.BitPacking.unpack(W, pair.input.view(torch.uint32), output=pair.output.view(torch.uint32))
+        assert np.array_equal(to_np(got, "u32"), want), layout
+        pair.free()
+        pair.free()                      # idempotent
+    # the bare stream: n units of 896 B (+ 128 B aux) read, 4096 B written; nothing outside them is touched, ragged unit count
+    src = to_dev(values("u8", n * 896, 9101))
+    aux = to_dev(values("u8", n * 128, 9102))
+    out = torch.full((n * 4096 + 8192,), 0x5A, dtype=torch.uint8, device="cuda:0")
+    for nt, waves, window in ((0, 5, 31), (1, 8, 16), (1, 3, 12)):
+        out.fill_(0x5A)
+        assert lib.fl_internal_bare_stream(src.data_ptr(), 896, aux.data_ptr(), 128, out.data_ptr(), 4096, n, nt, waves, window, None) == 0
+        torch.cuda.synchronize()
+        o = out.cpu().numpy()
+        assert (o[n * 4096:] == 0x5A).all() and not (o[:n * 4096].reshape(n, 4096) == 0x5A).all(axis=1).any()
+        if nt == 0:
+            first = o[:n * 4096].copy()
+        else:
+            assert np.array_equal(o[:n * 4096], first)          # the tile map and the cache policy never change a byte
+    # a pack-shaped stream (8 KiB read : 2176 B written) and a read-only one
+    big = to_dev(values("u8", 1000 * 8192, 9103))
+    small = torch.zeros(1000 * 2176 + 4096, dtype=torch.uint8, device="cuda:0")
+    assert lib.fl_internal_bare_stream(big.data_ptr(), 8192, None, 0, small.data_ptr(), 2176, 1000, 1, 8, 16, None) == 0
+    torch.cuda.synchronize()
+    assert not small[1000 * 2176:].any().item() and small[:1000 * 2176].any().item()
+    small.zero_()
+    assert lib.fl_internal_bare_stream(big.data_ptr(), 8192, None, 0, small.data_ptr(), 0, 1000, 1, 8, 31, None) == 0
+    torch.cuda.synchronize()
+    assert not small.any().item()
