@@ -60,7 +60,7 @@ extern "C" int example_min_for_pack_u32(unsigned width, const uint32_t* d_in, ui
     a.aux = nullptr;
     a.aux_stride = 0;
     a.n_blocks = n_blocks;
-    const unsigned grid = plan_grid(a, TRAFFIC_READ);
+    const unsigned grid = plan_grid(a, WIN_PACK, 32);
     hipStream_t s = static_cast<hipStream_t>(stream);
     (void)hipGetLastError();
     switch (width) {

@@ -174,7 +174,7 @@ hipError_t launch_batch_chain(const BatchArgs& b0, uint32_t max_blocks, int wave
     const uint64_t n_tiles = b.n_arrays * b.tiles_per_array;
     b.tiles_per_xcd = (n_tiles + 7) / 8;
     if (b.tiles_per_array == 0 || b.tiles_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;
-    b.window_shift = tile_window_shift(SNK == SNK_PACKED ? TRAFFIC_READ : TRAFFIC_WRITE, TILE_BLOCKS);
+    b.window_shift = tile_window_shift(chain_window_op<SRC, BODY, SNK>(), WaveBlock<T>::TB, TILE_BLOCKS);
     const unsigned need = TILE_BLOCKS * chain_wave_lds<T, SRC, SNK>();
     if (waves < 3) waves = 3;
     const unsigned pad = (CU_LDS_BYTES / (unsigned)waves) & ~1023u;
@@ -200,7 +200,7 @@ hipError_t launch_batch(const BatchArgs& b0, uint32_t max_blocks, int waves, hip
     const uint64_t n_tiles = b.n_arrays * b.tiles_per_array;
     b.tiles_per_xcd = (n_tiles + 7) / 8;
     if (b.tiles_per_array == 0 || b.tiles_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;
-    b.window_shift = tile_window_shift(PACK ? TRAFFIC_READ : TRAFFIC_WRITE, (unsigned)tile_blocks);
+    b.window_shift = tile_window_shift(PACK ? WIN_PACK : WIN_UNPACK, WaveBlock<T>::TB, (unsigned)tile_blocks);
     const unsigned lds = widths_lds_bytes<T>(waves, b.prefetch ? b.bpw : 1u);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     FL_LAUNCH((k_batch<T, PACK>), dim3((unsigned)(b.tiles_per_xcd * 8)), dim3(WG), lds, s, b);

@@ -779,7 +779,7 @@ int fl_internal_bare_stream_shape(int op, unsigned type_bits, unsigned width, si
     if (w == 0) w = op == 1 ? (type_bits >= 32 ? 1 : 2) : 3;       // a cell-column kernel: its waves_per_eu cap (fl_kernels.hpp)
     *waves = w < 3 ? 3 : w;
     *nt_loads = op == 1 || op == 3 || 2 * width >= type_bits;       // fl_widths.hpp: RD_AUTO; pack reads non-temporally
-    *window_log2_units = window_log2_blocks_default(op == 1 ? TRAFFIC_READ : TRAFFIC_WRITE);
+    *window_log2_units = window_log2_blocks(op == 1 ? WIN_PACK : op == 2 ? WIN_UNDELTA_PACK : WIN_UNPACK, type_bits);
     return FL_OK;
 }
 

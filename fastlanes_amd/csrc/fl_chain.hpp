@@ -590,6 +590,16 @@ __global__ __launch_bounds__(WG) void k_chain(ChainArgs a)
 
 typedef hipError_t (*chain_launch_t)(const ChainArgs&, int waves, hipStream_t);
 
+// the row of the generated window table (fl_dispatch.hpp) a (source, body, sink) triple belongs to
+template <int SRC, int BODY, int SNK> constexpr WindowOp chain_window_op()
+{
+    if (SNK == SNK_PACKED) return WIN_TRANSPOSE_DELTA_PACK;
+    if (SRC == SRC_PACKED) return SNK == SNK_ORIGINAL ? WIN_UNDELTA_PACK_UNTRANSPOSE : WIN_UNDELTA_PACK;
+    if (BODY == CHAIN_UNDELTA) return WIN_UNDELTA;
+    if (BODY == CHAIN_DELTA) return WIN_DELTA;
+    return SNK == SNK_ORIGINAL ? WIN_UNTRANSPOSE : WIN_TRANSPOSE;
+}
+
 template <typename T, int SRC, int BODY, int SNK, int RD = RD_VGPR, unsigned BPW = 1>
 hipError_t launch_chain(const ChainArgs& a0, int waves, hipStream_t s)
 {
@@ -599,7 +609,7 @@ hipError_t launch_chain(const ChainArgs& a0, int waves, hipStream_t s)
     const uint64_t n_tiles = (a.n_blocks + TILE_BLOCKS - 1) / TILE_BLOCKS;
     a.tiles_per_xcd = (n_tiles + 7) / 8;
     if (a.tiles_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;
-    a.window_shift = tile_window_shift(SNK == SNK_PACKED ? TRAFFIC_READ : SRC == SRC_PACKED ? TRAFFIC_WRITE : TRAFFIC_BALANCED, TILE_BLOCKS);
+    a.window_shift = tile_window_shift(chain_window_op<SRC, BODY, SNK>(), WaveBlock<T>::TB, TILE_BLOCKS);
     if constexpr (SRC == SRC_PACKED || SNK == SNK_PACKED) {
         if (a.widths) a.window_shift |= TILE_MAP_ROTATE;     // per-block widths may be periodic (fl_widths.hpp: launch_widths)
     } else {
@@ -786,7 +796,7 @@ hipError_t launch_chain_columns_pipelined(const ChainArgs& a0, int waves, hipStr
     const uint64_t n_tiles = (a.n_blocks + TILE_BLOCKS - 1) / TILE_BLOCKS;
     a.tiles_per_xcd = (n_tiles + 7) / 8;
     if (a.tiles_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;
-    a.window_shift = tile_window_shift(TRAFFIC_WRITE, TILE_BLOCKS);
+    a.window_shift = tile_window_shift(SNK == SNK_ORIGINAL ? WIN_UNDELTA_PACK_UNTRANSPOSE : WIN_UNDELTA_PACK, WaveBlock<T>::TB, TILE_BLOCKS);
     if (a.widths) a.window_shift |= TILE_MAP_ROTATE;
     const unsigned lds = TILE_BLOCKS * WaveBlock<T>::BLOCK_BYTES;
     unsigned grid = (unsigned)(a.tiles_per_xcd * 8);

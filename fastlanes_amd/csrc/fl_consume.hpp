@@ -532,7 +532,7 @@ template <typename T, int W, bool IS_EQ> hipError_t launch_unpack_compare(const 
     CompareArgs a = a0;
     const uint64_t n_tiles = (a.n_blocks + BLOCKS_PER_WG - 1) / BLOCKS_PER_WG;
     a.tiles_per_xcd = (n_tiles + 7) / 8;
-    a.window_shift = tile_window_shift(TRAFFIC_READ, BLOCKS_PER_WG);
+    a.window_shift = tile_window_shift(WIN_UNPACK_COMPARE, Elem<T>::BITS, BLOCKS_PER_WG);
     constexpr unsigned STATIC_LDS = sizeof(T) >= 4 ? 0u : BLOCKS_PER_WG * 144u;
     unsigned pad = 0;
     if (waves >= 3 && waves < 8) pad = ((160u * 1024u / (unsigned)waves) & ~1023u) - STATIC_LDS;   // < 64 KiB for waves >= 3
@@ -550,18 +550,18 @@ template <typename T, bool IS_EQ> const CompareTable<T>& compare_table_impl();
 
 typedef hipError_t (*reduce_launch_t)(const ReduceArgs&, hipStream_t);
 
-inline unsigned plan_grid(ReduceArgs& a)
+inline unsigned plan_grid(ReduceArgs& a, WindowOp op, unsigned type_bits)
 {
     const uint64_t n_tiles = (a.n_blocks + BLOCKS_PER_WG - 1) / BLOCKS_PER_WG;
     a.tiles_per_xcd = (n_tiles + 7) / 8;
-    a.window_shift = tile_window_shift(TRAFFIC_READ, BLOCKS_PER_WG);
+    a.window_shift = tile_window_shift(op, type_bits, BLOCKS_PER_WG);
     return (unsigned)(a.tiles_per_xcd * 8);
 }
 template <typename T, int W> hipError_t launch_unpack_block_sums(const ReduceArgs& a0, hipStream_t s)
 {
     if (a0.n_blocks == 0) return hipSuccess;
     ReduceArgs a = a0;
-    const unsigned grid = plan_grid(a);
+    const unsigned grid = plan_grid(a, WIN_UNPACK_BLOCK_SUMS, Elem<T>::BITS);
     FL_LAUNCH((k_unpack_block_sums<T, W>), dim3(grid), dim3(WG), 0, s, a);
     return hipGetLastError();
 }
@@ -569,7 +569,7 @@ template <typename T> hipError_t launch_block_min_max(const ReduceArgs& a0, hipS
 {
     if (a0.n_blocks == 0) return hipSuccess;
     ReduceArgs a = a0;
-    const unsigned grid = plan_grid(a);
+    const unsigned grid = plan_grid(a, WIN_BLOCK_MIN_MAX, Elem<T>::BITS);
     FL_LAUNCH((k_block_min_max<T>), dim3(grid), dim3(WG), 0, s, a);
     return hipGetLastError();
 }

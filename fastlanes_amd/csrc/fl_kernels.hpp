@@ -42,7 +42,7 @@ struct StreamArgs {
 // shorter; every window a multiple of 8 tiles): workgroups [first, first + span) serve window [first, first + span), and
 // inside it workgroup r -- which runs on XCD r % 8 (observed dispatch order; used for speed only, results never depend on
 // it) -- takes tile first + (r % 8) * span / 8 + r / 8, so XCD x owns one contiguous eighth of the window.  One window =
-// rounds 1-3's map (XCD x owns one contiguous eighth of the whole column).  Why windows: fl_dispatch.hpp (TrafficKind).
+// rounds 1-3's map (XCD x owns one contiguous eighth of the whole column).  Why windows, and which kernel gets one: fl_dispatch.hpp.
 // TILE_MAP_ROTATE (a flag next to the window shift; round 4, profiles/abmixed_rotate_r04.txt): inside an XCD's run the k-th row of
 // 32 tiles is rotated by k tiles.  An XCD has 32 CUs and its workgroups go to them round-robin, so WITHOUT the rotation CU c is
 // handed tiles c, c + 32, c + 64, ... of the run: if the data has a period that divides 32 tiles (BASELINE config 5: width[b] =
@@ -59,7 +59,9 @@ template <typename U> __device__ __forceinline__ U rotate_rows_of_32(U r, U run,
 }
 template <typename U = uint64_t> __device__ __forceinline__ U xcd_tile(unsigned b, U tiles_per_xcd, unsigned window_shift_and_flags)
 {
-    const unsigned window_shift = window_shift_and_flags & 0x7fu;
+    // a window is a multiple of 8 tiles: anything below 2^3 (a launcher that skipped plan_grid / tile_window_shift) is taken as 2^3,
+    // or several workgroups would map to one tile and others to none
+    const unsigned window_shift = (window_shift_and_flags & 0x7fu) < 3u ? 3u : (window_shift_and_flags & 0x7fu);
     const bool rotate = (window_shift_and_flags & TILE_MAP_ROTATE) != 0;
     if (window_shift >= 32) return (U)(b & 7u) * tiles_per_xcd + rotate_rows_of_32<U>((U)(b >> 3), tiles_per_xcd, rotate);
     const unsigned first = (b >> window_shift) << window_shift;
@@ -75,11 +77,11 @@ inline std::atomic<int>& window_override()
     static std::atomic<int> v{0};
     return v;
 }
-// window_shift of a launch: the kernel's traffic kind (or the override) in blocks -> tiles of `tile_blocks` blocks
-inline unsigned tile_window_shift(TrafficKind kind, unsigned tile_blocks)
+// window_shift of a launch: the (op, type)'s window from the generated table (or the override) in blocks -> tiles of `tile_blocks` blocks
+inline unsigned tile_window_shift(WindowOp op, unsigned type_bits, unsigned tile_blocks)
 {
     const int ov = window_override().load(std::memory_order_relaxed);
-    const int lg = ov ? ov : window_log2_blocks_default(kind);
+    const int lg = ov ? ov : window_log2_blocks(op, type_bits);
     if (lg >= WINDOW_WHOLE) return 63u;
     int tl = 0;
     while ((2u << tl) <= tile_blocks) ++tl;                  // floor(log2(tile_blocks))
@@ -373,11 +375,12 @@ void k_delta(StreamArgs a)
 typedef hipError_t (*stream_launch_t)(const StreamArgs&, hipStream_t);
 
 // grid = 8 XCD slots x tiles_per_xcd (padding workgroups exit immediately)
-inline unsigned plan_grid(StreamArgs& a, TrafficKind kind = TRAFFIC_BALANCED)
+// (user kernels on the functor API: plan_grid(a) = the whole-column map; plan_grid MUST fill the launch's tile-map fields)
+inline unsigned plan_grid(StreamArgs& a, WindowOp op = WIN_TRANSPOSE, unsigned type_bits = 0)
 {
     const uint64_t n_tiles = (a.n_blocks + BLOCKS_PER_WG - 1) / BLOCKS_PER_WG;
     a.tiles_per_xcd = (n_tiles + 7) / 8;
-    a.window_shift = tile_window_shift(kind, BLOCKS_PER_WG);
+    a.window_shift = type_bits ? tile_window_shift(op, type_bits, BLOCKS_PER_WG) : 63u;
     return (unsigned)(a.tiles_per_xcd * 8);
 }
 
@@ -386,7 +389,7 @@ hipError_t launch_unpack(const StreamArgs& a0, hipStream_t s)
 {
     if (a0.n_blocks == 0) return hipSuccess;
     StreamArgs a = a0;
-    const unsigned grid = plan_grid(a, TRAFFIC_WRITE);
+    const unsigned grid = plan_grid(a, BODY == BODY_UNDELTA ? WIN_UNDELTA_PACK : BODY == BODY_UNDELTA_UNTRANSPOSE ? WIN_UNDELTA_PACK_UNTRANSPOSE : WIN_UNPACK, Elem<T>::BITS);
     FL_LAUNCH((k_unpack<T, W, BODY>), dim3(grid), dim3(WG), 0, s, a);
     return hipGetLastError();
 }
@@ -395,7 +398,7 @@ hipError_t launch_pack(const StreamArgs& a0, hipStream_t s)
 {
     if (a0.n_blocks == 0 || W == 0) return hipSuccess;
     StreamArgs a = a0;
-    const unsigned grid = plan_grid(a, TRAFFIC_READ);
+    const unsigned grid = plan_grid(a, MODE == PACK_TRANSPOSE_DELTA ? WIN_TRANSPOSE_DELTA_PACK : WIN_PACK, Elem<T>::BITS);
     FL_LAUNCH((k_pack<T, W, MODE>), dim3(grid), dim3(WG), 0, s, a);
     return hipGetLastError();
 }
@@ -404,7 +407,7 @@ hipError_t launch_delta(const StreamArgs& a0, hipStream_t s)
 {
     if (a0.n_blocks == 0) return hipSuccess;
     StreamArgs a = a0;
-    const unsigned grid = plan_grid(a, TRAFFIC_BALANCED);
+    const unsigned grid = plan_grid(a, INVERSE ? WIN_UNDELTA : WIN_DELTA, Elem<T>::BITS);
     FL_LAUNCH((k_delta<T, INVERSE>), dim3(grid), dim3(WG), 0, s, a);
     return hipGetLastError();
 }

@@ -66,7 +66,7 @@ hipError_t launch_transpose(const StreamArgs& a0, hipStream_t s)
 {
     if (a0.n_blocks == 0) return hipSuccess;
     StreamArgs a = a0;
-    const unsigned grid = plan_grid(a, TRAFFIC_BALANCED);
+    const unsigned grid = plan_grid(a, INVERSE ? WIN_UNTRANSPOSE : WIN_TRANSPOSE, Elem<T>::BITS);
     FL_LAUNCH((k_transpose<T, INVERSE>), dim3(grid), dim3(WG), 0, s, a);
     return hipGetLastError();
 }

@@ -637,7 +637,7 @@ hipError_t launch_widths(const WidthsArgs& a0, int waves, hipStream_t s)
     const uint64_t n_tiles = (a.n_blocks + tile_blocks - 1) / tile_blocks;
     a.tiles_per_xcd = (n_tiles + 7) / 8;
     if (a.tiles_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;   // > 2^33 blocks in one launch
-    a.window_shift = tile_window_shift(PACK ? TRAFFIC_READ : TRAFFIC_WRITE, (unsigned)tile_blocks);
+    a.window_shift = tile_window_shift(PACK ? WIN_PACK : WIN_UNPACK, WaveBlock<T>::TB, (unsigned)tile_blocks);
     if (a.widths) a.window_shift |= TILE_MAP_ROTATE;         // per-block widths may be periodic: keep CUs from locking onto one phase
     const dim3 grid((unsigned)(a.tiles_per_xcd * 8));
     if (a.bpw < 2 || a.bpw > 16) a.prefetch = 0;

@@ -91,7 +91,16 @@ def main():
              ("transpose_delta_pack", "u8", 4), ("undelta_pack_untranspose", "u32", 12),
              ("unpack_compare", "u16", 3), ("unpack_compare", "u32", 7), ("unpack_compare", "u64", 17),
              ("unpack_block_sums", "u32", 7), ("unpack_block_sums", "u16", 3), ("block_min_max", "u32", 0)]
-    if args.cases != "all":
+    if args.cases == "matrix":
+        # every row of fl_window_table.inc x every element type (what tools/make_window_table.py reads), one mid-range width each
+        W1 = {"u8": 3, "u16": 3, "u32": 7, "u64": 17}          # BitPacking
+        W2 = {"u8": 4, "u16": 9, "u32": 12, "u64": 20}         # Delta
+        cases = []
+        for ty in ("u8", "u16", "u32", "u64"):
+            cases += [(op, ty, W1[ty]) for op in ("unpack", "pack", "unpack_compare", "unpack_block_sums")]
+            cases += [(op, ty, W2[ty]) for op in ("undelta_pack", "undelta_pack_untranspose", "transpose_delta_pack")]
+            cases += [(op, ty, 0) for op in ("delta", "undelta", "transpose", "untranspose", "block_min_max")]
+    elif args.cases != "all":
         keep = args.cases.split(",")
         cases = [c for c in cases if c[0] in keep]
     print(f"# {lib.fl_version().decode()}\n# GB/s of algorithmic bytes (fraction of 8 TB/s), median of {args.reps} round-robin launches per window; window = log2 blocks, "

@@ -42,6 +42,8 @@ for stage in "$@"; do
     timeout 900 python tools/sweep.py --cases single 2>&1 | grep -v amdgpu.ids > $R/sweep_single.txt; cat $R/sweep_single.txt ;;
   window_ab)    # the tile-map window per (op, T): whole-column map vs 2^16-block windows vs 8-GiB windows, same buffers
     timeout 1500 python tools/abwindow.py ${FL_WINDOW_CASES:+--cases $FL_WINDOW_CASES} 2>&1 | grep -v amdgpu.ids > $R/window_ab.txt; cat $R/window_ab.txt ;;
+  window_matrix) # every row of fl_window_table.inc x every type: the input of tools/make_window_table.py (one file per box)
+    timeout 1500 python tools/abwindow.py --cases matrix --windows 31,16 --gb 24 2>&1 | grep -v amdgpu.ids > $R/window_matrix.txt; cat $R/window_matrix.txt ;;
   bench)
     timeout 900 python bench.py > $R/bench_u32w7.json 2> $R/bench.err; echo "bench rc=$?"; cat $R/bench_u32w7.json ;;
   *) echo "unknown stage $stage" ;;

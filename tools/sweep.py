@@ -233,6 +233,12 @@ def main():
                  ("undelta_pack_untranspose", "u64", 20), ("transpose_delta_pack", "u64", 20),
                  ("undelta_pack_untranspose", "u16", 9), ("transpose_delta_pack", "u16", 9),
                  ("undelta_pack_untranspose", "u8", 4), ("transpose_delta_pack", "u8", 4)]
+    elif args.cases == "allwidths":
+        # EVERY (T, W) x {unpack, pack, unfor_pack, undelta_pack} through the automatic dispatch (the `match width` of
+        # bitpacking.rs:82-95 that every W must serve), one slab, class map printed; summarised per (op, T) at the end
+        for ty in ("u8", "u16", "u32", "u64"):
+            for w in range(1, ESZ[ty] * 8 + 1):
+                cases += [(op, ty, w) for op in ("unpack", "pack", "unfor_pack", "undelta_pack")]
     elif args.cases == "widths":
         for ty in ("u8", "u16", "u32", "u64"):
             T = ESZ[ty] * 8
@@ -529,20 +535,41 @@ def main():
             torch.cuda.empty_cache()
         return
     if args.cases == "single":
-        # batched unpack_single (random access): 64 M random indices into a 1 M-block u32 W=7 column
-        n, k = 1_000_000, 64_000_000
-        pk = rnd(n * 896, 1).view(torch.uint32)
-        g = torch.Generator(device=dev); g.manual_seed(5)
-        idx = torch.randint(0, n * 1024, (k,), dtype=torch.int64, device=dev, generator=g)
-        for sorted_idx in (False, True):
-            ii = torch.sort(idx).values if sorted_idx else idx
-            fl.BitPacking.unpack_single(7, pk, ii, n_blocks=n)
-            torch.cuda.synchronize()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(); fl.BitPacking.unpack_single(7, pk, ii, n_blocks=n); b.record(); b.synchronize()
-            ms = a.elapsed_time(b)
-            print(f"unpack_single u32 W=7 {k} {'sorted' if sorted_idx else 'random'} indices over {n} blocks: "
-                  f"{ms:.3f} ms  {k / ms / 1e6:.2f} G lookups/s", flush=True)
+        # batched unpack_single (bitpacking.rs:132-200; benches/bitpacking.rs:36-65 times one lookup): k lookups into an n-block column
+        # -- random, sorted, strided (one per block: every lookup a different block) and dense (all 1024 of consecutive blocks);
+        # uniform-width and mixed-width entry points.  A lookup needs 1-2 words of sizeof(T) bytes (:164-178); the memory system
+        # moves 32-byte sectors (64-byte requests on gfx950), so a RANDOM lookup costs a sector however small T is.
+        for ty, w in (("u32", 7), ("u64", 17), ("u16", 3), ("u8", 3)):
+            esz, T = ESZ[ty], ESZ[ty] * 8
+            n, k = 1_000_000, 64_000_000
+            pk = rnd(n * 128 * w, 1).view(TDT[ty])
+            g = torch.Generator(device=dev); g.manual_seed(5)
+            idx = torch.randint(0, n * 1024, (k,), dtype=torch.int64, device=dev, generator=g)
+            out1 = torch.empty(k, dtype=TDT[ty], device=dev)
+            widths = torch.full((n,), w, dtype=torch.uint8, device=dev)
+            offsets, _ = fl.widths_to_offsets(ty, widths)
+            patterns = (("random", idx), ("sorted", torch.sort(idx).values),
+                        ("strided (one per block)", (torch.arange(k, dtype=torch.int64, device=dev) % n) * 1024 + (torch.arange(k, dtype=torch.int64, device=dev) * 7) % 1024),
+                        ("dense (whole blocks in order)", torch.arange(k, dtype=torch.int64, device=dev)))
+            lib = fl.load()
+            err = torch.zeros(1, dtype=torch.int32, device=dev)
+            for name, ii in patterns:
+                # the raw C ABI: no allocation and no error-flag read-back inside the timed region
+                for label, f in (("unpack_single", lambda: getattr(lib, f"fl_{ty}_unpack_single")(w, pk.data_ptr(), n, ii.data_ptr(), k, out1.data_ptr(), err.data_ptr(), None)),
+                                 ("unpack_single_widths", lambda: getattr(lib, f"fl_{ty}_unpack_single_widths")(widths.data_ptr(), offsets.data_ptr(), pk.data_ptr(), n * 128 * w, n, ii.data_ptr(), k, out1.data_ptr(), err.data_ptr(), None))):
+                    assert f() == 0 and f() == 0
+                    torch.cuda.synchronize()
+                    ms = []
+                    for _ in range(args.reps):
+                        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        a.record(); f(); b.record(); b.synchronize()
+                        ms.append(a.elapsed_time(b))
+                    t = sorted(ms)[len(ms) // 2]
+                    io = k * (8 + esz)                  # the index read and the value written, per lookup
+                    print(f"{label:21s} {ty:4s} W={w:<2d} {k} lookups, {name:30s} {t:8.3f} ms  {k / t / 1e6:7.2f} G lookups/s  "
+                          f"index+result stream {io / t / 1e6:7.1f} GB/s ({io / t / 8e9:.3f} of peak)", flush=True)
+            del pk, idx, out1, widths, offsets
+            torch.cuda.empty_cache()
         return
     out = []
     for op, ty, w in cases:
@@ -550,6 +577,14 @@ def main():
         out.append(r)
         print(f"{op:13s} {ty:4s} W={w:<3d} n={r['n_blocks']:>9d} {r['ms']:9.4f} ms {r['GBps']:8.1f} GB/s {r['frac']:.3f} {r['Gints']:8.1f} Gint/s" + (f"   [{r['placed']}]" if r.get("placed") else ""), flush=True)
         torch.cuda.empty_cache()
+    if args.cases == "allwidths":
+        print("# ---- summary: fraction of the 8 TB/s peak per (op, type) over all widths 1..T: min (at W) / median / max (at W)")
+        for op in ("unpack", "pack", "unfor_pack", "undelta_pack"):
+            for ty in ("u8", "u16", "u32", "u64"):
+                rows = sorted((r["frac"], r["w"]) for r in out if r["op"] == op and r["ty"] == ty)
+                print(f"# {op:13s} {ty:4s} min {rows[0][0]:.3f} (W={rows[0][1]:<2d})  median {rows[len(rows) // 2][0]:.3f}  max {rows[-1][0]:.3f} (W={rows[-1][1]})")
+        worst = sorted(out, key=lambda r: r["frac"])[:8]
+        print("# ---- the eight slowest (op, T, W): " + "; ".join(f"{r['op']} {r['ty']} W={r['w']} {r['frac']:.3f}" for r in worst))
     if args.json:
         json.dump(out, open(args.json, "w"), indent=1)
 
