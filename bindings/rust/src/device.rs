@@ -155,3 +155,44 @@ impl_device_codec!(u8, fl_u8_unpack, fl_u8_pack, fl_u8_undelta_pack, fl_u8_unfor
 impl_device_codec!(u16, fl_u16_unpack, fl_u16_pack, fl_u16_undelta_pack, fl_u16_unfor_pack, fl_u16_unpack_batch);
 impl_device_codec!(u32, fl_u32_unpack, fl_u32_pack, fl_u32_undelta_pack, fl_u32_unfor_pack, fl_u32_unpack_batch);
 impl_device_codec!(u64, fl_u64_unpack, fl_u64_pack, fl_u64_undelta_pack, fl_u64_unfor_pack, fl_u64_unpack_batch);
+
+/// The optional allocation helper of `fastlanes_amd.h` as an owner: a (read side, write side) buffer pair for a column, placed by
+/// measurement by default (`ffi::FL_LAYOUT_PROBE`: the library allocates both layouts it knows, times a bare read : write stream on
+/// each and keeps the faster pair -- synchronous, contents unspecified afterwards).  Never needed to use the codec: every call above
+/// takes any 16-byte aligned device pointers.  (`fastlanes::ColumnPair` in `include/fastlanes_amd.hpp` is the compiled, GPU-tested twin.)
+pub struct ColumnPair<T> {
+    handle: *mut c_void,
+    input: *mut T,
+    output: *mut T,
+    in_len: usize,
+    out_len: usize,
+    /// `ffi::FL_LAYOUT_SEPARATE` / `ffi::FL_LAYOUT_ZONED`: the layout that was kept
+    pub layout: i32,
+    /// GB/s of the probe stream per layout (0 = not measured)
+    pub probe_gbps: [u32; 2],
+    _own: PhantomData<T>,
+}
+impl<T> ColumnPair<T> {
+    /// `in_len` / `out_len` in ELEMENTS of `T`; `layout` one of `ffi::FL_LAYOUT_*`
+    pub fn new(in_len: usize, out_len: usize, layout: i32, stream: Stream) -> Self {
+        let (mut i, mut o, mut h) = (core::ptr::null_mut::<c_void>(), core::ptr::null_mut::<c_void>(), core::ptr::null_mut::<c_void>());
+        let (mut kept, mut gbps) = (-1i32, [0u32; 2]);
+        ffi::check(
+            unsafe {
+                ffi::fl_column_pair_alloc(in_len * size_of::<T>(), 0, out_len * size_of::<T>(), layout, stream.0, &mut i,
+                                          core::ptr::null_mut(), &mut o, &mut h, &mut kept, gbps.as_mut_ptr())
+            },
+            "fl_column_pair_alloc",
+        );
+        Self { handle: h, input: i as *mut T, output: o as *mut T, in_len, out_len, layout: kept, probe_gbps: gbps, _own: PhantomData }
+    }
+    /// the read side, to be filled by the caller (e.g. a `hipMemcpy` of the packed column)
+    pub fn input_mut(&mut self) -> DeviceSliceMut<'_, T> { unsafe { DeviceSliceMut::from_raw_parts(self.input, self.in_len) } }
+    pub fn input(&self) -> DeviceSlice<'_, T> { unsafe { DeviceSlice::from_raw_parts(self.input as *const T, self.in_len) } }
+    pub fn output_mut(&mut self) -> DeviceSliceMut<'_, T> { unsafe { DeviceSliceMut::from_raw_parts(self.output, self.out_len) } }
+}
+impl<T> Drop for ColumnPair<T> {
+    fn drop(&mut self) {
+        unsafe { ffi::fl_column_pair_free(self.handle) };
+    }
+}

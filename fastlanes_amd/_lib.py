@@ -76,7 +76,7 @@ def _signatures(ty):
 
 # include/fastlanes_amd_internal.h: test / measurement hooks, not part of the stable ABI
 INTERNAL_SYMBOLS = ["fl_internal_set_kernel_policy", "fl_internal_get_kernel_policy", "fl_internal_probe_memory_classes",
-                    "fl_internal_bare_stream", "fl_internal_bare_stream_shape"]
+                    "fl_internal_bare_stream", "fl_internal_bare_stream_shape", "fl_internal_zero_copy_fallbacks"]
 
 
 def exported_symbols():
@@ -140,6 +140,8 @@ def load():
     lib.fl_fill_random.argtypes = [_P, _Z, _Q, _P]
     lib.fl_internal_probe_memory_classes.restype = ctypes.c_int
     lib.fl_internal_probe_memory_classes.argtypes = [_P, _Z, ctypes.POINTER(ctypes.c_int), _P]
+    lib.fl_internal_zero_copy_fallbacks.restype = ctypes.c_uint64
+    lib.fl_internal_zero_copy_fallbacks.argtypes = []
     lib.fl_internal_bare_stream.restype = ctypes.c_int
     lib.fl_internal_bare_stream.argtypes = [_P, _Z, _P, _Z, _P, _Z, _Z, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]
     lib.fl_internal_bare_stream_shape.restype = ctypes.c_int

@@ -35,18 +35,15 @@ std::atomic<int> g_kernel_policy{0};
 // waves per SIMD to run the wave-per-block kernel at, or 0 = use the cell-column kernel.  The per-(T,W) cell-column
 // families are only built where the table chose them (cell_column_built); Delta's / Transpose's per-type cell-column
 // kernels (no width parameter) always exist.
-inline int chosen_waves(unsigned type_bits, unsigned w, fl::WaveOp op, bool with_refs = false)
+inline int chosen_waves(unsigned type_bits, unsigned w, fl::WaveOp op)
 {
     const int p = g_kernel_policy.load(std::memory_order_relaxed);
-    int table = fl::wave_policy(type_bits, w, op);
-    // the one exception to the generated table (fl_dispatch.hpp: u8_two_blocks_in_flight)
-    if ((op == fl::WAVE_PACK || op == fl::WAVE_UNPACK) && fl::u8_two_blocks_in_flight(type_bits, w, op == fl::WAVE_PACK, with_refs))
-        table = 8;
+    const int table = fl::wave_policy(type_bits, w, op);
     const bool per_type = op == fl::WAVE_UNDELTA || op == fl::WAVE_DELTA || op == fl::WAVE_TRANSPOSE || op == fl::WAVE_UNTRANSPOSE;
     if ((p & 0xff) == 1) return (per_type || fl::cell_column_built(type_bits, w, op)) ? 0 : table;
     if ((p & 0xff) != 2) return table;
     if ((p >> 8) & 0xff) return (p >> 8) & 0xff;     // A/B tools: policy 2 + 256 * waves forces the occupancy too
-    return table ? table : fl::wave_fallback(type_bits, op == fl::WAVE_PACK || op == fl::WAVE_TRANSPOSE_DELTA_PACK);
+    return table ? table : fl::wave_fallback(type_bits, op == fl::WAVE_PACK || op == fl::WAVE_FOR_PACK || op == fl::WAVE_TRANSPOSE_DELTA_PACK);
 }
 
 
@@ -202,7 +199,7 @@ template <typename T>
 int dev_for_pack(unsigned w, const T* in, const T* refs, size_t stride, T* out, size_t n, void* s)
 {
     if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
-    if (const int waves = chosen_waves(Elem<T>::BITS, w, WAVE_PACK, true)) {
+    if (const int waves = chosen_waves(Elem<T>::BITS, w, WAVE_FOR_PACK)) {
         if (n && (!in || !refs)) return FL_ERR_NULL;
         return run_wave_uniform<T>(true, waves, w, out, const_cast<T*>(in), refs, stride, n, s);
     }
@@ -212,7 +209,7 @@ template <typename T>
 int dev_unfor_pack(unsigned w, const T* in, const T* refs, size_t stride, T* out, size_t n, void* s)
 {
     if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
-    if (const int waves = chosen_waves(Elem<T>::BITS, w, WAVE_UNPACK, true)) {
+    if (const int waves = chosen_waves(Elem<T>::BITS, w, WAVE_UNFOR_PACK)) {
         if (n && !refs) return FL_ERR_NULL;
         return run_wave_uniform<T>(false, waves, w, in, out, refs, stride, n, s);
     }
@@ -370,6 +367,10 @@ __global__ void k_host_done(uint64_t* flag, uint64_t seq)
     __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// zero-copy calls whose completion word did not arrive within the spin's bound (each cost a 50 ms stall and a real synchronise):
+// fl_internal_zero_copy_fallbacks() -- a 50-ms-per-call cliff must not be silent
+std::atomic<uint64_t> g_zero_copy_fallbacks{0};
+
 struct HostCtx {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -423,7 +424,10 @@ struct HostCtx {
             if ((spins & 0xffffu) == 0xffffu) {                   // every 65 536 polls (some tens of us): look at the clock
                 const auto now = std::chrono::steady_clock::now();
                 if (spins == 0xffffu) t0 = now;
-                else if (now - t0 > std::chrono::milliseconds(50)) return hipStreamSynchronize(stream);
+                else if (now - t0 > std::chrono::milliseconds(50)) {                  // never seen in a healthy run: make it visible
+                    g_zero_copy_fallbacks.fetch_add(1, std::memory_order_relaxed);
+                    return hipStreamSynchronize(stream);
+                }
             }
         }
     }
@@ -438,7 +442,9 @@ struct HostCtx {
         e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
         if (e != hipSuccess) { stream = nullptr; return e; }
         device = cur;
-        if (hipHostMalloc(reinterpret_cast<void**>(&done), 64, hipHostMallocDefault) == hipSuccess) *done = 0;
+        // fine-grained (coherent) and mapped, explicitly: the host must SEE the marker's system-scope store without a synchronising
+        // call, which hipHostMallocDefault only implies
+        if (hipHostMalloc(reinterpret_cast<void**>(&done), 64, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess) *done = 0;
         else { done = nullptr; (void)hipGetLastError(); }          // no marker word: wait_zero_copy() synchronises the stream instead
         seq = 0;
         return hipSuccess;
@@ -453,7 +459,7 @@ struct HostCtx {
             (void)hipHostFree(pin); pin = nullptr; pin_cap = 0;
         }
         const size_t cap = grown(bytes, pin_cap < 65536 ? 65536 : pin_cap);
-        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&pin), cap, hipHostMallocDefault);
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&pin), cap, hipHostMallocCoherent | hipHostMallocMapped);   // see `done`
         if (e == hipSuccess) pin_cap = cap; else pin = nullptr;
         return e;
     }
@@ -598,7 +604,7 @@ int run_chain_widths(int op, const uint8_t* widths, const uint64_t* offsets, con
     if (n_blocks == 0) return FL_OK;
     if (!widths || !offsets) return FL_ERR_NULL;
     int waves = mixed_waves(Elem<T>::BITS, op == OP_TRANSPOSE_DELTA_PACK);
-    if (sizeof(T) == 1 && op != OP_TRANSPOSE_DELTA_PACK) waves = 0;       // u8's decode is the persistent pipelined kernel: 0 = its own grid
+    if (sizeof(T) == 1) waves = 0;   // u8 runs the persistent pipelined kernels: 0 = their own grid
     const int pol = g_kernel_policy.load(std::memory_order_relaxed);       // A/B tools: 2 + 256 * waves
     if ((pol & 0xff) == 2 && ((pol >> 8) & 0xff)) waves = (pol >> 8) & 0xff;
     const int rc = run_chain<T>(op, waves, 0, in, bases, out, n_blocks, stream, widths, offsets, packed_bytes, err_flag);
@@ -932,11 +938,12 @@ int fl_internal_probe_memory_classes(void* slab, size_t slab_bytes, int* classes
             hipError_t h = hipEventRecord(t0, s);
             if (h != hipSuccess) return hip_fail(h);
             // under the whole-column tile map the class map was characterised with (a windowed read stream interferes less with the
-            // thin write stream, which is the point of the window and blunts the probe): process-wide override, restored at once --
-            // this is measurement tooling, synchronous by contract
-            const int saved = fl::window_override().exchange(fl::WINDOW_WHOLE, std::memory_order_relaxed);
+            // thin write stream, which is the point of the window and blunts the probe): an override for THIS THREAD's launches only --
+            // concurrent calls of other threads keep their own tile maps, and a concurrent fl_internal_set_kernel_policy is untouched
+            const int saved = fl::window_override_this_thread();
+            fl::window_override_this_thread() = fl::WINDOW_WHOLE;
             const int r = fl_u32_unpack_compare(PROBE_WIDTH, src, FL_CMP_LT, 1u << (PROBE_WIDTH - 1), PROBE_BLOCKS, mask, s);
-            fl::window_override().store(saved, std::memory_order_relaxed);
+            fl::window_override_this_thread() = saved;
             if (r != FL_OK) return r;
             h = hipEventRecord(t1, s);
             if (h == hipSuccess) h = hipEventSynchronize(t1);
@@ -1002,6 +1009,7 @@ void fl_internal_set_kernel_policy(int policy)
     fl::window_override().store(ok ? window : 0, std::memory_order_relaxed);
 }
 int fl_internal_get_kernel_policy(void) { return g_kernel_policy.load(std::memory_order_relaxed); }
+uint64_t fl_internal_zero_copy_fallbacks(void) { return g_zero_copy_fallbacks.load(std::memory_order_relaxed); }
 
 #ifdef FL_ALL_CELL_COLUMN
 const char* fl_version(void) { return "fastlanes_amd 0.4.0 (gfx950; wire format of spiraldb/fastlanes 0.1.8; FULL build: every cell-column instance, for A/B sweeps)"; }

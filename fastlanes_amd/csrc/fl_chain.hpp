@@ -132,50 +132,6 @@ template <typename T> __device__ __forceinline__ Cell<T> cell_from_group_below(c
     return __builtin_bit_cast(Cell<T>, r);
 }
 
-#ifdef FL_TEST_R03_REGISTER_SCAN
-// KNOWN-BAD, never built into libfastlanes_amd.so (make BADSCAN=1 -> libfastlanes_amd_badscan.so only): round 3's register-only
-// form of the lane-group scan (DPP + v_permlane16/32_swap instead of ds_bpermute).  It passed every per-(T, W) parity test and was
-// wrong on ~3 % of the blocks of a u64 undelta_pack, differently on every run, with all CUs busy (profiles/abscan_r03.txt), and was
-// dropped.  It is kept behind this macro for one purpose: to show that tests/test_gpu_full_check.py catches that class of error
-// (profiles/full_check_r04.txt).  The misbehaviour depends on instruction scheduling -- after this file was cut into stages the
-// same sequence stopped failing -- so the macro also plants a deterministic sparse fault (k_chain below).
-template <typename T> __device__ __forceinline__ Cell<T> scan_lane_groups_r03(Cell<T> v, unsigned lane)
-{
-    const bool odd_row = lane & 16u, upper_half = lane & 32u;
-    auto upper_group_to_both = [](const Cell<T>& x) {
-        u32x4 w = __builtin_bit_cast(u32x4, x), r;
-        for (int k = 0; k < 4; ++k) r[k] = (uint32_t)__builtin_amdgcn_update_dpp((int)w[k], (int)w[k], 0x108 /* row_shl:8 */, 0xF, 0xF, false);
-        return r;
-    };
-    {
-        const u32x4 w = __builtin_bit_cast(u32x4, v);
-        u32x4 below;
-        for (int k = 0; k < 4; ++k) below[k] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[k], 0x118 /* row_shr:8 */, 0xF, 0xF, true);
-        v = v.add(__builtin_bit_cast(Cell<T>, below));
-    }
-    {
-        const u32x4 t = upper_group_to_both(v);
-        u32x4 below;
-        for (int k = 0; k < 4; ++k) {
-            const auto sw = __builtin_amdgcn_permlane16_swap(t[k], t[k], false, false);
-            below[k] = odd_row ? (uint32_t)sw[0] : 0u;
-        }
-        v = v.add(__builtin_bit_cast(Cell<T>, below));
-    }
-    {
-        const u32x4 t = upper_group_to_both(v);
-        u32x4 below;
-        for (int k = 0; k < 4; ++k) {
-            const auto sw = __builtin_amdgcn_permlane16_swap(t[k], t[k], false, false);
-            const auto hf = __builtin_amdgcn_permlane32_swap(sw[1], sw[1], false, false);
-            below[k] = upper_half ? (uint32_t)hf[0] : 0u;
-        }
-        v = v.add(__builtin_bit_cast(Cell<T>, below));
-    }
-    return v;
-}
-#endif
-
 // n x n element tile: in[j] = cell of row j (n lanes), out[e] = cell of lane e (n rows)  -- and back (the map is an involution)
 template <typename T> __device__ __forceinline__ void tile_transpose(const Cell<T>* in, Cell<T>* out)
 {
@@ -333,16 +289,12 @@ __device__ __forceinline__ void chain_stage_rows(unsigned w, const char* lds, un
         // scan of the segment totals over the 8 lane groups (Hillis-Steele, 3 steps), base entering at segment 0
         if (i == 0) x[0] = x[0].add(base);
         static_for<R - 1>([&](auto J) { x[decltype(J)::value + 1] = x[decltype(J)::value + 1].add(x[decltype(J)::value]); });
-#ifdef FL_TEST_R03_REGISTER_SCAN
-        const Cell<T> excl = scan_lane_groups_r03<T>(x[R - 1], lane).sub(x[R - 1]);      // KNOWN-BAD test build only (see above)
-#else
         Cell<T> incl = x[R - 1];
         static_for<3>([&](auto S) {
             constexpr unsigned d = 1u << decltype(S)::value;
             incl = incl.add(cell_from_group_below<T>(incl, lane, d));
         });
         const Cell<T> excl = cell_from_group_below<T>(incl, lane, 1);
-#endif
         static_for<R>([&](auto J) { x[decltype(J)::value] = x[decltype(J)::value].add(excl); });
     }
 }
@@ -421,13 +373,6 @@ __device__ __forceinline__ void chain_one_block(const ChainArgs& a, uint64_t blk
     wave_lds_fence();
     Cell<T> x[R];
     chain_stage_rows<T, SRC, BODY>(w, lds, lane, base, x);
-#ifdef FL_TEST_R03_REGISTER_SCAN
-    // KNOWN-BAD test build only: a deterministic SPARSE fault on top of the (scheduling-dependent) register scan -- one wrong
-    // element in one of every 4 099 blocks of a u64 undelta chain.  Sampled checks miss it; the full check must not.
-    if constexpr (BODY == CHAIN_UNDELTA && sizeof(T) == 8) {
-        if (blk % 4099u == 4098u && lane == 13u) x[0].x[0] ^= 1u;   // first at block 4 098: beyond the small-size parity tests
-    }
-#endif
     if constexpr (FENCE_BEFORE_IMAGE) wave_lds_fence();
     chain_stage_image<T, SNK>(x, lds, lane);
     wave_lds_fence();
@@ -633,6 +578,52 @@ hipError_t launch_chain(const ChainArgs& a0, int waves, hipStream_t s)
 // Everything is an ordinary tracked load (no LDS-DMA): hipcc places the partial s_waitcnt vmcnt(N) of the loop-carried loads itself.
 // The loads of a block that is absent or fails a precondition go through an EMPTY descriptor (no traffic, zeros back; its stores
 // likewise), so the loop body is straight-line code.
+// ---- u8's transposition in REGISTERS --------------------------------------------------------------------------------------------
+// Along FL lane l's row order the original positions are consecutive (tau(index(r, l)) = lane_base(l) + r, transpose.rs:29-36): for
+// u8 the 8 rows of FL lane l = 16c + e are the 8 CONSECUTIVE BYTES at  e * 64 + FL_ORDER[c] * 8  of the original-order block.  A lane
+// that owns cell column c (FL lanes 16c .. 16c+15) for all 8 rows therefore needs sixteen 8-byte reads (ds_read_b64) instead of 128
+// single-byte ones, and a 16 x 8 byte transpose in registers: eight 4 x 4 byte tiles, 8 v_perm_b32 each.
+// The original-order image of block j sits at j * ORIGINAL_U8_STRIDE: 64 bytes of padding per image, so that the 8 lane groups of a
+// wavefront (8 blocks, every group reading one 64-byte span per instruction) spread over the banks instead of piling onto 16 of them.
+constexpr unsigned ORIGINAL_U8_STRIDE = 1024 + 64;
+
+// 4 x 4 byte transpose (an involution): a[i] = 4 bytes of thing i  ->  o[j] = byte j of things 0..3
+__device__ __forceinline__ void transpose4x4_bytes(const uint32_t* a, uint32_t* o)
+{
+    const uint32_t t0 = __builtin_amdgcn_perm(a[1], a[0], 0x05010400u);      // a0.b0 a1.b0 a0.b1 a1.b1
+    const uint32_t t1 = __builtin_amdgcn_perm(a[1], a[0], 0x07030602u);      // a0.b2 a1.b2 a0.b3 a1.b3
+    const uint32_t u0 = __builtin_amdgcn_perm(a[3], a[2], 0x05010400u);
+    const uint32_t u1 = __builtin_amdgcn_perm(a[3], a[2], 0x07030602u);
+    o[0] = __builtin_amdgcn_perm(u0, t0, 0x05040100u);                       // a0.b0 a1.b0 a2.b0 a3.b0
+    o[1] = __builtin_amdgcn_perm(u0, t0, 0x07060302u);
+    o[2] = __builtin_amdgcn_perm(u1, t1, 0x05040100u);
+    o[3] = __builtin_amdgcn_perm(u1, t1, 0x07060302u);
+}
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+// runs[e] = the 8 rows of FL lane 16c+e (8 bytes)  <->  rows[r] = the cell of row r (16 FL lanes); the map is its own inverse
+__device__ __forceinline__ void runs_to_rows_u8(const u32x2_t* runs, Cell<uint8_t>* rows)
+{
+    for (int k = 0; k < 4; ++k)
+        for (int h = 0; h < 2; ++h) {
+            uint32_t a[4], o[4];
+            for (int i = 0; i < 4; ++i) a[i] = runs[4 * k + i][h];
+            transpose4x4_bytes(a, o);
+            for (int j = 0; j < 4; ++j) rows[4 * h + j].x[k] = o[j];
+        }
+}
+__device__ __forceinline__ void rows_to_runs_u8(const Cell<uint8_t>* rows, u32x2_t* runs)
+{
+    for (int k = 0; k < 4; ++k)
+        for (int h = 0; h < 2; ++h) {
+            uint32_t a[4], o[4];
+            for (int j = 0; j < 4; ++j) a[j] = rows[4 * h + j].x[k];
+            transpose4x4_bytes(a, o);
+            for (int i = 0; i < 4; ++i) runs[4 * k + i][h] = o[i];
+        }
+}
+// byte offset of this lane's first run inside an original-order image (lane = 8j + c): FL_ORDER[c] * 8; run e is 64 * e further
+__device__ __forceinline__ unsigned first_run_of_column(unsigned c) { return ((0x73516240u >> (4u * c)) & 7u) * 8u; }
+
 template <typename T> struct ColumnTile {
     u32x4 p[COLUMN_LANES_BPW][WaveBlock<T>::GROUPS];        // block j, packed KiB g: this lane's 16 bytes
     Cell<T> base;                                           // base[lane] of this lane's cell column (delta.rs:56)
@@ -719,19 +710,36 @@ __device__ __forceinline__ void columns_consume(const ChainArgs& a, const Column
         const Cell<T> nxt = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(img + a1));
         x[r] = sum.step(cur, nxt, sh, m);
     });
-    // in place: a lane only ever touches its own column of its own block (rows of an absent block are never stored)
-    static_for<TB>([&](auto R) {
-        constexpr unsigned r = decltype(R)::value;
-        *reinterpret_cast<u32x4*>(img + Elem<T>::row_cell(r) * 16) = __builtin_bit_cast(u32x4, x[r]);
-    });
-    wave_lds_fence();
     // ONE descriptor over the tile's 8 consecutive unpacked blocks; a block that is not decoded keeps its bytes: its stores go out of range
     const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(a.out + d.first * G::BLOCK_BYTES, 0, d.count * G::BLOCK_BYTES, 0x00020000);
-    static_for<BPW>([&](auto Jt) {
-        constexpr unsigned j = decltype(Jt)::value;
-        const bool ok = (d.okmask >> j) & 1u;               // wave-uniform
-        chain_stage_out_unpacked<T, SNK>(out_rs, lds + j * IMG, lane, ok ? lane * 16u + j * G::BLOCK_BYTES : 0xfffff000u);
-    });
+    if constexpr (SNK == SNK_ORIGINAL && sizeof(T) == 1) {
+        // original order (transpose.rs:19-21) by a register transpose: this lane's 16 FL lanes' runs of 8 rows, 8 bytes each, into a
+        // (padded) original-order image -- the packed images are dead once every lane holds its rows
+        u32x2_t runs[16];
+        rows_to_runs_u8(x, runs);
+        wave_lds_fence();
+        char* at = lds + jm * ORIGINAL_U8_STRIDE + first_run_of_column(lane & 7u);
+        static_for<16>([&](auto E) { *reinterpret_cast<u32x2_t*>(at + 64 * decltype(E)::value) = runs[decltype(E)::value]; });
+        wave_lds_fence();
+        static_for<BPW>([&](auto Jt) {
+            constexpr unsigned j = decltype(Jt)::value;
+            const bool ok = (d.okmask >> j) & 1u;           // wave-uniform
+            const u32x4 v = *reinterpret_cast<const u32x4*>(lds + j * ORIGINAL_U8_STRIDE + lane * 16u);
+            __builtin_amdgcn_raw_buffer_store_b128(v, out_rs, ok ? lane * 16u + j * G::BLOCK_BYTES : 0xfffff000u, 0, STORE_AUX);
+        });
+    } else {
+        // in place: a lane only ever touches its own column of its own block (rows of an absent block are never stored)
+        static_for<TB>([&](auto R) {
+            constexpr unsigned r = decltype(R)::value;
+            *reinterpret_cast<u32x4*>(img + Elem<T>::row_cell(r) * 16) = __builtin_bit_cast(u32x4, x[r]);
+        });
+        wave_lds_fence();
+        static_for<BPW>([&](auto Jt) {
+            constexpr unsigned j = decltype(Jt)::value;
+            const bool ok = (d.okmask >> j) & 1u;           // wave-uniform
+            chain_stage_out_unpacked<T, SNK>(out_rs, lds + j * IMG, lane, ok ? lane * 16u + j * G::BLOCK_BYTES : 0xfffff000u);
+        });
+    }
     wave_lds_fence();
 }
 
@@ -798,7 +806,7 @@ hipError_t launch_chain_columns_pipelined(const ChainArgs& a0, int waves, hipStr
     if (a.tiles_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;
     a.window_shift = tile_window_shift(SNK == SNK_ORIGINAL ? WIN_UNDELTA_PACK_UNTRANSPOSE : WIN_UNDELTA_PACK, WaveBlock<T>::TB, TILE_BLOCKS);
     if (a.widths) a.window_shift |= TILE_MAP_ROTATE;
-    const unsigned lds = TILE_BLOCKS * WaveBlock<T>::BLOCK_BYTES;
+    const unsigned lds = TILE_BLOCKS * (SNK == SNK_ORIGINAL && sizeof(T) == 1 ? ORIGINAL_U8_STRIDE : WaveBlock<T>::BLOCK_BYTES);
     unsigned grid = (unsigned)(a.tiles_per_xcd * 8);
     int per_cu = per_cu_override, fit = 0, cus = 0, dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -809,6 +817,202 @@ hipError_t launch_chain_columns_pipelined(const ChainArgs& a0, int waves, hipStr
     const uint64_t resident = ((uint64_t)cus * (unsigned)per_cu + 7) / 8 * 8;          // a multiple of 8: a workgroup stays on its XCD
     if (resident >= 8 && resident < grid) grid = (unsigned)resident;
     FL_LAUNCH((k_chain_columns_pipelined<T, SNK>), dim3(grid), dim3(64), lds, s, a);
+    return hipGetLastError();
+}
+
+// ---- the ENCODE side on column lanes: transpose_delta_pack over a mixed-width u8 column, pipelined (round 5) ----------------------
+//     pack::<widths[b]>(delta(transpose(block b), bases[b]))        (delta.rs:88-95 composed, per block)
+// The lockstep kernel gathers the transposition byte by byte through LDS (1024 ds_read_u8 per block), takes the previous row from the
+// lane group below by ds_bpermute and packs a block at a time with LDS atomics: LDS busy 0.55, 0.66-0.70 of the HBM peak
+// (profiles/r05_sq_mixed_lockstep.txt).  Here, as in the decode kernel above, lane (j, c) owns cell column c of block first+j for all
+// 8 rows: sixteen 8-byte reads + a register transpose give it its rows (runs_to_rows_u8), the row before is its own register, and
+// the fields go into a per-lane bit buffer -- SPLIT like the decode's running sum: even and odd bytes in the 16-bit halves of two
+// registers per word, where `(delta & mask) << fill` cannot run into a neighbouring element and a subtraction is one v_pk_sub_u16
+// -- that emits one packed cell (word k of 16 FL lanes, macros.rs:84-92) whenever 8 bits are full.  The wavefront is persistent and
+// software-pipelined exactly like the decode kernel: tile k+2's widths / offsets and tile k+1's values + bases in flight while tile k
+// is encoded.
+template <typename T> struct EncodeTile {
+    u32x4 p[COLUMN_LANES_BPW][WaveBlock<T>::GROUPS];        // block j, original-order KiB g: this lane's 16 bytes
+    Cell<T> base;
+    unsigned wm;                                            // this lane's block's width (0 if the block is not encoded)
+    unsigned wv;                                            // lane j: block first+j's width, 0 if it is not encoded
+    uint64_t ov;                                            // lane j: its byte offset in the packed column
+    uint64_t first;
+};
+
+template <typename T>
+__device__ __forceinline__ void encode_issue(const ChainArgs& a, uint64_t first, unsigned count, const ColumnMeta& meta, unsigned lane,
+                                             EncodeTile<T>& d, uint32_t& lane_errors)
+{
+    using G = WaveBlock<T>;
+    constexpr unsigned BPW = COLUMN_LANES_BPW;
+    const bool mixed = a.widths != nullptr;                 // wave-uniform
+    const unsigned jm = lane >> 3;
+    unsigned wv = a.width;
+    uint64_t ov = (first + lane) * (uint64_t)(128u * a.width);
+    uint32_t e = 0;
+    if (mixed) {                                            // lane j checks block first+j (bitpacking.rs:93, :78-80), vector code
+        wv = meta.wv;
+        ov = meta.ov;
+        const uint32_t misaligned = (ov & 15u) ? DEVERR_ALIGN : 0u;
+        const uint32_t outside = (ov > a.packed_bytes || 128ull * wv > a.packed_bytes - ov) ? DEVERR_BOUNDS : 0u;
+        e = wv > (unsigned)G::TB ? DEVERR_WIDTH : (misaligned | outside);
+    }
+    const bool mine = lane < count;
+    e = mine ? e : 0u;
+    lane_errors |= e;
+    const bool okl = mine && e == 0;
+    d.wv = okl ? wv : 0u;                                   // W == 0 writes nothing (macros.rs:52-53), like a block that is skipped
+    d.ov = okl ? ov : 0ull;
+    d.first = first;
+    // the tile's 8 unpacked blocks are consecutive: one descriptor, 8 KiB, whatever the blocks' widths
+    const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.in) + first * G::BLOCK_BYTES, 0, count * G::BLOCK_BYTES, 0x00020000);
+    static_for<BPW>([&](auto Jt) {
+        constexpr unsigned j = decltype(Jt)::value;
+        static_for<G::GROUPS>([&](auto Gi) {
+            constexpr unsigned g = decltype(Gi)::value;
+            d.p[j][g] = __builtin_amdgcn_raw_buffer_load_b128(in_rs, lane * 16u + j * G::BLOCK_BYTES + g * 1024u, 0, 2 /* nt */);
+        });
+    });
+    d.wm = (unsigned)__builtin_amdgcn_ds_bpermute((int)(jm * 4u), (int)d.wv);
+    const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.bases) + first * 128u, 0, count * 128u, 0x00020000);
+    d.base = __builtin_bit_cast(Cell<T>, __builtin_amdgcn_raw_buffer_load_b128(b_rs, lane * 16u, 0, 0));
+}
+
+__device__ __forceinline__ uint32_t pk_sub_u16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b)));
+}
+
+__device__ __forceinline__ void encode_consume_u8(const ChainArgs& a, const EncodeTile<uint8_t>& d, char* lds, unsigned lane)
+{
+    using T = uint8_t;
+    using G = WaveBlock<T>;
+    constexpr unsigned BPW = COLUMN_LANES_BPW, IMG = ORIGINAL_U8_STRIDE;
+    const unsigned jm = lane >> 3, c16 = (lane & 7u) * 16u;
+    static_for<BPW>([&](auto Jt) { *reinterpret_cast<u32x4*>(lds + decltype(Jt)::value * IMG + lane * 16u) = d.p[decltype(Jt)::value][0]; });
+    wave_lds_fence();
+    // transpose.rs:12-14: this lane's 16 FL lanes' runs of 8 rows -> the 8 rows' cells
+    u32x2_t runs[16];
+    const char* at = lds + jm * IMG + first_run_of_column(lane & 7u);
+    static_for<16>([&](auto E) { runs[decltype(E)::value] = *reinterpret_cast<const u32x2_t*>(at + 64 * decltype(E)::value); });
+    Cell<T> x[8];
+    runs_to_rows_u8(runs, x);
+    wave_lds_fence();                                       // every lane holds its rows: the images may be overwritten with packed cells
+    // delta.rs:28-30 and macros.rs:72-92 per FL lane, in split form: ev / od = the even / odd bytes of a cell in the low bytes of u16x2
+    const unsigned wm = d.wm;
+    const uint32_t m = G::field_mask(wm);                   // (2^w - 1) in both halves; 0 for W == 0
+    uint32_t pe[4], po[4], ae[4], ao[4];
+    for (int k = 0; k < 4; ++k) { pe[k] = d.base.x[k]; po[k] = d.base.x[k] >> 8; ae[k] = 0; ao[k] = 0; }
+    unsigned fill = 0;
+    char* out_at = lds + jm * IMG + c16;                    // packed cell (word k, column c) of this lane's block: + 128 * k
+    static_for<8>([&](auto R) {
+        constexpr unsigned r = decltype(R)::value;
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t ce = x[r].x[k], co = x[r].x[k] >> 8;
+            const uint32_t de = pk_sub_u16(ce, pe[k]) & m, dd = pk_sub_u16(co, po[k]) & m;     // in[idx] - prev, masked to W bits (macros.rs:73)
+            pe[k] = ce;
+            po[k] = co;
+            ae[k] |= de << fill;                            // fill + W <= 15: stays inside the 16-bit half
+            ao[k] |= dd << fill;
+        }
+        fill += wm;
+        if (fill >= 8u) {                                   // a word of this lane's 16 streams is complete (macros.rs:84-92)
+            u32x4 cell;
+            for (int k = 0; k < 4; ++k) {
+                cell[k] = __builtin_amdgcn_perm(ao[k], ae[k], 0x06020400u);                    // od.b2 : ev.b2 : od.b0 : ev.b0
+                ae[k] = (ae[k] >> 8) & 0x00ff00ffu;
+                ao[k] = (ao[k] >> 8) & 0x00ff00ffu;
+            }
+            *reinterpret_cast<u32x4*>(out_at) = cell;
+            out_at += 128;
+            fill -= 8u;
+        }
+    });
+    wave_lds_fence();
+    // block j's 128 * w bytes leave 1 KiB-contiguously through a descriptor that ends where the block ends (nothing for W == 0 / a skipped block)
+    static_for<BPW>([&](auto Jt) {
+        constexpr unsigned j = decltype(Jt)::value;
+        const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)d.wv, (int)j);
+        const uint64_t packed_at = readlane_elem<uint64_t>(d.ov, j);
+        const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(a.out + packed_at, 0, 128u * w, 0x00020000);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(lds + j * IMG + lane * 16u);
+        __builtin_amdgcn_raw_buffer_store_b128(v, out_rs, lane * 16u, 0, STORE_AUX);
+    });
+    wave_lds_fence();
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_chain_columns_encode_pipelined(ChainArgs a)
+{
+    static_assert(sizeof(T) == 1, "the register transpose and the split bit buffer are u8's");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr unsigned BPW = COLUMN_LANES_BPW;
+    const unsigned tiles_per_xcd = (unsigned)a.tiles_per_xcd;                 // the launcher keeps 8 * tiles_per_xcd below 2^31
+    const unsigned slots = tiles_per_xcd * 8, grid = gridDim.x;
+    const unsigned n_tiles = (unsigned)((a.n_blocks + BPW - 1) / BPW);
+    const unsigned lane = threadIdx.x;
+    auto blocks_of = [&](unsigned t, uint64_t& first, unsigned& count) {      // slot t of the tile map; count = 0: nothing there
+        const unsigned tile = t < slots ? xcd_tile<uint32_t>(t, tiles_per_xcd, a.window_shift) : n_tiles;
+        const bool there = tile < n_tiles;
+        first = there ? (uint64_t)tile * BPW : 0;
+        const uint64_t left = a.n_blocks - first;
+        count = there ? (left < BPW ? (unsigned)left : BPW) : 0u;
+    };
+    uint32_t lane_errors = 0;
+    unsigned t1 = blockIdx.x + grid;
+    uint64_t first0, first1;
+    unsigned count0, count1;
+    blocks_of(blockIdx.x, first0, count0);
+    blocks_of(t1, first1, count1);
+    const ColumnMeta m0 = columns_meta_load(a, first0, count0, lane);
+    ColumnMeta m1 = columns_meta_load(a, first1, count1, lane);
+    EncodeTile<T> cur;
+    encode_issue<T>(a, first0, count0, m0, lane, cur, lane_errors);
+    for (;;) {
+        const unsigned t2 = t1 + grid;
+        uint64_t first2;
+        unsigned count2;
+        blocks_of(t2, first2, count2);
+        const ColumnMeta m2 = columns_meta_load(a, first2, count2, lane);      // tile k+2's metadata
+        EncodeTile<T> nxt;
+        encode_issue<T>(a, first1, count1, m1, lane, nxt, lane_errors);        // tile k+1's values and bases
+        encode_consume_u8(a, cur, lds, lane);                                  // tile k
+        if (t1 >= slots) break;
+        cur = nxt;
+        m1 = m2;
+        first1 = first2;
+        count1 = count2;
+        t1 = t2;
+    }
+    if (__builtin_amdgcn_ballot_w64(lane_errors != 0)) {
+        for (int o = 32; o; o >>= 1) lane_errors |= (uint32_t)__shfl_xor((int)lane_errors, o);
+        raise_device_error(a.err_flag, lane_errors, lane);
+    }
+}
+
+template <typename T>
+hipError_t launch_chain_columns_encode_pipelined(const ChainArgs& a0, int waves, hipStream_t s)
+{
+    if (a0.n_blocks == 0) return hipSuccess;
+    ChainArgs a = a0;
+    constexpr unsigned TILE_BLOCKS = COLUMN_LANES_BPW;
+    const uint64_t n_tiles = (a.n_blocks + TILE_BLOCKS - 1) / TILE_BLOCKS;
+    a.tiles_per_xcd = (n_tiles + 7) / 8;
+    if (a.tiles_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;
+    a.window_shift = tile_window_shift(WIN_TRANSPOSE_DELTA_PACK, WaveBlock<T>::TB, TILE_BLOCKS);
+    if (a.widths) a.window_shift |= TILE_MAP_ROTATE;
+    const unsigned lds = TILE_BLOCKS * ORIGINAL_U8_STRIDE;
+    unsigned grid = (unsigned)(a.tiles_per_xcd * 8);
+    int per_cu = waves > 0 ? 4 * waves : COLUMNS_WAVES_PER_CU, fit = 0, cus = 0, dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_chain_columns_encode_pipelined<T>, 64, lds);
+    if (e != hipSuccess) return e;
+    if (fit > 0 && per_cu > fit) per_cu = fit;
+    const uint64_t resident = ((uint64_t)cus * (unsigned)per_cu + 7) / 8 * 8;
+    if (resident >= 8 && resident < grid) grid = (unsigned)resident;
+    FL_LAUNCH((k_chain_columns_encode_pipelined<T>), dim3(grid), dim3(64), lds, s, a);
     return hipGetLastError();
 }
 

@@ -82,6 +82,7 @@ template <> chain_launch_t chain_widths_launcher<T>(int op)
     if constexpr (sizeof(T) == 1) {                         // u8's decode: column lanes, pipelined (fl_chain.hpp)
         if (op == OP_UNDELTA_PACK) return &launch_chain_columns_pipelined<T, SNK_ROWS>;
         if (op == OP_UNDELTA_PACK_UNTRANSPOSE) return &launch_chain_columns_pipelined<T, SNK_ORIGINAL>;
+        if (op == OP_TRANSPOSE_DELTA_PACK) return &launch_chain_columns_encode_pipelined<T>;
     }
     switch (op) {
     case OP_UNDELTA_PACK: return &launch_chain<T, SRC_PACKED, CHAIN_UNDELTA, SNK_ROWS, RD_VGPR, B>;

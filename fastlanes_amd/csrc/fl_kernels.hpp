@@ -77,10 +77,17 @@ inline std::atomic<int>& window_override()
     static std::atomic<int> v{0};
     return v;
 }
+// the same for the calling thread's launches only (the memory-class probe of fl_capi.hip); wins over the process-wide one
+inline int& window_override_this_thread()
+{
+    static thread_local int v = 0;
+    return v;
+}
 // window_shift of a launch: the (op, type)'s window from the generated table (or the override) in blocks -> tiles of `tile_blocks` blocks
 inline unsigned tile_window_shift(WindowOp op, unsigned type_bits, unsigned tile_blocks)
 {
-    const int ov = window_override().load(std::memory_order_relaxed);
+    const int mine = window_override_this_thread();
+    const int ov = mine ? mine : window_override().load(std::memory_order_relaxed);
     const int lg = ov ? ov : window_log2_blocks(op, type_bits);
     if (lg >= WINDOW_WHOLE) return 63u;
     int tl = 0;
@@ -419,9 +426,10 @@ template <typename T> struct WidthTable { stream_launch_t fn[Elem<T>::BITS + 1];
 // the other entries are nullptr and the C ABI serves those widths with the runtime-width wave-per-block kernels.
 constexpr WaveOp wave_op_of_body(int body)
 {
-    return body == BODY_UNDELTA ? WAVE_UNDELTA_PACK : body == BODY_UNDELTA_UNTRANSPOSE ? WAVE_UNDELTA_PACK_UNTRANSPOSE : WAVE_UNPACK;
+    return body == BODY_UNDELTA ? WAVE_UNDELTA_PACK : body == BODY_UNDELTA_UNTRANSPOSE ? WAVE_UNDELTA_PACK_UNTRANSPOSE
+         : body == BODY_ADD_REF ? WAVE_UNFOR_PACK : WAVE_UNPACK;
 }
-constexpr WaveOp wave_op_of_mode(int mode) { return mode == PACK_TRANSPOSE_DELTA ? WAVE_TRANSPOSE_DELTA_PACK : WAVE_PACK; }
+constexpr WaveOp wave_op_of_mode(int mode) { return mode == PACK_TRANSPOSE_DELTA ? WAVE_TRANSPOSE_DELTA_PACK : mode == PACK_FOR ? WAVE_FOR_PACK : WAVE_PACK; }
 
 template <typename T, int W, int BODY> constexpr stream_launch_t unpack_entry()
 {

@@ -106,8 +106,11 @@ inline hipError_t launch_widths_to_offsets(const ScanArgs& a, hipStream_t s)
         return hipSuccess;
     }
     const unsigned n_chunks = (unsigned)((a.n_blocks + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    // three launches: FL_LAUNCH clears the error slot before each, so each one's status is read before the next
     FL_LAUNCH(k_scan_local, dim3(n_chunks), dim3(WG), 0, s, a);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     FL_LAUNCH(k_scan_chunks, dim3(1), dim3(WG), 0, s, a);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     FL_LAUNCH(k_scan_add, dim3(n_chunks), dim3(WG), 0, s, a);
     return hipGetLastError();
 }

@@ -349,6 +349,35 @@ private:
     fl_mixed_plan* plan_ = nullptr;
 };
 
+// The optional allocation helper of fastlanes_amd.h as an owner: a (packed, unpacked) buffer pair for a column of `packed_len` /
+// `unpacked_len` ELEMENTS (either direction: in = what the op reads), placed by measurement by default (FL_LAYOUT_PROBE:
+// synchronous, contents unspecified afterwards).  Never needed to use the codec -- every call above takes any aligned pointers.
+template <typename T> class ColumnPair {
+public:
+    ColumnPair(std::size_t in_len, std::size_t out_len, std::size_t aux_len = 0, int layout = FL_LAYOUT_PROBE, void* stream = nullptr)
+    {
+        void *i = nullptr, *a = nullptr, *o = nullptr;
+        detail::check(fl_column_pair_alloc(in_len * sizeof(T), aux_len * sizeof(T), out_len * sizeof(T), layout, stream, &i, &a, &o, &handle_,
+                                           &layout_, probe_gbps_), "fl_column_pair_alloc");
+        in_ = DeviceSlice<T>(static_cast<T*>(i), in_len);
+        aux_ = DeviceSlice<T>(static_cast<T*>(a), aux_len);
+        out_ = DeviceSlice<T>(static_cast<T*>(o), out_len);
+    }
+    ~ColumnPair() { fl_column_pair_free(handle_); }
+    ColumnPair(const ColumnPair&) = delete;
+    ColumnPair& operator=(const ColumnPair&) = delete;
+    DeviceSlice<T> in() const { return in_; }
+    DeviceSlice<T> aux() const { return aux_; }
+    DeviceSlice<T> out() const { return out_; }
+    int layout() const { return layout_; }                                  // FL_LAYOUT_SEPARATE / FL_LAYOUT_ZONED: what was kept
+    std::uint32_t probe_gbps(int layout) const { return probe_gbps_[layout & 1]; }   // 0 = not measured
+private:
+    void* handle_ = nullptr;
+    DeviceSlice<T> in_, aux_, out_;
+    int layout_ = -1;
+    std::uint32_t probe_gbps_[2] = {0, 0};
+};
+
 // The same loop with the per-block widths / byte offsets already resident in HBM:
 // nothing is built on the host.  A block with a width > T, a misaligned offset or bytes outside [0, packed_bytes) is skipped and its
 // FL_DEVERR_* bit is ORed into *d_err_flag (device uint32, may be null).

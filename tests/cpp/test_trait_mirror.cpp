@@ -271,6 +271,18 @@ static void test_column_api()
         BitPacking<T>::unchecked_pack(W, v.data() + b * 1024, 1024, one.data(), PL);
         EXPECT(std::memcmp(one.data(), pk.data() + b * PL, PL * sizeof(T)) == 0);
     }
+    // the same round trip inside buffers from the optional allocation helper (fl_column_pair_alloc), every layout
+    for (int layout : {FL_LAYOUT_SEPARATE, FL_LAYOUT_ZONED, FL_LAYOUT_PROBE}) {
+        ColumnPair<T> pair(N * PL, N * 1024, 0, layout);
+        EXPECT(pair.in().len == N * PL && pair.out().len == N * 1024 && pair.aux().ptr == nullptr);
+        EXPECT(pair.layout() == FL_LAYOUT_SEPARATE || pair.layout() == FL_LAYOUT_ZONED);
+        EXPECT(layout == FL_LAYOUT_PROBE || pair.layout() == layout);
+        EXPECT(hipMemcpy(pair.in().ptr, dp.p, N * PL * sizeof(T), hipMemcpyDeviceToDevice) == hipSuccess);
+        unpack_column<T>(W, DeviceSlice<const T>(pair.in()), pair.out());
+        std::vector<T> back(N * 1024);
+        EXPECT(hipMemcpy(back.data(), pair.out().ptr, back.size() * sizeof(T), hipMemcpyDeviceToHost) == hipSuccess);
+        EXPECT(back == v);
+    }
     // fused Delta / FoR decode of the column == the per-block trait calls
     undelta_pack_column<T>(W, sp, cb, su);
     std::vector<T> got = du.down();

@@ -32,7 +32,7 @@ def test_table_shape():
     text, *_ = _inputs()
     rows = dict((m.group(1), [int(x) for x in m.group(3).split(",")])
                 for m in re.finditer(r"constexpr unsigned char (\w+)\[(\d+)\] = \{([^}]*)\};", text))
-    for op in ("UNPACK", "PACK", "UNDELTA_PACK", "UNDELTA_PACK_UNTRANSPOSE", "TRANSPOSE_DELTA_PACK"):
+    for op in ("UNPACK", "PACK", "UNFOR_PACK", "FOR_PACK", "UNDELTA_PACK", "UNDELTA_PACK_UNTRANSPOSE", "TRANSPOSE_DELTA_PACK"):
         for T in (8, 16, 32, 64):
             assert len(rows[f"{op}_U{T}"]) == T + 1
     for op in ("UNDELTA", "DELTA", "UNTRANSPOSE", "TRANSPOSE"):

@@ -1869,3 +1869,42 @@ def test_column_pair_alloc_and_the_bare_stream(fl, oracle):
     assert lib.fl_internal_bare_stream(big.data_ptr(), 8192, None, 0, small.data_ptr(), 0, 1000, 1, 8, 31, None) == 0
     torch.cuda.synchronize()
     assert not small.any().item()
+
+
+def test_zero_copy_host_calls_under_load_never_fall_back(fl, oracle):
+    """The host tier's small calls are zero-copy and wait for a completion word in pinned memory instead of synchronising the
+    stream (fl_capi.hip: HostCtx::wait_zero_copy): with the chip kept busy by a device-tier stream, 1500 single-block trait calls per
+    type return exactly the oracle's bytes, and not one of them hit the 50 ms fallback (fl_internal_zero_copy_fallbacks)."""
+    import threading
+    import torch
+    lib = fl.load()
+    before = lib.fl_internal_zero_copy_fallbacks()
+    big_in = to_dev(values("u32", 400000 * packed_len("u32", 7), 9200))
+    big_out = torch.empty(400000 * 1024, dtype=torch.uint32, device="cuda:0")
+    stop = threading.Event()
+
+    def load():
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            while not stop.is_set():
+                fl.BitPacking.unpack(7, big_in, output=big_out)
+                s.synchronize()
+    t = threading.Thread(target=load)
+    t.start()
+    try:
+        for ty, w in (("u32", 7), ("u64", 17), ("u16", 3), ("u8", 5)):
+            pl = packed_len(ty, w)
+            v = values(ty, 1500 * 1024, 9201 + w)
+            for b in range(1500):
+                blk = v[b * 1024:(b + 1) * 1024]
+                pk = fl.BitPacking.pack(w, blk)
+                assert pk.shape[0] == pl
+                if b % 50 == 0:
+                    assert np.array_equal(pk, oracle.pack(ty, w, blk)), (ty, b)
+                back = fl.BitPacking.unpack(w, pk)
+                m = np.array((1 << w) - 1, dtype=np.uint64).astype(TYPES[ty][0])
+                assert np.array_equal(back, blk & m), (ty, b)
+    finally:
+        stop.set()
+        t.join()
+    assert lib.fl_internal_zero_copy_fallbacks() == before

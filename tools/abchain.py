@@ -38,7 +38,13 @@ for ty, W in cases:
     un = rand_u8(n * 1024 * esz, 1, dev).view(tdt)
     out = torch.empty(n * 1024, dtype=tdt, device=dev)
     bases = rand_u8(n * 128, 3, dev).view(tdt)
-    ops = {"undelta_pack": (lambda: fl.Delta.undelta_pack(W, pk, bases, output=out), n * (128 * W + 128 + 128 * T))}
+    refs = bases[:n]
+    ops = {}
+    if "--for" in sys.argv or ALL:      # FoR's bodies (rows of their own in the dispatch table since round 5)
+        pk_for = torch.empty_like(pk)
+        ops["unfor_pack"] = (lambda: fl.FoR.unfor_pack(W, pk, refs, output=out), n * (128 * W + 128 * T))
+        ops["for_pack"] = (lambda: fl.FoR.for_pack(W, un, refs, output=pk_for), n * (128 * W + 128 * T))
+    ops.update({"undelta_pack": (lambda: fl.Delta.undelta_pack(W, pk, bases, output=out), n * (128 * W + 128 + 128 * T))})
     if True:
         pk_out = torch.empty_like(pk)
         ops["undelta_pack_untr"] = (lambda: fl.Delta.undelta_pack_untranspose(W, pk, bases, output=out), n * (128 * W + 128 + 128 * T))
@@ -51,7 +57,7 @@ for ty, W in cases:
         ops["undelta"] = (lambda: fl.Delta.undelta(un, bases, output=out), n * (256 * T + 128))
         ops["delta"] = (lambda: fl.Delta.delta(un, bases, output=out), n * (256 * T + 128))
     for name, (f, nbytes) in ops.items():
-        res_t = pk_out if name == "transp_delta_pack" else out
+        res_t = pk_out if name == "transp_delta_pack" else pk_for if name == "for_pack" else out
         lib.fl_internal_set_kernel_policy(1)
         f()
         ref = res_t.clone()

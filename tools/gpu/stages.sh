@@ -44,6 +44,8 @@ for stage in "$@"; do
     timeout 1500 python tools/abwindow.py ${FL_WINDOW_CASES:+--cases $FL_WINDOW_CASES} 2>&1 | grep -v amdgpu.ids > $R/window_ab.txt; cat $R/window_ab.txt ;;
   window_matrix) # every row of fl_window_table.inc x every type: the input of tools/make_window_table.py (one file per box)
     timeout 1500 python tools/abwindow.py --cases matrix --windows 31,16 --gb 24 2>&1 | grep -v amdgpu.ids > $R/window_matrix.txt; cat $R/window_matrix.txt ;;
+  dispatch_sweeps) # one box's input of tools/make_dispatch.py (needs libfastlanes_amd_full.so)
+    bash tools/gpu/dispatch_sweeps.sh $R ;;
   bench)
     timeout 900 python bench.py > $R/bench_u32w7.json 2> $R/bench.err; echo "bench rc=$?"; cat $R/bench_u32w7.json ;;
   *) echo "unknown stage $stage" ;;

@@ -34,7 +34,9 @@ TYPES = (8, 16, 32, 64)
 # ops of the uniform sweep, ops of the chain sweep that depend on the width, and the per-type ones
 UNIFORM_OPS = ("unpack", "pack")
 CHAIN_W_OPS = {"undelta_pack": "undelta_pack", "undelta_pack_untr": "undelta_pack_untranspose",
-               "transp_delta_pack": "transpose_delta_pack"}
+               "transp_delta_pack": "transpose_delta_pack", "unfor_pack": "unfor_pack", "for_pack": "for_pack"}
+# FoR's rows (round 5): if NO chain file holds them (sweeps older than round 5) they follow unpack / pack, as the library did then
+FOR_FOLLOWS = {"unfor_pack": "unpack", "for_pack": "pack"}
 CHAIN_T_OPS = ("undelta", "delta", "untranspose", "transpose")
 
 NUM = r"\s+(\d+)"
@@ -106,13 +108,17 @@ def build(uniform_files, chain_files, margin):
                     row.append(decide(samples, margin))
             table[(op, T)] = row
     for op in CHAIN_W_OPS.values():
+        if op in FOR_FOLLOWS and not any(k[0] == op for b in boxes_c for k in b):
+            for T in TYPES:
+                table[(op, T)] = list(table[(FOR_FOLLOWS[op], T)])
+            continue
         for T in TYPES:
             row = []
             for W in range(T + 1):
                 samples = [b[(op, T, W)] for b in boxes_c if (op, T, W) in b]
                 if len(samples) != len(boxes_c) or not samples:
                     raise SystemExit(f"chain sweep lacks {op} u{T} W={W} on some box (run tools/abchain.py --all)")
-                row.append(WAVES[0] if (op == "transpose_delta_pack" and W == 0) else decide(samples, margin))
+                row.append(WAVES[0] if (op in ("transpose_delta_pack", "for_pack") and W == 0) else decide(samples, margin))
             table[(op, T)] = row
     for op in CHAIN_T_OPS:
         for T in TYPES:
