@@ -26,6 +26,9 @@ if ALL:
 if "--types" in sys.argv:          # e.g. --types u16,u8: re-sweep some element types only (round 4: the narrow types' chain kernels
     keep = sys.argv[sys.argv.index("--types") + 1].split(",")   # now keep several blocks in flight per wavefront)
     cases = [c for c in cases if c[0] in keep]
+if "--start-at" in sys.argv:       # e.g. --start-at u64:64: resume a sweep that died (order: u32, u64, u16, u8, widths ascending)
+    ty0, w0 = sys.argv[sys.argv.index("--start-at") + 1].split(":")
+    cases = cases[cases.index((ty0, int(w0))):]
 if "--gb" in sys.argv:             # bytes moved per launch; BASELINE's config 4 is a 57.6 GB launch
     GB = int(sys.argv[sys.argv.index("--gb") + 1])
 print("GB/s, median of %d; cc = cell-column, then wave-per-block at %s waves/SIMD" % (ROUNDS, " ".join(map(str, WAVES))))
@@ -79,4 +82,8 @@ for ty, W in cases:
         g = [nbytes / sorted(res[p])[len(res[p]) // 2] / 1e6 for p in pols]
         print(f"{ty:3s} W={W:<2d} {name:17s}{'' if same else ' MISMATCH'} | cc {g[0]:6.0f}  wpb " + " ".join(f"{x:6.0f}" for x in g[1:]), flush=True)
     lib.fl_internal_set_kernel_policy(0)
-    del pk, un, out, bases
+    # the lambdas in `ops` hold every buffer of the case: drop them with the buffers, or the caching allocator fragments until a
+    # 45-GB case no longer fits (round 5: both boxes died at u64 W=64)
+    del ops, f, pk, un, out, bases, refs
+    pk_out = pk_for = res_t = None
+    torch.cuda.empty_cache()

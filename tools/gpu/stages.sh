@@ -43,9 +43,12 @@ for stage in "$@"; do
   window_ab)    # the tile-map window per (op, T): whole-column map vs 2^16-block windows vs 8-GiB windows, same buffers
     timeout 1500 python tools/abwindow.py ${FL_WINDOW_CASES:+--cases $FL_WINDOW_CASES} 2>&1 | grep -v amdgpu.ids > $R/window_ab.txt; cat $R/window_ab.txt ;;
   window_matrix) # every row of fl_window_table.inc x every type: the input of tools/make_window_table.py (one file per box)
-    timeout 1500 python tools/abwindow.py --cases matrix --windows 31,16 --gb 24 2>&1 | grep -v amdgpu.ids > $R/window_matrix.txt; cat $R/window_matrix.txt ;;
+    timeout 1500 python tools/abwindow.py --cases matrix --windows 31,16 --gb ${FL_MATRIX_GB:-48} 2>&1 | grep -v amdgpu.ids > $R/window_matrix.txt; cat $R/window_matrix.txt ;;
   dispatch_sweeps) # one box's input of tools/make_dispatch.py (needs libfastlanes_amd_full.so)
     bash tools/gpu/dispatch_sweeps.sh $R ;;
+  chain_resume)  # the rest of a chain sweep that died: FL_CHAIN_START=u64:64 (round 5: the allocator fragmented at u64 W=64 on both boxes)
+    FL_LIB=$PWD/fastlanes_amd/libfastlanes_amd_full.so timeout 2400 python tools/abchain.py 3 --all --gb 45 --start-at ${FL_CHAIN_START:-u64:64} 2>&1 | grep -v amdgpu > $R/abchain_resume.txt
+    grep -c MISMATCH $R/abchain_resume.txt; tail -n 3 $R/abchain_resume.txt ;;
   bench)
     timeout 900 python bench.py > $R/bench_u32w7.json 2> $R/bench.err; echo "bench rc=$?"; cat $R/bench_u32w7.json ;;
   *) echo "unknown stage $stage" ;;
