@@ -24,6 +24,10 @@ def cp(src, dst):
 cp(os.path.join(G, "bench_u32w7.json"), f"{RD}_bench_u32w7.json")
 cp(os.path.join(G, "bench_other.jsonl"), f"{RD}_bench_other_workloads.jsonl")
 cp(os.path.join(G, "host_latency.txt"), f"{RD}_host_latency.txt")
+cp(os.path.join(G, "pmc_unpack_single.txt"), f"{RD}_pmc_unpack_single.txt")
+cp(os.path.join(G, "sq_mixed", "sq_derived.txt"), f"{RD}_sq_mixed_final.txt")
+cp(os.path.join(G, "full_check.txt"), f"{RD}_full_check.txt")
+cp(os.path.join(G, "full_check_badscan.txt"), f"{RD}_full_check_known_bad_build.txt")
 for src, dst in (("bench_8ranks_one_device.json", f"{RD}_bench_8ranks_one_device_gloo.json"),
                  ("bench_2ranks_gloo.json", f"{RD}_bench_2ranks_one_device_gloo.json"),
                  ("bench_2ranks_auto.json", f"{RD}_bench_2ranks_one_device_rccl_attempt.json")):

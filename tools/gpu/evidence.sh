@@ -26,6 +26,13 @@ for c in quick fused consume refbench mixed single; do timeout 900 python tools/
 timeout 2400 python tools/sweep.py --cases allwidths --gb 8 --reps 5 2>&1 | grep -v amdgpu.ids > $R/sweep_allwidths.txt
 timeout 600 python tools/sweep.py --cases batch --batch-all 2>&1 | grep -v amdgpu.ids > $R/sweep_batch.txt
 timeout 120 tools/host_latency > $R/host_latency.txt 2>&1
+timeout 600 python tools/pmc_single.py > $R/pmc_unpack_single.txt 2> $R/pmc_single.err; echo "pmc single rc=$?"
+bash tools/gpu/sq_counters.sh tools/pmc_probe_mixed_delta.py $R/sq_mixed > $R/sq_mixed.log 2>&1; echo "sq counters rc=$?"
+( time timeout 900 python -m pytest tests/test_gpu_full_check.py -m gpu -q ) > $R/full_check.txt 2>&1; echo "full check rc=$?"
+# ... and shown to FAIL on the known-bad build (make -C fastlanes_amd/csrc BADSCAN=1: a patched copy of the sources, tests/checker/make_badscan_sources.py)
+if [ -f fastlanes_amd/libfastlanes_amd_badscan.so ]; then
+  FL_LIB=$ROOT/fastlanes_amd/libfastlanes_amd_badscan.so timeout 600 python -m pytest tests/test_gpu_full_check.py -m gpu -q -k under_load 2>&1 | grep -E "^E +AssertionError|^FAILED|passed|failed" > $R/full_check_badscan.txt; echo "known-bad build: $(tail -n 1 $R/full_check_badscan.txt)"
+fi
 # N > 1 on this one device: 2 ranks, gloo control plane; then the same with the RCCL attempt (RCCL refuses two ranks on one
 # GPU: the fallback path on real hardware)
 timeout 600 python bench.py --gpus 2 --single-device --backend gloo --blocks 2000000 --steps 5 > $R/bench_2ranks_gloo.json 2> $R/bench_2ranks_gloo.err; echo "2 ranks gloo rc=$?"

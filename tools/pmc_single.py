@@ -69,14 +69,17 @@ def main():
     assert len(singles) == 2 * len(PATTERNS) * len(CASES), len(singles)
     print(f"# HBM bytes fetched per lookup of fl_<ty>_unpack_single ({K} lookups into a {N_BLOCKS}-block column; rocprofv3 --pmc FETCH_SIZE, KiB units, "
           f"x{factor:.3f} from a {CAL_BYTES >> 30}-GiB copy in the same pass).  Every lookup also reads its 8-byte index (sequentially) and needs 1-2 words "
-          "of T from the column (bitpacking.rs:164-178).")
+          "of T from the column (bitpacking.rs:164-178).  READING: the factor is what WIDE COALESCED reads need on gfx950 (the copy, the dense pattern); a scattered "
+          "lookup is one 64-byte request per word touched, and there the RAW counter is the plausible one: 8 B of index + 64 B x (1 + the share of fields that "
+          "straddle two words).")
     k = 0
     for ty, w in CASES:
         esz = {"u8": 1, "u16": 2, "u32": 4, "u64": 8}[ty]
         for p in PATTERNS:
-            b = (singles[k] + singles[k + 1]) / 2 * factor / K
+            raw = (singles[k] + singles[k + 1]) / 2 / K
             k += 2
-            print(f"{ty:4s} W={w:<2d} {p:32s} {b:7.1f} B fetched per lookup  ({b - 8:6.1f} beyond the 8-byte index; the lookup needs {esz}-{2 * esz} B; column = {N_BLOCKS * 128 * w / 1e6:.0f} MB)")
+            print(f"{ty:4s} W={w:<2d} {p:32s} raw counter {raw:6.1f} B per lookup, x{factor:.1f} = {raw * factor:6.1f} B  (the lookup needs its 8-byte index + {esz}-{2 * esz} B; "
+                  f"column = {N_BLOCKS * 128 * w / 1e6:.0f} MB)")
     shutil.rmtree(d, ignore_errors=True)
 
 

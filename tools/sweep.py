@@ -14,6 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fastlanes_amd as fl  # noqa: E402
 
 WINDOW_AB = "--window-ab" in sys.argv
+BARE = "--bare" in sys.argv or ("--cases" in sys.argv and sys.argv[sys.argv.index("--cases") + 1] == "allwidths")
 PLACEMENT = "separate" if "--placement" in sys.argv and sys.argv[sys.argv.index("--placement") + 1] == "separate" else "zoned"
 ESZ = {"u8": 1, "u16": 2, "u32": 4, "u64": 8}
 TDT = {"u8": torch.uint8, "u16": torch.uint16, "u32": torch.uint32, "u64": torch.uint64}
@@ -181,8 +182,28 @@ def run(op, ty, w, gb, reps):
         lib.fl_internal_set_kernel_policy(0)
         placed = (placed + " " if placed else "") + "whole-column map %.3f, 2^16-block windows %.3f, 8-GiB windows %.3f" % tuple(
             n * bpb / sorted(alt[k])[len(alt[k]) // 2] / 8e9 for k in (31, 16, big))
+    bare = None
+    if BARE and op in ("unpack", "unfor_pack", "pack", "for_pack", "undelta_pack"):
+        # a bare stream of the same bytes per wavefront, same cache policy / occupancy / tile map as the kernel the dispatch runs, on the
+        # SAME buffers (fl_internal_bare_stream; it overwrites the output, which nothing reads afterwards)
+        import ctypes
+        Z, I = ctypes.c_size_t, ctypes.c_int
+        iu, au, ou, nt, wv, wn = Z(), Z(), Z(), I(), I(), I()
+        code = 1 if op in ("pack", "for_pack") else 2 if op == "undelta_pack" else 0
+        if lib.fl_internal_bare_stream_shape(code, T, w, *[ctypes.byref(x) for x in (iu, au, ou, nt, wv, wn)]) == 0:
+            g = lambda: lib.fl_internal_bare_stream(src8.data_ptr(), iu.value, aux8.data_ptr() if au.value else None, au.value, dst8.data_ptr(), ou.value, n,
+                                                    nt.value, wv.value, wn.value, None)
+            g(); g()
+            torch.cuda.synchronize()
+            bms = []
+            for _ in range(reps):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); g(); b.record(); b.synchronize()
+                bms.append(a.elapsed_time(b))
+            bare = n * (iu.value + au.value + ou.value) / sorted(bms)[len(bms) // 2] / 1e6
     return {"op": op, "ty": ty, "w": w, "n_blocks": n, "ms": round(med, 4), "GBps": round(gbps, 1),
-            "frac": round(gbps / 8000, 4), "Gints": round(n * 1024 / med / 1e6, 1), "placed": placed}
+            "frac": round(gbps / 8000, 4), "Gints": round(n * 1024 / med / 1e6, 1), "placed": placed,
+            "bare_GBps": round(bare, 1) if bare else None, "of_bare": round(gbps / bare, 4) if bare else None}
 
 
 def host_tier(reps=3):
@@ -205,6 +226,7 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--placement", default="zoned", choices=("zoned", "separate"))
     ap.add_argument("--window-ab", action="store_true", help="every row also under the whole-column tile map and under 2^16-block windows")
+    ap.add_argument("--bare", action="store_true", help="pack / unpack / FoR / undelta_pack rows: also a bare stream of the row's bytes on the row's buffers (always on for allwidths)")
     ap.add_argument("--batch-all", action="store_true", help="--cases batch: every element type and the pack direction too")
     ap.add_argument("--batch-policies", default="", help="--cases batch: comma-separated kernel policies to time next to the default")
     args = ap.parse_args()
@@ -575,16 +597,21 @@ def main():
     for op, ty, w in cases:
         r = run(op, ty, w, args.gb, args.reps)
         out.append(r)
-        print(f"{op:13s} {ty:4s} W={w:<3d} n={r['n_blocks']:>9d} {r['ms']:9.4f} ms {r['GBps']:8.1f} GB/s {r['frac']:.3f} {r['Gints']:8.1f} Gint/s" + (f"   [{r['placed']}]" if r.get("placed") else ""), flush=True)
+        print(f"{op:13s} {ty:4s} W={w:<3d} n={r['n_blocks']:>9d} {r['ms']:9.4f} ms {r['GBps']:8.1f} GB/s {r['frac']:.3f} {r['Gints']:8.1f} Gint/s" +
+              (f"   bare stream {r['bare_GBps']:7.1f} GB/s -> {r['of_bare']:.3f} of it" if r.get("of_bare") else "") + (f"   [{r['placed']}]" if r.get("placed") else ""), flush=True)
         torch.cuda.empty_cache()
     if args.cases == "allwidths":
         print("# ---- summary: fraction of the 8 TB/s peak per (op, type) over all widths 1..T: min (at W) / median / max (at W)")
         for op in ("unpack", "pack", "unfor_pack", "undelta_pack"):
             for ty in ("u8", "u16", "u32", "u64"):
                 rows = sorted((r["frac"], r["w"]) for r in out if r["op"] == op and r["ty"] == ty)
-                print(f"# {op:13s} {ty:4s} min {rows[0][0]:.3f} (W={rows[0][1]:<2d})  median {rows[len(rows) // 2][0]:.3f}  max {rows[-1][0]:.3f} (W={rows[-1][1]})")
+                ob = sorted((r["of_bare"], r["w"]) for r in out if r["op"] == op and r["ty"] == ty and r.get("of_bare"))
+                print(f"# {op:13s} {ty:4s} min {rows[0][0]:.3f} (W={rows[0][1]:<2d})  median {rows[len(rows) // 2][0]:.3f}  max {rows[-1][0]:.3f} (W={rows[-1][1]:<2d})" +
+                      (f"   | of the bare stream of the same bytes on the same buffers: min {ob[0][0]:.3f} (W={ob[0][1]:<2d})  median {ob[len(ob) // 2][0]:.3f}" if ob else ""))
         worst = sorted(out, key=lambda r: r["frac"])[:8]
-        print("# ---- the eight slowest (op, T, W): " + "; ".join(f"{r['op']} {r['ty']} W={r['w']} {r['frac']:.3f}" for r in worst))
+        print("# ---- the eight slowest (op, T, W): " + "; ".join(f"{r['op']} {r['ty']} W={r['w']} {r['frac']:.3f}" + (f" ({r['of_bare']:.2f} of its bare stream)" if r.get("of_bare") else "") for r in worst))
+        wb = sorted((r for r in out if r.get("of_bare")), key=lambda r: r["of_bare"])[:8]
+        print("# ---- the eight furthest below their own bare stream: " + "; ".join(f"{r['op']} {r['ty']} W={r['w']} {r['of_bare']:.3f} (frac {r['frac']:.3f})" for r in wb))
     if args.json:
         json.dump(out, open(args.json, "w"), indent=1)
 
