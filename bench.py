@@ -807,10 +807,10 @@ def bare_stream(w, launches=9):
     lib = fl.load()
     op = {"unpack": 0, "pack": 1, "undelta_pack": 2, "unpack_mixed": 3}[w.op]
     Z, I = ctypes.c_size_t, ctypes.c_int
-    iu, au, ou, nt, wv, wn = Z(), Z(), Z(), I(), I(), I()
-    if lib.fl_internal_bare_stream_shape(op, 8 * ESZ[w.ty], 33 if op == 3 else w.width, *[ctypes.byref(x) for x in (iu, au, ou, nt, wv, wn)]) != 0:
+    iu, au, ou, nt, wv, wn, bpu = Z(), Z(), Z(), I(), I(), I(), ctypes.c_uint()
+    if lib.fl_internal_bare_stream_shape(op, 8 * ESZ[w.ty], 33 if op == 3 else w.width, *[ctypes.byref(x) for x in (iu, au, ou, nt, wv, wn, bpu)]) != 0:
         return None
-    n = w.n
+    n = w.n // bpu.value             # units of bpu consecutive blocks (u8: 4, u16: 2): a wavefront's share in the library's kernels too
     in_unit = iu.value
     if op == 3:                      # a mixed-width column: units of the column's mean packed block, rounded down to a cell
         in_unit = (w.in_bytes // n) & ~15

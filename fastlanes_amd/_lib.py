@@ -145,7 +145,8 @@ def load():
     lib.fl_internal_bare_stream.restype = ctypes.c_int
     lib.fl_internal_bare_stream.argtypes = [_P, _Z, _P, _Z, _P, _Z, _Z, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]
     lib.fl_internal_bare_stream_shape.restype = ctypes.c_int
-    lib.fl_internal_bare_stream_shape.argtypes = [ctypes.c_int, _U, _U] + [ctypes.POINTER(ctypes.c_size_t)] * 3 + [ctypes.POINTER(ctypes.c_int)] * 3
+    lib.fl_internal_bare_stream_shape.argtypes = ([ctypes.c_int, _U, _U] + [ctypes.POINTER(ctypes.c_size_t)] * 3 + [ctypes.POINTER(ctypes.c_int)] * 3 +
+                                                  [ctypes.POINTER(ctypes.c_uint)])
     lib.fl_column_pair_alloc.restype = ctypes.c_int
     lib.fl_column_pair_alloc.argtypes = [_Z, _Z, _Z, ctypes.c_int, _P] + [ctypes.POINTER(_P)] * 4 + [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint32)]
     lib.fl_column_pair_free.restype = ctypes.c_int

@@ -770,19 +770,24 @@ int fl_internal_bare_stream(const void* in, size_t in_unit, const void* aux, siz
 // times 2, so that 16.5 can be said).  The shape a bare stream must have to shadow that call: bytes per block on either side, the
 // cache policy of the loads, waves per SIMD and tile-map window the library's own kernel for that (T, W) runs with.
 int fl_internal_bare_stream_shape(int op, unsigned type_bits, unsigned width, size_t* in_unit, size_t* aux_unit, size_t* out_unit,
-                                  int* nt_loads, int* waves, int* window_log2_units)
+                                  int* nt_loads, int* waves, int* window_log2_units, unsigned* blocks_per_unit)
 {
     if (type_bits != 8 && type_bits != 16 && type_bits != 32 && type_bits != 64) return FL_ERR_INDEX;
     if (op < 0 || op > 3) return FL_ERR_INDEX;
     if (width > (op == 3 ? 2 * type_bits : type_bits)) return FL_ERR_WIDTH;
-    if (!in_unit || !aux_unit || !out_unit || !nt_loads || !waves || !window_log2_units) return FL_ERR_NULL;
-    const size_t packed = op == 3 ? 64u * width : 128u * width, unpacked = 128u * type_bits;
+    if (!in_unit || !aux_unit || !out_unit || !nt_loads || !waves || !window_log2_units || !blocks_per_unit) return FL_ERR_NULL;
+    // a wavefront's unit is at least 4 KiB of unpacked values: 4 consecutive u8 blocks, 2 u16 blocks -- the library's own kernels never
+    // give a wavefront a single 1- or 2-KiB block either (8 blocks per wavefront in the cell-column kernels, 2-4 in flight in the others),
+    // and a stream that did would measure the starving wavefront, not the memory
+    const unsigned k = type_bits == 8 ? 4u : type_bits == 16 ? 2u : 1u;
+    const size_t packed = (op == 3 ? 64u * width : 128u * width) * k, unpacked = 128u * type_bits * k;
+    *blocks_per_unit = k;
     *in_unit = op == 1 ? unpacked : packed;
     *out_unit = op == 1 ? packed : unpacked;
-    *aux_unit = op == 2 ? 128 : 0;
+    *aux_unit = op == 2 ? 128u * k : 0;
     const WaveOp wop = op == 1 ? WAVE_PACK : op == 2 ? WAVE_UNDELTA_PACK : WAVE_UNPACK;
     int w = op == 3 ? mixed_waves(type_bits, false) : chosen_waves(type_bits, width, wop);
-    if (w == 0) w = op == 1 ? (type_bits >= 32 ? 1 : 2) : 3;       // a cell-column kernel: its waves_per_eu cap (fl_kernels.hpp)
+    if (w == 0) w = 8;       // a cell-column kernel gives a wavefront 8 blocks at 2-3 waves per SIMD: the one-unit-per-wavefront stream needs every slot to keep as many bytes in flight
     *waves = w < 3 ? 3 : w;
     *nt_loads = op == 1 || op == 3 || 2 * width >= type_bits;       // fl_widths.hpp: RD_AUTO; pack reads non-temporally
     *window_log2_units = window_log2_blocks(op == 1 ? WIN_PACK : op == 2 ? WIN_UNDELTA_PACK : WIN_UNPACK, type_bits);

@@ -49,14 +49,16 @@ def test_column_pair_and_bare_stream_argument_checks_need_no_gpu(lib):
     assert lib.fl_column_pair_alloc(1 << 20, 0, 1 << 20, 3, None, ctypes.byref(i), None, ctypes.byref(o), ctypes.byref(h), ctypes.byref(kept), None) == 2
     assert lib.fl_column_pair_free(None) == 0
     Z, I = ctypes.c_size_t, ctypes.c_int
-    iu, au, ou, nt, wv, wn = Z(), Z(), Z(), I(), I(), I()
-    refs = [ctypes.byref(x) for x in (iu, au, ou, nt, wv, wn)]
+    iu, au, ou, nt, wv, wn, bpu = Z(), Z(), Z(), I(), I(), I(), ctypes.c_uint()
+    refs = [ctypes.byref(x) for x in (iu, au, ou, nt, wv, wn, bpu)]
     assert lib.fl_internal_bare_stream_shape(0, 32, 7, *refs) == 0
     assert (iu.value, au.value, ou.value, nt.value, wn.value) == (896, 0, 4096, 0, 31) and 3 <= wv.value <= 8
     assert lib.fl_internal_bare_stream_shape(1, 64, 17, *refs) == 0
     assert (iu.value, au.value, ou.value, nt.value, wn.value) == (8192, 0, 2176, 1, 16)
     assert lib.fl_internal_bare_stream_shape(2, 32, 12, *refs) == 0 and (iu.value, au.value, ou.value) == (1536, 128, 4096)
-    assert lib.fl_internal_bare_stream_shape(3, 32, 33, *refs) == 0 and (iu.value, ou.value, nt.value) == (2112, 4096, 1)
+    assert lib.fl_internal_bare_stream_shape(3, 32, 33, *refs) == 0 and (iu.value, ou.value, nt.value, bpu.value) == (2112, 4096, 1, 1)
+    assert lib.fl_internal_bare_stream_shape(0, 8, 3, *refs) == 0 and (iu.value, ou.value, bpu.value) == (4 * 384, 4096, 4)       # u8: 4 blocks per wavefront
+    assert lib.fl_internal_bare_stream_shape(2, 16, 9, *refs) == 0 and (iu.value, au.value, ou.value, bpu.value) == (2 * 1152, 256, 4096, 2)
     assert lib.fl_internal_bare_stream_shape(0, 32, 33, *refs) == 1 and lib.fl_internal_bare_stream_shape(0, 12, 3, *refs) == 2
     assert lib.fl_internal_bare_stream_shape(4, 32, 3, *refs) == 2 and lib.fl_internal_bare_stream_shape(0, 32, 3, None, *refs[1:]) == 3
     p = ctypes.c_void_p(0x1000)

@@ -188,10 +188,11 @@ def run(op, ty, w, gb, reps):
         # SAME buffers (fl_internal_bare_stream; it overwrites the output, which nothing reads afterwards)
         import ctypes
         Z, I = ctypes.c_size_t, ctypes.c_int
-        iu, au, ou, nt, wv, wn = Z(), Z(), Z(), I(), I(), I()
+        iu, au, ou, nt, wv, wn, bpu = Z(), Z(), Z(), I(), I(), I(), ctypes.c_uint()
         code = 1 if op in ("pack", "for_pack") else 2 if op == "undelta_pack" else 0
-        if lib.fl_internal_bare_stream_shape(code, T, w, *[ctypes.byref(x) for x in (iu, au, ou, nt, wv, wn)]) == 0:
-            g = lambda: lib.fl_internal_bare_stream(src8.data_ptr(), iu.value, aux8.data_ptr() if au.value else None, au.value, dst8.data_ptr(), ou.value, n,
+        if lib.fl_internal_bare_stream_shape(code, T, w, *[ctypes.byref(x) for x in (iu, au, ou, nt, wv, wn, bpu)]) == 0:
+            nu = n // bpu.value
+            g = lambda: lib.fl_internal_bare_stream(src8.data_ptr(), iu.value, aux8.data_ptr() if au.value else None, au.value, dst8.data_ptr(), ou.value, nu,
                                                     nt.value, wv.value, wn.value, None)
             g(); g()
             torch.cuda.synchronize()
@@ -200,7 +201,7 @@ def run(op, ty, w, gb, reps):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record(); g(); b.record(); b.synchronize()
                 bms.append(a.elapsed_time(b))
-            bare = n * (iu.value + au.value + ou.value) / sorted(bms)[len(bms) // 2] / 1e6
+            bare = nu * (iu.value + au.value + ou.value) / sorted(bms)[len(bms) // 2] / 1e6
     return {"op": op, "ty": ty, "w": w, "n_blocks": n, "ms": round(med, 4), "GBps": round(gbps, 1),
             "frac": round(gbps / 8000, 4), "Gints": round(n * 1024 / med / 1e6, 1), "placed": placed,
             "bare_GBps": round(bare, 1) if bare else None, "of_bare": round(gbps / bare, 4) if bare else None}
