@@ -31,6 +31,7 @@
 // LDS is wave-local: no s_barrier.
 #pragma once
 #include "fl_widths.hpp"
+#include <atomic>
 
 namespace fl {
 
@@ -791,6 +792,32 @@ __global__ __launch_bounds__(64) void k_chain_columns_pipelined(ChainArgs a)
     }
 }
 
+// Workgroups of a persistent single-wavefront kernel that are resident at once on the current device: CUs x min(wanted per CU, what
+// fits).  The two device queries cost microseconds and never change for a kernel on a device: cached per kernel (one slot per
+// template instantiation) and device id.
+template <auto KERNEL>
+inline hipError_t persistent_grid(unsigned lds, int per_cu, unsigned& grid)
+{
+    struct Slot { std::atomic<int> dev{-1}; std::atomic<int> cus{0}; std::atomic<int> fit{0}; };
+    static Slot slot;                                       // one per instantiation = per kernel (KERNEL is a non-type parameter)
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    int cus = slot.cus.load(std::memory_order_relaxed), fit = slot.fit.load(std::memory_order_relaxed);
+    if (slot.dev.load(std::memory_order_acquire) != dev || cus <= 0 || fit <= 0) {
+        e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, KERNEL, 64, lds);
+        if (e != hipSuccess) return e;
+        slot.cus.store(cus, std::memory_order_relaxed);
+        slot.fit.store(fit, std::memory_order_relaxed);
+        slot.dev.store(dev, std::memory_order_release);
+    }
+    if (fit > 0 && per_cu > fit) per_cu = fit;              // a persistent grid must be resident at once to be worth anything
+    const uint64_t resident = ((uint64_t)cus * (unsigned)per_cu + 7) / 8 * 8;          // a multiple of 8: a workgroup stays on its XCD
+    if (resident >= 8 && resident < grid) grid = (unsigned)resident;
+    return hipSuccess;
+}
+
 // Resident wavefronts per CU: 8 (two per SIMD) measured best or equal against 12 (what the 130 VGPRs allow) and 16
 // (profiles/exp_columns_r05.txt, step 3); `waves` (the A/B tools' occupancy knob: waves per SIMD) overrides it.
 constexpr int COLUMNS_WAVES_PER_CU = 8;
@@ -808,14 +835,7 @@ hipError_t launch_chain_columns_pipelined(const ChainArgs& a0, int waves, hipStr
     if (a.widths) a.window_shift |= TILE_MAP_ROTATE;
     const unsigned lds = TILE_BLOCKS * (SNK == SNK_ORIGINAL && sizeof(T) == 1 ? ORIGINAL_U8_STRIDE : WaveBlock<T>::BLOCK_BYTES);
     unsigned grid = (unsigned)(a.tiles_per_xcd * 8);
-    int per_cu = per_cu_override, fit = 0, cus = 0, dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_chain_columns_pipelined<T, SNK>, 64, lds);
-    if (e != hipSuccess) return e;
-    if (fit > 0 && per_cu > fit) per_cu = fit;              // a persistent grid must be resident at once to be worth anything
-    const uint64_t resident = ((uint64_t)cus * (unsigned)per_cu + 7) / 8 * 8;          // a multiple of 8: a workgroup stays on its XCD
-    if (resident >= 8 && resident < grid) grid = (unsigned)resident;
+    if (hipError_t e = persistent_grid<k_chain_columns_pipelined<T, SNK>>(lds, per_cu_override, grid); e != hipSuccess) return e;
     FL_LAUNCH((k_chain_columns_pipelined<T, SNK>), dim3(grid), dim3(64), lds, s, a);
     return hipGetLastError();
 }
@@ -1004,14 +1024,7 @@ hipError_t launch_chain_columns_encode_pipelined(const ChainArgs& a0, int waves,
     if (a.widths) a.window_shift |= TILE_MAP_ROTATE;
     const unsigned lds = TILE_BLOCKS * ORIGINAL_U8_STRIDE;
     unsigned grid = (unsigned)(a.tiles_per_xcd * 8);
-    int per_cu = waves > 0 ? 4 * waves : COLUMNS_WAVES_PER_CU, fit = 0, cus = 0, dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_chain_columns_encode_pipelined<T>, 64, lds);
-    if (e != hipSuccess) return e;
-    if (fit > 0 && per_cu > fit) per_cu = fit;
-    const uint64_t resident = ((uint64_t)cus * (unsigned)per_cu + 7) / 8 * 8;
-    if (resident >= 8 && resident < grid) grid = (unsigned)resident;
+    if (hipError_t e = persistent_grid<k_chain_columns_encode_pipelined<T>>(lds, waves > 0 ? 4 * waves : COLUMNS_WAVES_PER_CU, grid); e != hipSuccess) return e;
     FL_LAUNCH((k_chain_columns_encode_pipelined<T>), dim3(grid), dim3(64), lds, s, a);
     return hipGetLastError();
 }
