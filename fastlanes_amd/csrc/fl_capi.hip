@@ -115,9 +115,13 @@ int run_stream(stream_launch_t fn, const T* in, T* out, const void* aux, size_t 
 // by the kernel, `w` unused.
 template <typename T>
 int run_chain(int op, int waves, unsigned w, const T* in, const T* bases, T* out, size_t n_blocks, void* stream,
-              const uint8_t* widths = nullptr, const uint64_t* offsets = nullptr, size_t packed_bytes = 0, uint32_t* err_flag = nullptr)
+              const uint8_t* widths = nullptr, const uint64_t* offsets = nullptr, size_t packed_bytes = 0, uint32_t* err_flag = nullptr,
+              bool two_blocks = false)
 {
-    const fl::chain_launch_t fn = widths ? fl::chain_widths_launcher<T>(op) : fl::chain_launcher<T>(op);
+    fl::chain_launch_t fn = widths ? fl::chain_widths_launcher<T>(op) : fl::chain_launcher<T>(op);
+    if (two_blocks && !widths) {                            // the two-blocks-per-wavefront form, where it exists (fl_chain.hpp)
+        if (const fl::chain_launch_t fn2 = fl::chain_launcher_two_blocks<T>(op)) fn = fn2;
+    }
     if (!fn) return -1;
     if (n_blocks == 0) return FL_OK;
     const bool packed_in = op == fl::OP_UNDELTA_PACK || op == fl::OP_UNDELTA_PACK_UNTRANSPOSE;
@@ -220,8 +224,14 @@ int dev_undelta_pack(unsigned w, const T* in, const T* bases, T* out, size_t n, 
 {
     if (w > (unsigned)Elem<T>::BITS) return FL_ERR_WIDTH;
     if (n && misaligned(bases)) return FL_ERR_ALIGN;
-    if (const int waves = chosen_waves(Elem<T>::BITS, w, WAVE_UNDELTA_PACK)) {
-        const int rc = run_chain<T>(OP_UNDELTA_PACK, waves, w, in, bases, out, n, s);
+    if (int waves = chosen_waves(Elem<T>::BITS, w, WAVE_UNDELTA_PACK)) {
+        // a table entry 10 + k = the wave-per-block kernel with TWO blocks per wavefront in lockstep at k waves per SIMD (fl_dispatch.hpp);
+        // the A/B tools force either form with the policy's blocks-per-wavefront field (2 + 256 * waves + 65536 * {1, 2})
+        bool two = waves >= TWO_BLOCKS;
+        if (two) waves -= TWO_BLOCKS;
+        const int pol = g_kernel_policy.load(std::memory_order_relaxed);
+        if ((pol & 0xff) == 2 && ((pol >> 16) & 0xff)) two = ((pol >> 16) & 0xff) == 2;
+        const int rc = run_chain<T>(OP_UNDELTA_PACK, waves, w, in, bases, out, n, s, nullptr, nullptr, 0, nullptr, two);
         if (rc >= 0) return rc;                  // -1: no pipeline form of this op (cannot happen today): the cell-column kernel
     }
     return run_stream<T>(unpack_table_impl<T, BODY_UNDELTA>().fn[w], in, out, bases, 0, n, w != 0, true, true, s);
@@ -787,6 +797,7 @@ int fl_internal_bare_stream_shape(int op, unsigned type_bits, unsigned width, si
     *aux_unit = op == 2 ? 128u * k : 0;
     const WaveOp wop = op == 1 ? WAVE_PACK : op == 2 ? WAVE_UNDELTA_PACK : WAVE_UNPACK;
     int w = op == 3 ? mixed_waves(type_bits, false) : chosen_waves(type_bits, width, wop);
+    if (w >= TWO_BLOCKS) w -= TWO_BLOCKS;                           // two blocks per wavefront: same bytes per launch, the occupancy is what the table says
     if (w == 0) w = 8;       // a cell-column kernel gives a wavefront 8 blocks at 2-3 waves per SIMD: the one-unit-per-wavefront stream needs every slot to keep as many bytes in flight
     *waves = w < 3 ? 3 : w;
     *nt_loads = op == 1 || op == 3 || 2 * width >= type_bits;       // fl_widths.hpp: RD_AUTO; pack reads non-temporally

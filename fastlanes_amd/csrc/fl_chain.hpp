@@ -390,7 +390,7 @@ __device__ __forceinline__ void chain_blocks_lockstep(const ChainArgs& a, uint64
     constexpr unsigned WAVE_LDS = chain_wave_lds<T, SRC, SNK>();
     // narrow types: all of the wavefront's blocks requested up front by LDS-DMA (their images are linear in every layout),
     // the bases behind them; then every stage for all of them
-    static_assert(sizeof(T) < 4, "the padded original-order image of u32 / u64 cannot be filled by LDS-DMA");
+    static_assert(sizeof(T) < 4 || (SRC != SRC_ORIGINAL && SNK != SNK_ORIGINAL), "the padded original-order image of u32 / u64 cannot be filled by LDS-DMA");
     constexpr bool FENCE_BEFORE_IMAGE = !(SRC == SRC_ROWS && SNK == SNK_ROWS);
     unsigned w[BPW];
     uint64_t packed_at[BPW];
@@ -1035,5 +1035,7 @@ enum ChainOp { OP_UNDELTA_PACK = 0, OP_UNDELTA = 1, OP_DELTA = 2, OP_UNTRANSPOSE
 template <typename T> chain_launch_t chain_launcher(int op);
 // the mixed-width form (ChainArgs.widths != nullptr) of the three ops with a packed side
 template <typename T> chain_launch_t chain_widths_launcher(int op);
+// the two-blocks-per-wavefront form of an op (u32 / u64 undelta_pack), or nullptr
+template <typename T> chain_launch_t chain_launcher_two_blocks(int op);
 
 }  // namespace fl

@@ -76,6 +76,13 @@ template <> chain_launch_t chain_launcher<T>(int op)
     default: return nullptr;
     }
 }
+template <> chain_launch_t chain_launcher_two_blocks<T>(int op)
+{
+    if constexpr (sizeof(T) >= 4) {
+        if (op == OP_UNDELTA_PACK) return &launch_chain<T, SRC_PACKED, CHAIN_UNDELTA, SNK_ROWS, RD_VGPR, 2>;
+    }
+    return nullptr;
+}
 template <> chain_launch_t chain_widths_launcher<T>(int op)
 {
     constexpr unsigned B = chain_blocks_per_wave<T>();

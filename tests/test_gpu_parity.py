@@ -90,6 +90,25 @@ def test_all_widths_vs_oracle(fl, oracle, kernel_policy, ty, policy):
         assert np.array_equal(got, oracle.batch("undelta_pack", ty, w, pk, aux=bases, n_blocks=n)), (ty, w, "undelta_pack")
 
 
+@pytest.mark.parametrize("waves", [0, 3, 8])
+@pytest.mark.parametrize("ty", ["u32", "u64"])
+def test_undelta_pack_two_blocks_per_wavefront(fl, oracle, kernel_policy, ty, waves):
+    """Delta::undelta_pack::<W> (delta.rs:47-63) of the wide types through the TWO-blocks-per-wavefront form of the pipeline kernel
+    (a dispatch-table entry 10 + k; forced here by the policy's blocks-per-wavefront field): every width against the oracle, an odd
+    block count (the last wavefront holds ONE block), and byte for byte the same as the one-block form."""
+    T = tbits(ty)
+    n = 37
+    for w in range(T + 1):
+        seed = 7700 + 64 * T + w
+        pk = values(ty, n * packed_len(ty, w), seed)
+        bases = values(ty, n * lanes(ty), seed + 1)
+        kernel_policy(2 + 256 * waves + 65536 * 2)
+        two = to_np(fl.Delta.undelta_pack(w, to_dev(pk), to_dev(bases)), ty)
+        assert np.array_equal(two, oracle.batch("undelta_pack", ty, w, pk, aux=bases, n_blocks=n)), (ty, w, waves)
+        kernel_policy(2 + 256 * waves + 65536 * 1)
+        assert np.array_equal(two, to_np(fl.Delta.undelta_pack(w, to_dev(pk), to_dev(bases)), ty)), (ty, w, "one block per wavefront")
+
+
 @pytest.mark.parametrize("policy", [0, 1, 2])
 @pytest.mark.parametrize("ty", TYS)
 def test_delta_transpose_vs_oracle(fl, oracle, kernel_policy, ty, policy):

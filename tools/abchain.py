@@ -59,17 +59,23 @@ for ty, W in cases:
         seen_plain.add(ty)
         ops["undelta"] = (lambda: fl.Delta.undelta(un, bases, output=out), n * (256 * T + 128))
         ops["delta"] = (lambda: fl.Delta.delta(un, bases, output=out), n * (256 * T + 128))
+    if T >= 32:                            # the two-blocks-per-wavefront form of the wide types' undelta_pack (a table entry 10 + waves)
+        ops["undelta_pack_2b"] = ops["undelta_pack"]
+    if "--only" in sys.argv:               # e.g. --only undelta_pack,undelta_pack_2b
+        keep_ops = sys.argv[sys.argv.index("--only") + 1].split(",")
+        ops = {k: v for k, v in ops.items() if k in keep_ops}
     for name, (f, nbytes) in ops.items():
         res_t = pk_out if name == "transp_delta_pack" else pk_for if name == "for_pack" else out
+        two = 65536 * 2 if name.endswith("_2b") else 0
         lib.fl_internal_set_kernel_policy(1)
         f()
         ref = res_t.clone()
-        lib.fl_internal_set_kernel_policy(2)
+        lib.fl_internal_set_kernel_policy(2 + two)
         f()
         same = torch.equal(ref.view(torch.uint8), res_t.view(torch.uint8))
         del ref
         res = {}
-        pols = [1] + [2 + 256 * w for w in WAVES]
+        pols = [1] + [2 + 256 * w + two for w in WAVES]
         for _ in range(ROUNDS):
             for p in pols:
                 lib.fl_internal_set_kernel_policy(p)

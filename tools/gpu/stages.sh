@@ -49,6 +49,9 @@ for stage in "$@"; do
   chain_resume)  # the rest of a chain sweep that died: FL_CHAIN_START=u64:64 (round 5: the allocator fragmented at u64 W=64 on both boxes)
     FL_LIB=$PWD/fastlanes_amd/libfastlanes_amd_full.so timeout 2400 python tools/abchain.py 3 --all --gb 45 --start-at ${FL_CHAIN_START:-u64:64} 2>&1 | grep -v amdgpu > $R/abchain_resume.txt
     grep -c MISMATCH $R/abchain_resume.txt; tail -n 3 $R/abchain_resume.txt ;;
+  chain_two_blocks) # the one- and two-blocks-per-wavefront forms of the wide types' undelta_pack, every width (input of make_dispatch.py; needs libfastlanes_amd_full.so)
+    FL_LIB=$PWD/fastlanes_amd/libfastlanes_amd_full.so timeout 2400 python tools/abchain.py 3 --all --gb 45 --types u32,u64 --only undelta_pack,undelta_pack_2b 2>&1 | grep -v amdgpu > $R/abchain_two_blocks.txt
+    grep -c MISMATCH $R/abchain_two_blocks.txt; tail -n 4 $R/abchain_two_blocks.txt ;;
   bench)
     timeout 900 python bench.py > $R/bench_u32w7.json 2> $R/bench.err; echo "bench rc=$?"; cat $R/bench_u32w7.json ;;
   *) echo "unknown stage $stage" ;;

@@ -34,7 +34,10 @@ TYPES = (8, 16, 32, 64)
 # ops of the uniform sweep, ops of the chain sweep that depend on the width, and the per-type ones
 UNIFORM_OPS = ("unpack", "pack")
 CHAIN_W_OPS = {"undelta_pack": "undelta_pack", "undelta_pack_untr": "undelta_pack_untranspose",
-               "transp_delta_pack": "transpose_delta_pack", "unfor_pack": "unfor_pack", "for_pack": "for_pack"}
+               "transp_delta_pack": "transpose_delta_pack", "unfor_pack": "unfor_pack", "for_pack": "for_pack",
+               "undelta_pack_2b": "undelta_pack_2b"}
+# undelta_pack of u32 / u64 also exists with TWO blocks per wavefront in lockstep (fl_dispatch.hpp: TWO_BLOCKS): a table entry 10 + k
+TWO_BLOCKS = 10
 # FoR's rows (round 5): if NO chain file holds them (sweeps older than round 5) they follow unpack / pack, as the library did then
 FOR_FOLLOWS = {"unfor_pack": "unpack", "for_pack": "pack"}
 CHAIN_T_OPS = ("undelta", "delta", "untranspose", "transpose")
@@ -91,6 +94,25 @@ def decide(samples, margin):
     return WAVES[best_k]
 
 
+def decide_two(one, two, margin):
+    """one / two: per box (cc, [wpb...]) of the one-block and the two-block form -> waves, TWO_BLOCKS + waves, or 0 (cell-column).
+    The two-block form is taken only where its best geometric-mean rate leads the one-block form's best by more than the margin."""
+    def best(samples):
+        bk, bg = 0, -1.0
+        for k in range(len(WAVES)):
+            gm = math.exp(sum(math.log(max(w[k], 1) / max(cc, 1)) for cc, w in samples) / len(samples))
+            if gm > bg:
+                bk, bg = k, gm
+        return bk, bg
+    k1, g1 = best(one)
+    k2, g2 = best(two)
+    use_two = g2 > (1.0 + margin) * g1
+    chosen, k = (two, k2) if use_two else (one, k1)
+    if all(cc > 0 for cc, _ in chosen) and all(cc > (1.0 + margin) * w[k] for cc, w in chosen):
+        return 0
+    return (TWO_BLOCKS if use_two else 0) + WAVES[k]
+
+
 def build(uniform_files, chain_files, margin):
     boxes_u = [parse_uniform(f) for f in uniform_files]
     boxes_c = [parse_chain(f) for f in chain_files]
@@ -108,6 +130,8 @@ def build(uniform_files, chain_files, margin):
                     row.append(decide(samples, margin))
             table[(op, T)] = row
     for op in CHAIN_W_OPS.values():
+        if op == "undelta_pack_2b":
+            continue                                  # not a row of its own: folded into undelta_pack below
         if op in FOR_FOLLOWS and not any(k[0] == op for b in boxes_c for k in b):
             for T in TYPES:
                 table[(op, T)] = list(table[(FOR_FOLLOWS[op], T)])
@@ -118,7 +142,11 @@ def build(uniform_files, chain_files, margin):
                 samples = [b[(op, T, W)] for b in boxes_c if (op, T, W) in b]
                 if len(samples) != len(boxes_c) or not samples:
                     raise SystemExit(f"chain sweep lacks {op} u{T} W={W} on some box (run tools/abchain.py --all)")
-                row.append(WAVES[0] if (op in ("transpose_delta_pack", "for_pack") and W == 0) else decide(samples, margin))
+                two = [b[("undelta_pack_2b", T, W)] for b in boxes_c if ("undelta_pack_2b", T, W) in b] if op == "undelta_pack" else []
+                if two and len(two) == len(boxes_c) and W > 0:
+                    row.append(decide_two(samples, two, margin))
+                else:
+                    row.append(WAVES[0] if (op in ("transpose_delta_pack", "for_pack") and W == 0) else decide(samples, margin))
             table[(op, T)] = row
     for op in CHAIN_T_OPS:
         for T in TYPES:
@@ -140,10 +168,11 @@ def render(table, uniform_files, chain_files, margin):
     lines += [
         f"// Rule: k* = occupancy with the best geometric-mean rate over the boxes; the cell-column kernel (entry 0) is kept only",
         f"// where it leads wave-per-block@k* by more than {margin * 100:.0f} % on EVERY box; otherwise the entry is k* (waves per SIMD).",
-        "// Index = width W (0..T); the per-type ops have one entry.",
+        "// Index = width W (0..T); the per-type ops have one entry.  UNDELTA_PACK of u32 / u64: an entry 10 + k = the two-blocks-per-wavefront",
+        f"// form at k waves per SIMD, taken where its best geometric-mean rate leads the one-block form's best by more than {margin * 100:.0f} %.",
         "namespace fl { namespace dispatch_table {",
     ]
-    order = list(UNIFORM_OPS) + list(CHAIN_W_OPS.values()) + list(CHAIN_T_OPS)
+    order = list(UNIFORM_OPS) + [o for o in CHAIN_W_OPS.values() if o != "undelta_pack_2b"] + list(CHAIN_T_OPS)
     for op in order:
         for T in TYPES:
             row = table[(op, T)]
