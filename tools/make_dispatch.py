@@ -97,15 +97,17 @@ def decide(samples, margin):
 def decide_two(one, two, margin):
     """one / two: per box (cc, [wpb...]) of the one-block and the two-block form -> waves, TWO_BLOCKS + waves, or 0 (cell-column).
     The two-block form is taken only where its best geometric-mean rate leads the one-block form's best by more than the margin."""
-    def best(samples):
-        bk, bg = 0, -1.0
-        for k in range(len(WAVES)):
+    def best(samples, first=0):
+        bk, bg = first, -1.0
+        for k in range(first, len(WAVES)):
             gm = math.exp(sum(math.log(max(w[k], 1) / max(cc, 1)) for cc, w in samples) / len(samples))
             if gm > bg:
                 bk, bg = k, gm
         return bk, bg
     k1, g1 = best(one)
-    k2, g2 = best(two)
+    # the two-block form is not offered at 3 workgroups per CU: it wins some 45-GB sweep cells there by 2-3 % and falls off a cliff
+    # on 8-GB columns (u32 W=24: 0.668 of the peak against 0.80 at 4+; profiles/exp_two_blocks_r05.txt)
+    k2, g2 = best(two, first=1)
     use_two = g2 > (1.0 + margin) * g1
     chosen, k = (two, k2) if use_two else (one, k1)
     if all(cc > 0 for cc, _ in chosen) and all(cc > (1.0 + margin) * w[k] for cc, w in chosen):
@@ -169,7 +171,7 @@ def render(table, uniform_files, chain_files, margin):
         f"// Rule: k* = occupancy with the best geometric-mean rate over the boxes; the cell-column kernel (entry 0) is kept only",
         f"// where it leads wave-per-block@k* by more than {margin * 100:.0f} % on EVERY box; otherwise the entry is k* (waves per SIMD).",
         "// Index = width W (0..T); the per-type ops have one entry.  UNDELTA_PACK of u32 / u64: an entry 10 + k = the two-blocks-per-wavefront",
-        f"// form at k waves per SIMD, taken where its best geometric-mean rate leads the one-block form's best by more than {margin * 100:.0f} %.",
+        f"// form at k >= 4 waves per SIMD, taken where its best geometric-mean rate leads the one-block form's best by more than {margin * 100:.0f} %.",
         "namespace fl { namespace dispatch_table {",
     ]
     order = list(UNIFORM_OPS) + [o for o in CHAIN_W_OPS.values() if o != "undelta_pack_2b"] + list(CHAIN_T_OPS)
