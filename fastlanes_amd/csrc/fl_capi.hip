@@ -885,6 +885,7 @@ int fl_column_pair_alloc(size_t in_bytes, size_t aux_bytes, size_t out_bytes, in
 {
     if (!in || !out || !handle || (aux_bytes && !aux)) return FL_ERR_NULL;
     if (layout != FL_LAYOUT_SEPARATE && layout != FL_LAYOUT_ZONED && layout != FL_LAYOUT_PROBE) return FL_ERR_INDEX;
+    FL_DEVICE_TIER(stream);                                  // FL_CHECK_DEVICE=1: `stream` must belong to the current device (the memory will)
     *in = *out = *handle = nullptr;
     if (aux) *aux = nullptr;
     if (probe_gbps) probe_gbps[0] = probe_gbps[1] = 0;
@@ -894,8 +895,8 @@ int fl_column_pair_alloc(size_t in_bytes, size_t aux_bytes, size_t out_bytes, in
     if (layout != FL_LAYOUT_PROBE) {
         if (hipError_t e = pair_alloc(layout, in_bytes, aux_bytes, out_bytes, *kept); e != hipSuccess) { delete kept; return hip_fail(e); }
     } else {
-        // both layouts, one after the other where both do not fit together: a bare stream of the pair's read : write proportion is
-        // timed on each, the faster one is kept.  The contents of the buffers are whatever the stream left there.
+        // both layouts (a candidate that cannot be allocated next to the one already held is skipped): a bare stream of the pair's
+        // read : write proportion is timed on each, the faster one is kept.  The contents of the buffers are whatever the stream left there.
         double best = -1.0;
         kept_layout = -1;
         for (int cand = FL_LAYOUT_SEPARATE; cand <= FL_LAYOUT_ZONED; ++cand) {
