@@ -16,6 +16,8 @@ for stage in "$@"; do
   full_check)
     ( time timeout 900 python -m pytest tests/test_gpu_full_check.py -m gpu -q -x ) > $R/full_check.txt 2>&1; echo "full check rc=$?"; tail -n 4 $R/full_check.txt ;;
   ab_r03)       # the round-3 build (eb76dff, tools/ab/libfastlanes_amd_r03.so) against HEAD, same buffers, interleaved
+                # (the old build is not tracked: git worktree add build/r03_src eb76dff && make -C build/r03_src/fastlanes_amd/csrc -j8 &&
+                #  mkdir -p tools/ab && cp build/r03_src/fastlanes_amd/libfastlanes_amd.so tools/ab/libfastlanes_amd_r03.so && git worktree remove --force build/r03_src)
     L="tools/ab/libfastlanes_amd_r03.so fastlanes_amd/libfastlanes_amd.so"
     { echo "# columns: round 3 (eb76dff) | HEAD;  BASELINE sizes (10 M blocks; config 5: 9 765 625), same buffers, round-robin"
       FL_AB_BLOCKS=10000000 timeout 600 python tools/ablibs.py 15 unpack u32:7,u64:17 $L
