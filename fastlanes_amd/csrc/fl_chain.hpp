@@ -457,58 +457,6 @@ __device__ __forceinline__ void chain_blocks_lockstep(const ChainArgs& a, uint64
     });
 }
 
-// ---- COLUMN LANES (round 5): Delta's decode over a mixed-width u8 column, EIGHT consecutive blocks per wavefront --------------------
-// The lockstep form above gives a lane R = T/8 rows of a block -- for u8 ONE row -- so the running sum of delta.rs:56-61 runs ACROSS
-// lanes: base into group 0, a 3-step Hillis-Steele scan of the 8 lane groups by ds_bpermute (16 of them per block) with a SWAR byte
-// add (6 VALU per word) at every step: ~200 VALU instructions per 1-KiB block, VALU issue 0.75-0.81 of nominal, 0.56-0.60 of the HBM
-// peak (VERDICT r04 weak #4; profiles/r05_sq_mixed_lockstep.txt).
-// Here lane (j = lane/8, c = lane%8) owns cell column c of block first+j for ALL T rows -- the ownership of the per-(T,W) cell-column
-// kernels (fl_device.hpp), but with the block's width in a VGPR: the lane funnel-shifts its T fields out of its block's LDS image
-// (macros.rs:144-164 with per-lane shift and mask) and the chain is a thread-local running value: no cross-lane traffic, no scan
-// (58 VALU per block).  The decoded rows go back into the same image IN PLACE (a lane only ever touches its own 16-byte column of
-// its own block), and every block leaves 1 KiB-contiguously as before.
-// The running value is kept SPLIT -- even bytes and odd bytes in the low bytes of two u16x2 registers, exactly what the funnel's two
-// v_perm produce anyway -- so an add is two v_pk_add_u16 (carries run into the unused high bytes) instead of the 6-op SWAR form,
-// and one v_perm per word merges them for the store.
-// That alone bought nothing (profiles/exp_columns_r05.txt, step 1): with a tile = a fresh workgroup the kernel is bound by the
-// wavefront's serial life, not by instructions.  The kernel below is therefore PIPELINED (k_chain_columns_pipelined).
-// Tried for u16 as well (16 rows per lane, 162 VGPRs) and not adopted: u16's lockstep kernel is not instruction-bound and stays ahead.
-template <typename T> struct ColumnSum;        // running value of one cell column, += one row's fields, -> the row's cell
-template <> struct ColumnSum<uint8_t> {
-    uint32_t ev[4], od[4];
-    __device__ __forceinline__ void start(const Cell<uint8_t>& base)
-    {
-        for (int k = 0; k < 4; ++k) { ev[k] = base.x[k]; od[k] = base.x[k] >> 8; }   // the bytes above each low byte are never read
-    }
-    // fields of the row from (nxt:cur) >> sh, masked with m (WaveBlock<u8>::field_mask); returns the row's cell
-    __device__ __forceinline__ Cell<uint8_t> step(const Cell<uint8_t>& cur, const Cell<uint8_t>& nxt, unsigned sh, uint32_t m)
-    {
-        Cell<uint8_t> r;
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t e = (__builtin_amdgcn_perm(nxt.x[k], cur.x[k], 0x06020400u) >> sh) & m;   // nxt.b2:cur.b2 | nxt.b0:cur.b0
-            const uint32_t o = (__builtin_amdgcn_perm(nxt.x[k], cur.x[k], 0x07030501u) >> sh) & m;   // nxt.b3:cur.b3 | nxt.b1:cur.b1
-            ev[k] = __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, ev[k]) + __builtin_bit_cast(u16x2, e)));
-            od[k] = __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, od[k]) + __builtin_bit_cast(u16x2, o)));
-            r.x[k] = __builtin_amdgcn_perm(od[k], ev[k], 0x06020400u);                                // od.b2 : ev.b2 : od.b0 : ev.b0
-        }
-        return r;
-    }
-};
-constexpr unsigned COLUMN_LANES_BPW = 8;       // 64 lanes = 8 blocks x 8 cell columns
-
-// width and packed-side byte offset of block first+j in lane j (j < count), as loaded -- possibly still in flight
-struct ColumnMeta { unsigned wv; uint64_t ov; };
-__device__ __forceinline__ ColumnMeta columns_meta_load(const ChainArgs& a, uint64_t first, unsigned count, unsigned lane)
-{
-    ColumnMeta m{a.width, 0};
-    if (a.widths && count) {                                // wave-uniform
-        const uint64_t mine = first + (lane < count ? lane : 0u);
-        m.wv = a.widths[mine];
-        m.ov = a.offsets[mine];
-    }
-    return m;
-}
-
 template <typename T, int SRC, int BODY, int SNK, int RD = RD_VGPR, unsigned BPW = 1>
 __global__ __launch_bounds__(WG) void k_chain(ChainArgs a)
 {
@@ -566,6 +514,58 @@ hipError_t launch_chain(const ChainArgs& a0, int waves, hipStream_t s)
     const unsigned pad = (CU_LDS_BYTES / (unsigned)waves) & ~1023u;
     FL_LAUNCH((k_chain<T, SRC, BODY, SNK, RD, BPW>), dim3((unsigned)(a.tiles_per_xcd * 8)), dim3(WG), pad > need ? pad : need, s, a);
     return hipGetLastError();
+}
+
+// ---- COLUMN LANES (round 5): Delta's decode over a mixed-width u8 column, EIGHT consecutive blocks per wavefront --------------------
+// The lockstep form above gives a lane R = T/8 rows of a block -- for u8 ONE row -- so the running sum of delta.rs:56-61 runs ACROSS
+// lanes: base into group 0, a 3-step Hillis-Steele scan of the 8 lane groups by ds_bpermute (16 of them per block) with a SWAR byte
+// add (6 VALU per word) at every step: ~200 VALU instructions per 1-KiB block, VALU issue 0.75-0.81 of nominal, 0.56-0.60 of the HBM
+// peak (VERDICT r04 weak #4; profiles/r05_sq_mixed_lockstep.txt).
+// Here lane (j = lane/8, c = lane%8) owns cell column c of block first+j for ALL T rows -- the ownership of the per-(T,W) cell-column
+// kernels (fl_device.hpp), but with the block's width in a VGPR: the lane funnel-shifts its T fields out of its block's LDS image
+// (macros.rs:144-164 with per-lane shift and mask) and the chain is a thread-local running value: no cross-lane traffic, no scan
+// (58 VALU per block).  The decoded rows go back into the same image IN PLACE (a lane only ever touches its own 16-byte column of
+// its own block), and every block leaves 1 KiB-contiguously as before.
+// The running value is kept SPLIT -- even bytes and odd bytes in the low bytes of two u16x2 registers, exactly what the funnel's two
+// v_perm produce anyway -- so an add is two v_pk_add_u16 (carries run into the unused high bytes) instead of the 6-op SWAR form,
+// and one v_perm per word merges them for the store.
+// That alone bought nothing (profiles/exp_columns_r05.txt, step 1): with a tile = a fresh workgroup the kernel is bound by the
+// wavefront's serial life, not by instructions.  The kernel below is therefore PIPELINED (k_chain_columns_pipelined).
+// Tried for u16 as well (16 rows per lane, 162 VGPRs) and not adopted: u16's lockstep kernel is not instruction-bound and stays ahead.
+template <typename T> struct ColumnSum;        // running value of one cell column, += one row's fields, -> the row's cell
+template <> struct ColumnSum<uint8_t> {
+    uint32_t ev[4], od[4];
+    __device__ __forceinline__ void start(const Cell<uint8_t>& base)
+    {
+        for (int k = 0; k < 4; ++k) { ev[k] = base.x[k]; od[k] = base.x[k] >> 8; }   // the bytes above each low byte are never read
+    }
+    // fields of the row from (nxt:cur) >> sh, masked with m (WaveBlock<u8>::field_mask); returns the row's cell
+    __device__ __forceinline__ Cell<uint8_t> step(const Cell<uint8_t>& cur, const Cell<uint8_t>& nxt, unsigned sh, uint32_t m)
+    {
+        Cell<uint8_t> r;
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t e = (__builtin_amdgcn_perm(nxt.x[k], cur.x[k], 0x06020400u) >> sh) & m;   // nxt.b2:cur.b2 | nxt.b0:cur.b0
+            const uint32_t o = (__builtin_amdgcn_perm(nxt.x[k], cur.x[k], 0x07030501u) >> sh) & m;   // nxt.b3:cur.b3 | nxt.b1:cur.b1
+            ev[k] = __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, ev[k]) + __builtin_bit_cast(u16x2, e)));
+            od[k] = __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, od[k]) + __builtin_bit_cast(u16x2, o)));
+            r.x[k] = __builtin_amdgcn_perm(od[k], ev[k], 0x06020400u);                                // od.b2 : ev.b2 : od.b0 : ev.b0
+        }
+        return r;
+    }
+};
+constexpr unsigned COLUMN_LANES_BPW = 8;       // 64 lanes = 8 blocks x 8 cell columns
+
+// width and packed-side byte offset of block first+j in lane j (j < count), as loaded -- possibly still in flight
+struct ColumnMeta { unsigned wv; uint64_t ov; };
+__device__ __forceinline__ ColumnMeta columns_meta_load(const ChainArgs& a, uint64_t first, unsigned count, unsigned lane)
+{
+    ColumnMeta m{a.width, 0};
+    if (a.widths && count) {                                // wave-uniform
+        const uint64_t mine = first + (lane < count ? lane : 0u);
+        m.wv = a.widths[mine];
+        m.ov = a.offsets[mine];
+    }
+    return m;
 }
 
 // ---- the PIPELINED form of the column-lanes kernel (round 5) -----------------------------------------------------------------
