@@ -39,7 +39,7 @@ for stage in "$@"; do
   sweep_fused)
     timeout 900 python tools/sweep.py --cases fused 2>&1 | grep -v amdgpu.ids > $R/sweep_fused.txt; cat $R/sweep_fused.txt ;;
   allwidths)    # every (T, W) x {pack, unpack, unfor_pack, undelta_pack} through the automatic dispatch, one slab
-    timeout 2400 python tools/sweep.py --cases allwidths --gb 8 --reps 5 --json $R/sweep_allwidths.json 2>&1 | grep -v amdgpu.ids > $R/sweep_allwidths.txt; tail -n 30 $R/sweep_allwidths.txt ;;
+    timeout 2400 python tools/sweep.py --cases allwidths --gb 8 --reps 5 2>&1 | grep -v amdgpu.ids > $R/sweep_allwidths.txt; tail -n 30 $R/sweep_allwidths.txt ;;
   single)       # unpack_single (a7)
     timeout 900 python tools/sweep.py --cases single 2>&1 | grep -v amdgpu.ids > $R/sweep_single.txt; cat $R/sweep_single.txt ;;
   window_ab)    # the tile-map window per (op, T): whole-column map vs 2^16-block windows vs 8-GiB windows, same buffers

@@ -13,6 +13,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fastlanes_amd as fl  # noqa: E402
 
+ALLWIDTH_OPS = ("unpack", "pack", "unfor_pack", "for_pack", "undelta_pack", "undelta_pack_untranspose", "transpose_delta_pack")
 WINDOW_AB = "--window-ab" in sys.argv
 BARE = "--bare" in sys.argv or ("--cases" in sys.argv and sys.argv[sys.argv.index("--cases") + 1] == "allwidths")
 PLACEMENT = "separate" if "--placement" in sys.argv and sys.argv[sys.argv.index("--placement") + 1] == "separate" else "zoned"
@@ -183,14 +184,16 @@ def run(op, ty, w, gb, reps):
         placed = (placed + " " if placed else "") + "whole-column map %.3f, 2^16-block windows %.3f, 8-GiB windows %.3f" % tuple(
             n * bpb / sorted(alt[k])[len(alt[k]) // 2] / 8e9 for k in (31, 16, big))
     bare = None
-    if BARE and op in ("unpack", "unfor_pack", "pack", "for_pack", "undelta_pack"):
+    if BARE and op in ALLWIDTH_OPS:
         # a bare stream of the same bytes per wavefront, same cache policy / occupancy / tile map as the kernel the dispatch runs, on the
         # SAME buffers (fl_internal_bare_stream; it overwrites the output, which nothing reads afterwards)
         import ctypes
         Z, I = ctypes.c_size_t, ctypes.c_int
         iu, au, ou, nt, wv, wn, bpu = Z(), Z(), Z(), I(), I(), I(), ctypes.c_uint()
-        code = 1 if op in ("pack", "for_pack") else 2 if op == "undelta_pack" else 0
+        code = 1 if op in ("pack", "for_pack", "transpose_delta_pack") else 2 if op.startswith("undelta_pack") else 0
         if lib.fl_internal_bare_stream_shape(code, T, w, *[ctypes.byref(x) for x in (iu, au, ou, nt, wv, wn, bpu)]) == 0:
+            if op == "transpose_delta_pack":              # pack's shape plus the bases on the read side
+                au = Z(128 * bpu.value)
             nu = n // bpu.value
             g = lambda: lib.fl_internal_bare_stream(src8.data_ptr(), iu.value, aux8.data_ptr() if au.value else None, au.value, dst8.data_ptr(), ou.value, nu,
                                                     nt.value, wv.value, wn.value, None)
@@ -257,11 +260,11 @@ def main():
                  ("undelta_pack_untranspose", "u16", 9), ("transpose_delta_pack", "u16", 9),
                  ("undelta_pack_untranspose", "u8", 4), ("transpose_delta_pack", "u8", 4)]
     elif args.cases == "allwidths":
-        # EVERY (T, W) x {unpack, pack, unfor_pack, undelta_pack} through the automatic dispatch (the `match width` of
-        # bitpacking.rs:82-95 that every W must serve), one slab, class map printed; summarised per (op, T) at the end
+        # EVERY (T, W) x {unpack, pack, FoR's two bodies, undelta_pack, the two fused transpose extensions} through the automatic dispatch
+        # (the `match width` of bitpacking.rs:82-95 that every W must serve), one slab, class map printed; summarised per (op, T) at the end
         for ty in ("u8", "u16", "u32", "u64"):
             for w in range(1, ESZ[ty] * 8 + 1):
-                cases += [(op, ty, w) for op in ("unpack", "pack", "unfor_pack", "undelta_pack")]
+                cases += [(op, ty, w) for op in ALLWIDTH_OPS]
     elif args.cases == "widths":
         for ty in ("u8", "u16", "u32", "u64"):
             T = ESZ[ty] * 8
@@ -598,16 +601,16 @@ def main():
     for op, ty, w in cases:
         r = run(op, ty, w, args.gb, args.reps)
         out.append(r)
-        print(f"{op:13s} {ty:4s} W={w:<3d} n={r['n_blocks']:>9d} {r['ms']:9.4f} ms {r['GBps']:8.1f} GB/s {r['frac']:.3f} {r['Gints']:8.1f} Gint/s" +
+        print(f"{op:{24 if args.cases == 'allwidths' else 13}s} {ty:4s} W={w:<3d} n={r['n_blocks']:>9d} {r['ms']:9.4f} ms {r['GBps']:8.1f} GB/s {r['frac']:.3f} {r['Gints']:8.1f} Gint/s" +
               (f"   bare stream {r['bare_GBps']:7.1f} GB/s -> {r['of_bare']:.3f} of it" if r.get("of_bare") else "") + (f"   [{r['placed']}]" if r.get("placed") else ""), flush=True)
         torch.cuda.empty_cache()
     if args.cases == "allwidths":
         print("# ---- summary: fraction of the 8 TB/s peak per (op, type) over all widths 1..T: min (at W) / median / max (at W)")
-        for op in ("unpack", "pack", "unfor_pack", "undelta_pack"):
+        for op in ALLWIDTH_OPS:
             for ty in ("u8", "u16", "u32", "u64"):
                 rows = sorted((r["frac"], r["w"]) for r in out if r["op"] == op and r["ty"] == ty)
                 ob = sorted((r["of_bare"], r["w"]) for r in out if r["op"] == op and r["ty"] == ty and r.get("of_bare"))
-                print(f"# {op:13s} {ty:4s} min {rows[0][0]:.3f} (W={rows[0][1]:<2d})  median {rows[len(rows) // 2][0]:.3f}  max {rows[-1][0]:.3f} (W={rows[-1][1]:<2d})" +
+                print(f"# {op:24s} {ty:4s} min {rows[0][0]:.3f} (W={rows[0][1]:<2d})  median {rows[len(rows) // 2][0]:.3f}  max {rows[-1][0]:.3f} (W={rows[-1][1]:<2d})" +
                       (f"   | of the bare stream of the same bytes on the same buffers: min {ob[0][0]:.3f} (W={ob[0][1]:<2d})  median {ob[len(ob) // 2][0]:.3f}" if ob else ""))
         worst = sorted(out, key=lambda r: r["frac"])[:8]
         print("# ---- the eight slowest (op, T, W): " + "; ".join(f"{r['op']} {r['ty']} W={r['w']} {r['frac']:.3f}" + (f" ({r['of_bare']:.2f} of its bare stream)" if r.get("of_bare") else "") for r in worst))
