@@ -29,9 +29,11 @@ counter-based stream regenerated on the host (`per_rank[i].correct`,
 Where a workload's buffers live in HBM moves the kernel by a few per cent (DESIGN.md
 section 4): the buffers come from the C ABI's own optional helper, fl_column_pair_alloc
 (include/fastlanes_amd.h), and --placement auto (default) is its FL_LAYOUT_PROBE: the LIBRARY
-allocates both layouts it knows, times a bare stream of the pair's read : write proportion on
-each before anything is filled, keeps the faster pair and reports both figures
-(`roofline.placement_probe_GBps`) -- a figure any user of the header can reproduce.  After
+allocates every layout it knows -- the one it CONSTRUCTS from measured 1-GiB chunks
+(FL_LAYOUT_INTERLEAVED, round 6), plain allocations, the 64-GiB-zoned slab --, times a bare
+stream of the pair's read : write proportion on each before anything is filled, keeps the
+fastest pair and reports every figure (`roofline.placement_probe_GBps`) -- figures any user of
+the header can reproduce.  After
 the checks a BARE STREAM of the workload's exact read : write mix is timed on the workload's
 own buffers (`roofline.bare_stream_GBps`, `roofline.frac_of_bare_stream`): box and
 placement cancel in that ratio, the kernel stays.
@@ -106,11 +108,13 @@ def parse():
                     help="control plane for the barrier / max-time reduction: auto = RCCL if every rank gets it working, "
                          "else gloo; nccl = the same (the fallback still applies, the line reports it); gloo = never try RCCL")
     ap.add_argument("--no-check", action="store_true", help="skip the per-rank oracle check of the timed output")
-    ap.add_argument("--placement", default="auto", choices=("auto", "zoned", "separate"),
+    ap.add_argument("--placement", default="auto", choices=("auto", "interleaved", "zoned", "separate"),
                     help="where a workload's buffers live in HBM moves every streaming kernel by a few per cent (DESIGN.md section 4). "
                          "The buffers come from fl_column_pair_alloc (include/fastlanes_amd.h).  auto (default) = FL_LAYOUT_PROBE: the library "
-                         "allocates both layouts below, times a bare stream on each before anything is filled and keeps the faster pair, "
-                         "both figures are reported (roofline.placement_probe_GBps); "
+                         "allocates every layout below, times a bare stream on each before anything is filled and keeps the fastest pair, "
+                         "every figure is reported (roofline.placement_probe_GBps); "
+                         "interleaved: constructed from 1-GiB physical chunks whose class of memory the library measures (input in one "
+                         "class, output alternating between the other two); "
                          "separate: one hipMalloc per buffer, wherever the driver puts it; "
                          "zoned: input and output carved from one allocation, the output centred on a 64-GiB multiple")
     ap.add_argument("--verify", default="auto", choices=("auto", "full", "sample"),
@@ -278,8 +282,9 @@ class Workload:
     def __init__(self, name, n, first_block, rank, dev, placement="separate"):
         """placement: the layout asked of fl_column_pair_alloc (include/fastlanes_amd.h) -- "separate" = one hipMalloc per buffer,
         wherever the driver puts them; "zoned" = input and output carved from ONE allocation, the input at offset 0, the output
-        centred on a 64-GiB multiple; "auto" = the library tries both, times a bare stream of in_bytes : out_bytes on each and keeps
-        the faster pair (self.probe = both figures) -- or "torch" = plain torch tensors (several ranks on one device)."""
+        centred on a 64-GiB multiple; "interleaved" = constructed from measured 1-GiB chunks; "auto" = the library tries all of them,
+        times a bare stream of in_bytes : out_bytes on each and keeps the fastest pair (self.probe = every figure) -- or "torch" = plain
+        torch tensors (several ranks on one device)."""
         import torch
         import fastlanes_amd as fl
         from fastlanes_amd import placement as pl
@@ -303,11 +308,12 @@ class Workload:
                 dst = torch.empty(out_bytes, dtype=torch.uint8, device=dev)
                 self.placement = "torch"
             else:
-                # through the C ABI's own helper (include/fastlanes_amd.h: fl_column_pair_alloc): "auto" = both layouts probed with a
-                # bare stream INSIDE the library, the faster pair kept -- before the buffers are filled
+                # through the C ABI's own helper (include/fastlanes_amd.h: fl_column_pair_alloc): "auto" = every layout probed with a
+                # bare stream INSIDE the library, the fastest pair kept -- before the buffers are filled
                 self.pair = pl.ColumnPair(in_bytes, out_bytes, dev, aux_bytes, layout=placement)
                 src, aux, dst = self.pair.input, self.pair.aux, self.pair.output
                 self.placement, self.probe = self.pair.layout, self.pair.probe_GBps
+                self.classes = self.pair.classes
             st = ctypes_stream(dev)
             self.src_seed, self.aux_seed = 1234 + rank, 99 + rank
             for t, seed in ((src, self.src_seed), (aux, self.aux_seed)):
@@ -771,15 +777,20 @@ PLACEMENT_TEXT = {
     "zoned": "fl_column_pair_alloc(FL_LAYOUT_ZONED): input and output carved from ONE allocation, the input at offset 0, the output centred "
              "on the 64-GiB multiple behind it (include/fastlanes_amd.h, DESIGN.md section 4)",
     "separate": "fl_column_pair_alloc(FL_LAYOUT_SEPARATE): one hipMalloc per buffer, wherever the driver puts it",
+    "interleaved": "fl_column_pair_alloc(FL_LAYOUT_INTERLEAVED): CONSTRUCTED from 1-GiB physical chunks (hipMemCreate / hipMemMap) whose class "
+                   "of memory the library measured -- the input inside one class, the output alternating between the other two "
+                   "(include/fastlanes_amd.h, DESIGN.md section 4)",
     "torch": "one torch allocation per buffer (several ranks share one device)",
 }
 
 
-def placement_text(placed, probe):
+def placement_text(placed, probe, classes=""):
     t = PLACEMENT_TEXT[placed]
+    if placed == "interleaved" and classes:
+        t += f"; measured class of every chunk, input first: {classes}"
     if probe:
         t += ("; chosen by fl_column_pair_alloc(FL_LAYOUT_PROBE) -- the library's own measurement, reproducible through the header alone: a "
-              "bare stream of the pair's read : write proportion on each layout before the buffers were filled, GB/s " +
+              "bare stream of the pair's read : write proportion on each candidate layout before the buffers were filled, GB/s " +
               ", ".join(f"{k} {v}" for k, v in probe.items()))
     return t
 
@@ -866,7 +877,7 @@ def config5_leg(args, world, rank, dev, ctl):
         release(w)
         return {"flags": flags}
     traffic = source = None
-    placed = w.placement
+    placed, classes = w.placement, getattr(w, "classes", "")
     bare = bare_stream(w)                    # after the checks (it overwrites the output), same buffers, same run
     release(w)                               # measured and checked (the PMC child builds its own copy of the column)
     if world == 1 and not args.no_pmc:
@@ -895,7 +906,7 @@ def config5_leg(args, world, rank, dev, ctl):
         "aggregate_GBps": round(sum(v[2] for v in per_rank) * args.steps / elapsed / 1e9, 1),
         "per_rank": ranks,
         "roofline_rank0": dict(roofline(w, kern_ms, traffic, source, bare), **({"placement_probe_GBps": probe} if probe else {})),
-        "placement": placement_text(placed, probe),
+        "placement": placement_text(placed, probe, classes),
         "correctness": check_text(flags, n_checked, verified),
         "flags": flags,
     }
@@ -968,7 +979,7 @@ def main():
     avg_ms = sum(kern_ms) / len(kern_ms)
     per_rank = ctl.gather([float(n), avg_ms, float(w.bytes)])
     flags, n_checked, verified = run_check(w, args, ctl)       # every rank, its own slice, outside the timed region
-    placed = w.placement
+    placed, classes = w.placement, getattr(w, "classes", "")
     bare = bare_stream(w) if rank == 0 else None     # after the checks (it overwrites the output), same buffers, same run
     release(w)                                       # leg 1 is measured and checked: its column can go
 
@@ -1033,7 +1044,7 @@ def main():
             "per_rank": ranks,
             "correctness": check_text(flags, n_checked, verified),
         }
-        out["config"]["placement"] = placement_text(placed, probe)
+        out["config"]["placement"] = placement_text(placed, probe, classes)
         if probe:
             out["roofline"]["placement_probe_GBps"] = probe
         out.update(control)

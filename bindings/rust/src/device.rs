@@ -157,8 +157,9 @@ impl_device_codec!(u32, fl_u32_unpack, fl_u32_pack, fl_u32_undelta_pack, fl_u32_
 impl_device_codec!(u64, fl_u64_unpack, fl_u64_pack, fl_u64_undelta_pack, fl_u64_unfor_pack, fl_u64_unpack_batch);
 
 /// The optional allocation helper of `fastlanes_amd.h` as an owner: a (read side, write side) buffer pair for a column, placed by
-/// measurement by default (`ffi::FL_LAYOUT_PROBE`: the library allocates both layouts it knows, times a bare read : write stream on
-/// each and keeps the faster pair -- synchronous, contents unspecified afterwards).  Never needed to use the codec: every call above
+/// measurement by default (`ffi::FL_LAYOUT_PROBE`: the library allocates every layout it knows -- the one constructed from measured 1-GiB
+/// chunks, `FL_LAYOUT_INTERLEAVED`, first --, times a bare read : write stream on each and keeps the fastest pair -- synchronous, contents
+/// unspecified afterwards).  Never needed to use the codec: every call above
 /// takes any 16-byte aligned device pointers.  (`fastlanes::ColumnPair` in `include/fastlanes_amd.hpp` is the compiled, GPU-tested twin.)
 pub struct ColumnPair<T> {
     handle: *mut c_void,
@@ -166,17 +167,17 @@ pub struct ColumnPair<T> {
     output: *mut T,
     in_len: usize,
     out_len: usize,
-    /// `ffi::FL_LAYOUT_SEPARATE` / `ffi::FL_LAYOUT_ZONED`: the layout that was kept
+    /// `ffi::FL_LAYOUT_SEPARATE` / `ffi::FL_LAYOUT_ZONED` / `ffi::FL_LAYOUT_INTERLEAVED`: the layout that was kept
     pub layout: i32,
     /// GB/s of the probe stream per layout (0 = not measured)
-    pub probe_gbps: [u32; 2],
+    pub probe_gbps: [u32; ffi::FL_LAYOUT_COUNT],
     _own: PhantomData<T>,
 }
 impl<T> ColumnPair<T> {
     /// `in_len` / `out_len` in ELEMENTS of `T`; `layout` one of `ffi::FL_LAYOUT_*`
     pub fn new(in_len: usize, out_len: usize, layout: i32, stream: Stream) -> Self {
         let (mut i, mut o, mut h) = (core::ptr::null_mut::<c_void>(), core::ptr::null_mut::<c_void>(), core::ptr::null_mut::<c_void>());
-        let (mut kept, mut gbps) = (-1i32, [0u32; 2]);
+        let (mut kept, mut gbps) = (-1i32, [0u32; ffi::FL_LAYOUT_COUNT]);
         ffi::check(
             unsafe {
                 ffi::fl_column_pair_alloc(in_len * size_of::<T>(), 0, out_len * size_of::<T>(), layout, stream.0, &mut i,
@@ -190,6 +191,10 @@ impl<T> ColumnPair<T> {
     pub fn input_mut(&mut self) -> DeviceSliceMut<'_, T> { unsafe { DeviceSliceMut::from_raw_parts(self.input, self.in_len) } }
     pub fn input(&self) -> DeviceSlice<'_, T> { unsafe { DeviceSlice::from_raw_parts(self.input as *const T, self.in_len) } }
     pub fn output_mut(&mut self) -> DeviceSliceMut<'_, T> { unsafe { DeviceSliceMut::from_raw_parts(self.output, self.out_len) } }
+    /// both sides at once (the two buffers never overlap): `let (packed, out) = pair.split(); codec.unpack(w, packed, out)`
+    pub fn split(&mut self) -> (DeviceSlice<'_, T>, DeviceSliceMut<'_, T>) {
+        unsafe { (DeviceSlice::from_raw_parts(self.input as *const T, self.in_len), DeviceSliceMut::from_raw_parts(self.output, self.out_len)) }
+    }
 }
 impl<T> Drop for ColumnPair<T> {
     fn drop(&mut self) {

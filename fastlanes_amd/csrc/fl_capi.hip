@@ -805,25 +805,275 @@ int fl_internal_bare_stream_shape(int op, unsigned type_bits, unsigned width, si
     return FL_OK;
 }
 
+// ---- the class of every piece of a stretch of device memory, by measurement (fastlanes_amd_internal.h: fl_internal_probe_memory_classes;
+// FL_LAYOUT_INTERLEAVED below) ---------------------------------------------------------------------------------------------------------
+namespace {
+// classes[g] = 0, 1, 2 (or -1: no clean answer) for the n pieces of `piece` bytes at `base`: unpack_compare u32 W=20 reads the start of a
+// representative piece and writes its 1/20 mask into piece g (at piece - min(piece / 2, 1 GiB)); the slow ones are of the
+// representative's class (7.0 TB/s across classes, 6.05 TB/s inside one: profiles/exp_region_map_r03.txt, profiles/r06_vmm_placement.txt)
+int probe_classes(char* base, size_t n, size_t piece, int* classes, hipStream_t s)
+{
+    constexpr unsigned PROBE_WIDTH = 20;
+    const size_t probe_blocks = std::min<size_t>(2000000, piece / (128 * PROBE_WIDTH));
+    const size_t mask_off = piece - std::min<size_t>(piece / 2, (size_t)1 << 30);
+    for (size_t g = 0; g < n; ++g) classes[g] = -1;
+    if (n == 0 || probe_blocks == 0) return FL_OK;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    hipError_t e = hipEventCreate(&t0);
+    if (e == hipSuccess) e = hipEventCreate(&t1);
+    int rc = e == hipSuccess ? FL_OK : hip_fail(e);
+    // milliseconds of the probe reading piece gi and writing into piece gm: median of 3 after one untimed launch
+    auto probe_ms = [&](size_t gi, size_t gm, float& ms) -> int {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(base + gi * piece);
+        uint32_t* mask = reinterpret_cast<uint32_t*>(base + gm * piece + mask_off);
+        float t[3] = {0.f, 0.f, 0.f};
+        for (int i = -1; i < 3; ++i) {
+            hipError_t h = hipEventRecord(t0, s);
+            if (h != hipSuccess) return hip_fail(h);
+            // under the whole-column tile map the class map was characterised with (a windowed read stream interferes less with the
+            // thin write stream, which is the point of the window and blunts the probe): an override for THIS THREAD's launches only --
+            // concurrent calls of other threads keep their own tile maps, and a concurrent fl_internal_set_kernel_policy is untouched
+            const int saved = fl::window_override_this_thread();
+            fl::window_override_this_thread() = fl::WINDOW_WHOLE;
+            const int r = fl_u32_unpack_compare(PROBE_WIDTH, src, FL_CMP_LT, 1u << (PROBE_WIDTH - 1), probe_blocks, mask, s);
+            fl::window_override_this_thread() = saved;
+            if (r != FL_OK) return r;
+            h = hipEventRecord(t1, s);
+            if (h == hipSuccess) h = hipEventSynchronize(t1);
+            float x = 0.f;
+            if (h == hipSuccess) h = hipEventElapsedTime(&x, t0, t1);
+            if (h != hipSuccess) return hip_fail(h);
+            if (i >= 0) t[i] = x;
+        }
+        std::sort(t, t + 3);
+        ms = t[1];
+        return FL_OK;
+    };
+    float threshold = 0.f;                                   // between the two levels, from the first representative
+    std::vector<float> ms(n);
+    for (int c = 0; c < 3 && rc == FL_OK; ++c) {
+        size_t rep = 0;
+        while (rep < n && classes[rep] != -1) ++rep;
+        if (rep == n) break;
+        classes[rep] = c;
+        rc = fl_fill_random(base + rep * piece, probe_blocks * 128 * PROBE_WIDTH, 17 + rep, s);   // full-entropy probe input
+        float slowest = 0.f, fastest = 1e30f;
+        size_t others = 0;
+        for (size_t g = 0; g < n && rc == FL_OK; ++g) {
+            if (classes[g] != -1) continue;
+            rc = probe_ms(rep, g, ms[g]);
+            slowest = std::max(slowest, ms[g]);
+            fastest = std::min(fastest, ms[g]);
+            ++others;
+        }
+        if (rc != FL_OK || others == 0) break;
+        if (threshold == 0.f) {
+            if (slowest - fastest <= 0.05f * slowest) break;     // one level only: "all of my class" and "none of it" look the same
+            threshold = 0.5f * (slowest + fastest);
+        }
+        for (size_t g = 0; g < n; ++g)
+            if (classes[g] == -1 && ms[g] > threshold) classes[g] = c;
+    }
+    if (t0) (void)hipEventDestroy(t0);
+    if (t1) (void)hipEventDestroy(t1);
+    return rc;
+}
+}  // namespace
+
+int fl_internal_probe_memory_classes(void* slab, size_t slab_bytes, int* classes, void* stream)
+{
+    const size_t n_granules = slab_bytes / FL_INTERNAL_GRANULE_BYTES;
+    if (n_granules == 0) return FL_OK;
+    if (!slab || !classes) return FL_ERR_NULL;
+    if (misaligned(slab)) return FL_ERR_ALIGN;
+    return probe_classes(static_cast<char*>(slab), n_granules, FL_INTERNAL_GRANULE_BYTES, classes, static_cast<hipStream_t>(stream));
+}
+
 // ---- fl_column_pair_alloc / _free: the OPTIONAL allocation helper of fastlanes_amd.h ------------------------------------------------
 namespace {
+constexpr size_t PAIR_ALIGN = 256, PAIR_ZONE = (size_t)64 << 30, PAIR_MIB = (size_t)1 << 20, PAIR_GIB = (size_t)1 << 30;
+inline size_t pair_pad(size_t b) { return (b + PAIR_ALIGN - 1) & ~(PAIR_ALIGN - 1); }
+
 struct ColumnPair {
     void* bufs[3] = {nullptr, nullptr, nullptr};       // separate: in, aux, out; zoned: the slab only
     void *in = nullptr, *aux = nullptr, *out = nullptr;
+    // FL_LAYOUT_INTERLEAVED: physical chunks (hipMemCreate) mapped into one reserved address range
+    std::vector<hipMemGenericAllocationHandle_t> chunks;
+    char* va = nullptr;
+    size_t va_bytes = 0, chunk_bytes = 0, n_mapped = 0;
+    char class_map[96] = {0};                            // 'A' 'B' 'C' '?' per mapped chunk (first 95), input first
     void release()
     {
         for (void*& b : bufs) {
             if (b) (void)hipFree(b);
             b = nullptr;
         }
+        for (size_t i = 0; i < n_mapped; ++i) (void)hipMemUnmap(va + i * chunk_bytes, chunk_bytes);
+        n_mapped = 0;
+        for (auto h : chunks) (void)hipMemRelease(h);
+        chunks.clear();
+        if (va) (void)hipMemAddressFree(va, va_bytes);
+        va = nullptr;
     }
 };
-constexpr size_t PAIR_ALIGN = 256, PAIR_ZONE = (size_t)64 << 30;
-inline size_t pair_pad(size_t b) { return (b + PAIR_ALIGN - 1) & ~(PAIR_ALIGN - 1); }
 
-hipError_t pair_alloc(int layout, size_t in_bytes, size_t aux_bytes, size_t out_bytes, ColumnPair& p)
+// Address ranges for FL_LAYOUT_INTERLEAVED.  On this ROCm (7.2) an address range that held a mapping, was unmapped and is mapped AGAIN --
+// even after hipMemAddressFree + hipMemAddressReserve -- keeps translating to the chunks it held FIRST (tools/exp_vmm remap,
+// profiles/r06_vmm_placement.txt): kernels would silently read and write memory that is no longer ours.  So no range is ever used twice
+// within a process: ranges are asked for at monotonically growing addresses of a private stretch of the address space (32 .. 64 TiB), and
+// whatever the runtime returns is checked against every range this library used before.
+std::atomic<uintptr_t> g_va_next{(uintptr_t)0x200000000000ull};
+constexpr uintptr_t VA_ARENA_END = (uintptr_t)0x400000000000ull;
+std::atomic_flag g_va_lock = ATOMIC_FLAG_INIT;
+std::vector<std::pair<uintptr_t, uintptr_t>> g_va_used;
+
+hipError_t reserve_fresh_range(size_t bytes, char** out)
 {
-    if (layout == FL_LAYOUT_SEPARATE) {
+    std::vector<void*> rejected;
+    hipError_t e = hipErrorOutOfMemory;
+    *out = nullptr;
+    for (int attempt = 0; attempt < 6 && !*out; ++attempt) {
+        const uintptr_t span = ((bytes + PAIR_GIB - 1) & ~(PAIR_GIB - 1)) + PAIR_GIB;
+        const uintptr_t hint = g_va_next.fetch_add(span, std::memory_order_relaxed);
+        if (hint + span > VA_ARENA_END) { e = hipErrorOutOfMemory; break; }
+        void* p = nullptr;
+        e = hipMemAddressReserve(&p, bytes, 2 * PAIR_MIB, reinterpret_cast<void*>(hint), 0);
+        if (e != hipSuccess) { (void)hipGetLastError(); continue; }
+        const uintptr_t lo = reinterpret_cast<uintptr_t>(p), hi = lo + bytes;
+        while (g_va_lock.test_and_set(std::memory_order_acquire)) {}
+        bool used = false;
+        for (const auto& r : g_va_used) used = used || (lo < r.second && r.first < hi);
+        if (!used) g_va_used.emplace_back(lo, hi);
+        g_va_lock.clear(std::memory_order_release);
+        if (used) { rejected.push_back(p); e = hipErrorOutOfMemory; }    // held until the end so that the runtime offers another one
+        else *out = static_cast<char*>(p);
+    }
+    for (void* p : rejected) (void)hipMemAddressFree(p, bytes);
+    return *out ? hipSuccess : e;
+}
+
+// which chunks of a classified pool form the pair: the input inside ONE class, the output alternating between the OTHER two in runs of
+// `run` chunks (reads together, writes spread, reads and writes apart: profiles/r06_vmm_placement.txt -- in A | out BC 0.864-0.866, out
+// ABC 0.860, out AB 0.855, out B 0.80, out A 0.78 of the peak at u32 W=7).  Falls back to creation order (short class runs by nature:
+// 0.854-0.861) when the probe saw one level only or no class can hold the input.
+void choose_chunks(const std::vector<int>& cls, size_t n_in, size_t n_out, size_t run, std::vector<int>& order)
+{
+    const size_t n = cls.size();
+    order.clear();
+    std::vector<int> by[4];                                    // 0..2 = classes, 3 = unclassified
+    for (size_t g = 0; g < n; ++g) by[cls[g] < 0 || cls[g] > 2 ? 3 : cls[g]].push_back((int)g);
+    int best_c = -1;
+    size_t best_score = 0;
+    for (int c = 0; c < 3; ++c) {
+        if (by[c].size() < n_in) continue;
+        const size_t a = by[(c + 1) % 3].size(), b = by[(c + 2) % 3].size();
+        const size_t balanced = std::min(std::min(a, b) * 2, n_out), others = std::min(a + b, n_out);
+        const size_t score = 2 * balanced + others + 1;
+        if (score > best_score) { best_score = score; best_c = c; }
+    }
+    if (best_c < 0 || by[(best_c + 1) % 3].size() + by[(best_c + 2) % 3].size() == 0) {
+        for (size_t g = 0; g < n_in + n_out && g < n; ++g) order.push_back((int)g);
+        return;
+    }
+    size_t next[4] = {0, 0, 0, 0};
+    for (size_t i = 0; i < n_in; ++i) order.push_back(by[best_c][next[best_c]++]);
+    int cur = (best_c + 1) % 3, other = (best_c + 2) % 3;
+    if (by[other].size() > by[cur].size()) std::swap(cur, other);
+    size_t in_run = 0;
+    while (order.size() < n_in + n_out) {
+        auto left = [&](int c) { return by[c].size() - next[c]; };
+        if (in_run >= run && left(other)) { std::swap(cur, other); in_run = 0; }
+        if (!left(cur)) {
+            if (left(other)) { std::swap(cur, other); in_run = 0; }
+            else if (left(3)) { order.push_back(by[3][next[3]++]); continue; }
+            else if (left(best_c)) { order.push_back(by[best_c][next[best_c]++]); continue; }
+            else break;
+        }
+        order.push_back(by[cur][next[cur]++]);
+        ++in_run;
+    }
+}
+
+hipError_t pair_alloc_interleaved(size_t in_bytes, size_t aux_bytes, size_t out_bytes, hipStream_t s, ColumnPair& p, int& rc)
+{
+    rc = FL_OK;
+    int dev = 0, vmm = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, dev);
+    if (e != hipSuccess) return e;
+    if (!vmm) return hipErrorNotSupported;
+    const size_t in_span = pair_pad(in_bytes) + pair_pad(aux_bytes), total = in_span + pair_pad(out_bytes);
+    const size_t chunk = total >= 8 * PAIR_GIB ? PAIR_GIB : 256 * PAIR_MIB;     // the probe needs >= 40 us of reading per piece to be binary
+    const size_t n_in = std::max<size_t>(1, (in_span + chunk - 1) / chunk), n_out = std::max<size_t>(1, (pair_pad(out_bytes) + chunk - 1) / chunk);
+    // enough chunks that a third of them holds the input and the other two thirds hold half the output each, + 30 % for uneven classes
+    size_t n_pool = std::max(3 * n_in, (3 * n_out + 1) / 2);
+    n_pool = std::max(n_pool + (3 * n_pool + 9) / 10, n_in + n_out);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 3 * PAIR_GIB) n_pool = std::min(n_pool, (free_b - 2 * PAIR_GIB) / chunk);
+    if (n_pool < n_in + n_out) return hipErrorOutOfMemory;
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    hipMemAccessDesc acc{};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    std::vector<hipMemGenericAllocationHandle_t> pool;
+    pool.reserve(n_pool);
+    for (size_t i = 0; i < n_pool; ++i) {
+        hipMemGenericAllocationHandle_t h;
+        if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
+        pool.push_back(h);
+    }
+    auto drop_pool = [&] { for (auto h : pool) (void)hipMemRelease(h); pool.clear(); };
+    if (pool.size() < n_in + n_out) { drop_pool(); return hipErrorOutOfMemory; }
+    // 1. every chunk's class, measured through a scratch address range (used once, never again)
+    std::vector<int> cls(pool.size(), -1);
+    char* scratch = nullptr;
+    e = reserve_fresh_range(pool.size() * chunk, &scratch);
+    if (e != hipSuccess) { drop_pool(); return e; }
+    size_t mapped = 0;
+    for (; mapped < pool.size() && e == hipSuccess; ++mapped) e = hipMemMap(scratch + mapped * chunk, chunk, 0, pool[mapped], 0);
+    if (e != hipSuccess) --mapped;
+    if (e == hipSuccess) e = hipMemSetAccess(scratch, pool.size() * chunk, &acc, 1);
+    if (e == hipSuccess) rc = probe_classes(scratch, pool.size(), chunk, cls.data(), s);
+    if (e == hipSuccess && rc == FL_OK) e = hipStreamSynchronize(s);
+    for (size_t i = 0; i < mapped; ++i) (void)hipMemUnmap(scratch + i * chunk, chunk);
+    (void)hipMemAddressFree(scratch, pool.size() * chunk);
+    if (e != hipSuccess || rc != FL_OK) { drop_pool(); return e; }
+    // 2. the pair's chunks in their final order, mapped ONCE into the address range the caller gets
+    std::vector<int> order;
+    choose_chunks(cls, n_in, n_out, std::max<size_t>(1, 2 * PAIR_GIB / chunk), order);
+    if (order.size() < n_in + n_out) { drop_pool(); return hipErrorOutOfMemory; }
+    std::vector<char> keep(pool.size(), 0);
+    for (int g : order) keep[g] = 1;
+    p.chunk_bytes = chunk;
+    p.va_bytes = order.size() * chunk;
+    e = reserve_fresh_range(p.va_bytes, &p.va);
+    for (size_t i = 0; i < order.size() && e == hipSuccess; ++i) {
+        e = hipMemMap(p.va + i * chunk, chunk, 0, pool[order[i]], 0);
+        if (e == hipSuccess) p.n_mapped = i + 1;
+    }
+    if (e == hipSuccess) e = hipMemSetAccess(p.va, p.va_bytes, &acc, 1);
+    for (size_t g = 0; g < pool.size(); ++g) {
+        if (keep[g]) p.chunks.push_back(pool[g]);
+        else (void)hipMemRelease(pool[g]);
+    }
+    pool.clear();
+    if (e != hipSuccess) { p.release(); return e; }
+    for (size_t i = 0; i < order.size() && i + 1 < sizeof p.class_map; ++i) p.class_map[i] = cls[order[i]] < 0 ? '?' : (char)('A' + cls[order[i]]);
+    p.in = p.va;
+    p.aux = aux_bytes ? p.va + pair_pad(in_bytes) : nullptr;
+    p.out = p.va + n_in * chunk;
+    return hipSuccess;
+}
+
+hipError_t pair_alloc(int layout, size_t in_bytes, size_t aux_bytes, size_t out_bytes, hipStream_t s, ColumnPair& p, int& rc)
+{
+    rc = FL_OK;
+    if (layout == FL_LAYOUT_INTERLEAVED && pair_pad(in_bytes) + pair_pad(aux_bytes) + pair_pad(out_bytes) >= 2 * PAIR_GIB)
+        return pair_alloc_interleaved(in_bytes, aux_bytes, out_bytes, s, p, rc);
+    if (layout == FL_LAYOUT_SEPARATE || layout == FL_LAYOUT_INTERLEAVED) {
         hipError_t e = hipMalloc(&p.bufs[0], in_bytes ? in_bytes : PAIR_ALIGN);
         if (e == hipSuccess && aux_bytes) e = hipMalloc(&p.bufs[1], aux_bytes);
         if (e == hipSuccess) e = hipMalloc(&p.bufs[2], out_bytes ? out_bytes : PAIR_ALIGN);
@@ -847,7 +1097,7 @@ hipError_t pair_alloc(int layout, size_t in_bytes, size_t aux_bytes, size_t out_
     return hipSuccess;
 }
 
-// GB/s of a bare stream in -> out over the pair (median of 5 after 2 untimed), in the proportion of the two sizes
+// GB/s of a bare stream in -> out over the pair (median of 5 after 2 untimed), in the proportion of the two sizes; 0 = not measured
 int pair_probe(const ColumnPair& p, size_t in_bytes, size_t aux_bytes, size_t out_bytes, hipStream_t s, double& gbps)
 {
     const size_t big = in_bytes > out_bytes ? in_bytes : out_bytes;
@@ -875,6 +1125,7 @@ int pair_probe(const ColumnPair& p, size_t in_bytes, size_t aux_bytes, size_t ou
     if (t1) (void)hipEventDestroy(t1);
     if (e != hipSuccess) return hip_fail(e);
     std::sort(ms, ms + 5);
+    if (!(ms[2] > 0.f)) return FL_OK;                           // a zero median: not measured
     gbps = (double)n_units * (a.in_unit + a.aux_unit + a.out_unit) / (ms[2] * 1e6);
     return FL_OK;
 }
@@ -884,30 +1135,42 @@ int fl_column_pair_alloc(size_t in_bytes, size_t aux_bytes, size_t out_bytes, in
                          void** handle, int* layout_kept, uint32_t* probe_gbps)
 {
     if (!in || !out || !handle || (aux_bytes && !aux)) return FL_ERR_NULL;
-    if (layout != FL_LAYOUT_SEPARATE && layout != FL_LAYOUT_ZONED && layout != FL_LAYOUT_PROBE) return FL_ERR_INDEX;
+    if (layout < 0 || layout >= FL_LAYOUT_COUNT) return FL_ERR_INDEX;
     FL_DEVICE_TIER(stream);                                  // FL_CHECK_DEVICE=1: `stream` must belong to the current device (the memory will)
+    hipStream_t s = static_cast<hipStream_t>(stream);
     *in = *out = *handle = nullptr;
     if (aux) *aux = nullptr;
-    if (probe_gbps) probe_gbps[0] = probe_gbps[1] = 0;
+    if (probe_gbps) for (int i = 0; i < FL_LAYOUT_COUNT; ++i) probe_gbps[i] = 0;
     ColumnPair* kept = new (std::nothrow) ColumnPair;
     if (!kept) return hip_fail(hipErrorOutOfMemory);
-    int kept_layout = layout;
+    int kept_layout = layout, rc = FL_OK;
+    const size_t biggest = in_bytes > out_bytes ? in_bytes : out_bytes;
+    if (layout == FL_LAYOUT_PROBE && biggest / 4096 < 1024) layout = kept_layout = FL_LAYOUT_SEPARATE;   // too small to time: nothing to choose
     if (layout != FL_LAYOUT_PROBE) {
-        if (hipError_t e = pair_alloc(layout, in_bytes, aux_bytes, out_bytes, *kept); e != hipSuccess) { delete kept; return hip_fail(e); }
+        if (hipError_t e = pair_alloc(layout, in_bytes, aux_bytes, out_bytes, s, *kept, rc); e != hipSuccess || rc != FL_OK) {
+            kept->release();
+            delete kept;
+            return rc != FL_OK ? rc : hip_fail(e);
+        }
     } else {
-        // both layouts (a candidate that cannot be allocated next to the one already held is skipped): a bare stream of the pair's
-        // read : write proportion is timed on each, the faster one is kept.  The contents of the buffers are whatever the stream left there.
+        // the candidates one after the other (one that cannot be allocated next to the pair already held is skipped): a bare stream of
+        // the pair's read : write proportion is timed on each; a later candidate replaces the kept one only if it wins by a margin
+        // (ZONED pins ~64 GiB: 2 %).  The contents of the buffers are whatever the stream left there.
         double best = -1.0;
         kept_layout = -1;
-        for (int cand = FL_LAYOUT_SEPARATE; cand <= FL_LAYOUT_ZONED; ++cand) {
+        const bool large = pair_pad(in_bytes) + pair_pad(aux_bytes) + pair_pad(out_bytes) >= 2 * PAIR_GIB;
+        for (int cand : {FL_LAYOUT_INTERLEAVED, FL_LAYOUT_SEPARATE, FL_LAYOUT_ZONED}) {
+            if (cand == FL_LAYOUT_INTERLEAVED && !large) continue;      // would be the SEPARATE candidate twice
             ColumnPair p;
-            if (pair_alloc(cand, in_bytes, aux_bytes, out_bytes, p) != hipSuccess) { (void)hipGetLastError(); continue; }
+            int prc = FL_OK;
+            if (pair_alloc(cand, in_bytes, aux_bytes, out_bytes, s, p, prc) != hipSuccess || prc != FL_OK) { (void)hipGetLastError(); p.release(); continue; }
             double gbps = 0.0;
-            if (const int rc = pair_probe(p, in_bytes, aux_bytes, out_bytes, static_cast<hipStream_t>(stream), gbps); rc != FL_OK) {
-                p.release(); kept->release(); delete kept; return rc;
+            if (const int r = pair_probe(p, in_bytes, aux_bytes, out_bytes, s, gbps); r != FL_OK) {
+                p.release(); kept->release(); delete kept; return r;
             }
             if (probe_gbps) probe_gbps[cand] = (uint32_t)(gbps + 0.5);
-            if (gbps > best) { kept->release(); *kept = p; best = gbps; kept_layout = cand; }
+            const double margin = cand == FL_LAYOUT_ZONED ? 1.02 : 1.01;
+            if (kept_layout < 0 || gbps > best * margin) { kept->release(); *kept = std::move(p); p = ColumnPair(); best = gbps; kept_layout = cand; }
             else p.release();
         }
         if (kept_layout < 0) { delete kept; return hip_fail(hipErrorOutOfMemory); }
@@ -929,78 +1192,9 @@ int fl_column_pair_free(void* handle)
     return FL_OK;
 }
 
-int fl_internal_probe_memory_classes(void* slab, size_t slab_bytes, int* classes, void* stream)
+const char* fl_internal_column_pair_classes(const void* handle)
 {
-    const size_t n_granules = slab_bytes / FL_INTERNAL_GRANULE_BYTES;
-    if (n_granules == 0) return FL_OK;
-    if (!slab || !classes) return FL_ERR_NULL;
-    if (misaligned(slab)) return FL_ERR_ALIGN;
-    // the probe: unpack_compare u32 W=20 on 2 M blocks -- 5.1 GB read from the start of one granule, 0.26 GB of mask written into
-    // the last GiB of another (7.0 TB/s across classes, 6.05 TB/s inside one: profiles/exp_region_map_r03.txt)
-    constexpr size_t PROBE_BLOCKS = 2000000;
-    constexpr unsigned PROBE_WIDTH = 20;
-    char* const base = static_cast<char*>(slab);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    for (size_t g = 0; g < n_granules; ++g) classes[g] = -1;
-    hipEvent_t t0 = nullptr, t1 = nullptr;
-    hipError_t e = hipEventCreate(&t0);
-    if (e == hipSuccess) e = hipEventCreate(&t1);
-    int rc = e == hipSuccess ? FL_OK : hip_fail(e);
-    // milliseconds of the probe reading granule gi and writing into granule gm: median of 3 after one untimed launch
-    auto probe_ms = [&](size_t gi, size_t gm, float& ms) -> int {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(base + gi * FL_INTERNAL_GRANULE_BYTES);
-        uint32_t* mask = reinterpret_cast<uint32_t*>(base + gm * FL_INTERNAL_GRANULE_BYTES + FL_INTERNAL_GRANULE_BYTES - ((size_t)1 << 30));
-        float t[3] = {0.f, 0.f, 0.f};
-        for (int i = -1; i < 3; ++i) {
-            hipError_t h = hipEventRecord(t0, s);
-            if (h != hipSuccess) return hip_fail(h);
-            // under the whole-column tile map the class map was characterised with (a windowed read stream interferes less with the
-            // thin write stream, which is the point of the window and blunts the probe): an override for THIS THREAD's launches only --
-            // concurrent calls of other threads keep their own tile maps, and a concurrent fl_internal_set_kernel_policy is untouched
-            const int saved = fl::window_override_this_thread();
-            fl::window_override_this_thread() = fl::WINDOW_WHOLE;
-            const int r = fl_u32_unpack_compare(PROBE_WIDTH, src, FL_CMP_LT, 1u << (PROBE_WIDTH - 1), PROBE_BLOCKS, mask, s);
-            fl::window_override_this_thread() = saved;
-            if (r != FL_OK) return r;
-            h = hipEventRecord(t1, s);
-            if (h == hipSuccess) h = hipEventSynchronize(t1);
-            float x = 0.f;
-            if (h == hipSuccess) h = hipEventElapsedTime(&x, t0, t1);
-            if (h != hipSuccess) return hip_fail(h);
-            if (i >= 0) t[i] = x;
-        }
-        std::sort(t, t + 3);
-        ms = t[1];
-        return FL_OK;
-    };
-    float threshold = 0.f;                                   // between the two levels, from the first representative
-    std::vector<float> ms(n_granules);
-    for (int c = 0; c < 3 && rc == FL_OK; ++c) {
-        size_t rep = 0;
-        while (rep < n_granules && classes[rep] != -1) ++rep;
-        if (rep == n_granules) break;
-        classes[rep] = c;
-        rc = fl_fill_random(base + rep * FL_INTERNAL_GRANULE_BYTES, PROBE_BLOCKS * 128 * PROBE_WIDTH, 17 + rep, s);   // full-entropy probe input
-        float slowest = 0.f, fastest = 1e30f;
-        size_t others = 0;
-        for (size_t g = 0; g < n_granules && rc == FL_OK; ++g) {
-            if (classes[g] != -1) continue;
-            rc = probe_ms(rep, g, ms[g]);
-            slowest = std::max(slowest, ms[g]);
-            fastest = std::min(fastest, ms[g]);
-            ++others;
-        }
-        if (rc != FL_OK || others == 0) break;
-        if (threshold == 0.f) {
-            if (slowest - fastest <= 0.05f * slowest) break;     // one level only: "all of my class" and "none of it" look the same
-            threshold = 0.5f * (slowest + fastest);
-        }
-        for (size_t g = 0; g < n_granules; ++g)
-            if (classes[g] == -1 && ms[g] > threshold) classes[g] = c;
-    }
-    if (t0) (void)hipEventDestroy(t0);
-    if (t1) (void)hipEventDestroy(t1);
-    return rc;
+    return handle ? static_cast<const ColumnPair*>(handle)->class_map : "";
 }
 
 void fl_mixed_plan_destroy(fl_mixed_plan* p)

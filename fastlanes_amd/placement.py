@@ -191,8 +191,9 @@ def consumer_pair(in_bytes, out_bytes, device, slab_bytes=128 << 30):
 # The C ABI's optional allocation helper (include/fastlanes_amd.h: fl_column_pair_alloc / _free), mirrored: what bench.py's
 # --placement auto uses since round 5, so that the figure it prints is one the header alone reproduces.
 # ---------------------------------------------------------------------------------------------------------------------------
-LAYOUTS = {"separate": 0, "zoned": 1, "auto": 2}
-LAYOUT_NAMES = {0: "separate", 1: "zoned"}
+LAYOUTS = {"separate": 0, "zoned": 1, "auto": 2, "interleaved": 3}
+LAYOUT_NAMES = {0: "separate", 1: "zoned", 3: "interleaved"}
+LAYOUT_COUNT = 4
 
 
 class _DeviceBytes:
@@ -204,10 +205,13 @@ class _DeviceBytes:
 
 class ColumnPair:
     """An (input, aux, output) triple of device buffers from fl_column_pair_alloc: `layout` "separate" (one allocation each), "zoned"
-    (one allocation, the output centred on a 64-GiB multiple) or "auto" (both tried, a bare stream of in_bytes : out_bytes timed on
-    each, the faster kept -- synchronous, contents unspecified).  .input / .aux / .output are uint8 torch tensors over the memory
-    (zero copy; they do NOT own it), .layout the layout kept, .probe_GBps {"separate": .., "zoned": ..} (auto only).  The memory is
-    released by .free() or when this object dies: keep it for as long as the tensors are in use."""
+    (one allocation, the output centred on a 64-GiB multiple: pins ~64 GiB), "interleaved" (round 6: built from 1-GiB physical chunks
+    whose class of memory was measured -- the input inside one class, the output alternating between the other two) or "auto" (every
+    candidate tried, a bare stream of in_bytes : out_bytes timed on each, the fastest kept -- synchronous, contents unspecified).
+    .input / .aux / .output are uint8 torch tensors over the memory (zero copy; they do NOT own it), .layout the layout kept,
+    .probe_GBps {"interleaved": .., "separate": .., "zoned": ..} (auto only), .classes the measured class of every chunk of an
+    interleaved pair ("AAAAAAAAABBCCBBCC..", input first).  The memory is released by .free() or when this object dies: keep it for as
+    long as the tensors are in use."""
 
     def __init__(self, in_bytes, out_bytes, device, aux_bytes=0, layout="auto", stream=None):
         import ctypes
@@ -217,7 +221,7 @@ class ColumnPair:
         P = ctypes.c_void_p
         i, a, o, h = P(), P(), P(), P()
         kept = ctypes.c_int(-1)
-        gbps = (ctypes.c_uint32 * 2)(0, 0)
+        gbps = (ctypes.c_uint32 * LAYOUT_COUNT)()
         dev = torch.device(device)
         with torch.cuda.device(dev):
             st = P(torch.cuda.current_stream(dev).cuda_stream) if stream is None else stream
@@ -228,7 +232,8 @@ class ColumnPair:
             raise FastLanesError(rc, "fl_column_pair_alloc")
         self._handle = h
         self.layout = LAYOUT_NAMES[kept.value]
-        self.probe_GBps = {LAYOUT_NAMES[k]: int(gbps[k]) for k in (0, 1) if gbps[k]} if layout == "auto" else None
+        self.probe_GBps = {LAYOUT_NAMES[k]: int(gbps[k]) for k in LAYOUT_NAMES if gbps[k]} if layout == "auto" else None
+        self.classes = (self._lib.fl_internal_column_pair_classes(h) or b"").decode()
 
         def view(ptr, nbytes):
             if not nbytes:

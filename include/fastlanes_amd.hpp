@@ -369,13 +369,13 @@ public:
     DeviceSlice<T> in() const { return in_; }
     DeviceSlice<T> aux() const { return aux_; }
     DeviceSlice<T> out() const { return out_; }
-    int layout() const { return layout_; }                                  // FL_LAYOUT_SEPARATE / FL_LAYOUT_ZONED: what was kept
-    std::uint32_t probe_gbps(int layout) const { return probe_gbps_[layout & 1]; }   // 0 = not measured
+    int layout() const { return layout_; }                                  // FL_LAYOUT_SEPARATE / _ZONED / _INTERLEAVED: what was kept
+    std::uint32_t probe_gbps(int layout) const { return layout >= 0 && layout < FL_LAYOUT_COUNT ? probe_gbps_[layout] : 0; }   // 0 = not measured
 private:
     void* handle_ = nullptr;
     DeviceSlice<T> in_, aux_, out_;
     int layout_ = -1;
-    std::uint32_t probe_gbps_[2] = {0, 0};
+    std::uint32_t probe_gbps_[FL_LAYOUT_COUNT] = {0, 0, 0, 0};
 };
 
 // The same loop with the per-block widths / byte offsets already resident in HBM:

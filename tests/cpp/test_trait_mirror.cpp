@@ -272,10 +272,10 @@ static void test_column_api()
         EXPECT(std::memcmp(one.data(), pk.data() + b * PL, PL * sizeof(T)) == 0);
     }
     // the same round trip inside buffers from the optional allocation helper (fl_column_pair_alloc), every layout
-    for (int layout : {FL_LAYOUT_SEPARATE, FL_LAYOUT_ZONED, FL_LAYOUT_PROBE}) {
+    for (int layout : {FL_LAYOUT_SEPARATE, FL_LAYOUT_ZONED, FL_LAYOUT_PROBE, FL_LAYOUT_INTERLEAVED}) {
         ColumnPair<T> pair(N * PL, N * 1024, 0, layout);
         EXPECT(pair.in().len == N * PL && pair.out().len == N * 1024 && pair.aux().ptr == nullptr);
-        EXPECT(pair.layout() == FL_LAYOUT_SEPARATE || pair.layout() == FL_LAYOUT_ZONED);
+        EXPECT(pair.layout() == FL_LAYOUT_SEPARATE || pair.layout() == FL_LAYOUT_ZONED || pair.layout() == FL_LAYOUT_INTERLEAVED);
         EXPECT(layout == FL_LAYOUT_PROBE || pair.layout() == layout);
         EXPECT(hipMemcpy(pair.in().ptr, dp.p, N * PL * sizeof(T), hipMemcpyDeviceToDevice) == hipSuccess);
         unpack_column<T>(W, DeviceSlice<const T>(pair.in()), pair.out());

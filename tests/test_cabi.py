@@ -33,7 +33,7 @@ def _header_symbols():
 def test_every_declared_symbol_is_exported(lib):
     import fastlanes_amd
     syms = _header_symbols()
-    assert len(syms) == 4 * 42 + 21
+    assert len(syms) == 4 * 42 + 22
     assert sorted(fastlanes_amd.exported_symbols()) == syms
     for s in syms:
         assert hasattr(lib, s), s
@@ -46,7 +46,8 @@ def test_column_pair_and_bare_stream_argument_checks_need_no_gpu(lib):
     kept = ctypes.c_int(-1)
     assert lib.fl_column_pair_alloc(1 << 20, 0, 1 << 20, 0, None, None, None, ctypes.byref(o), ctypes.byref(h), None, None) == 3   # FL_ERR_NULL
     assert lib.fl_column_pair_alloc(1 << 20, 128, 1 << 20, 0, None, ctypes.byref(i), None, ctypes.byref(o), ctypes.byref(h), None, None) == 3
-    assert lib.fl_column_pair_alloc(1 << 20, 0, 1 << 20, 3, None, ctypes.byref(i), None, ctypes.byref(o), ctypes.byref(h), ctypes.byref(kept), None) == 2
+    assert lib.fl_column_pair_alloc(1 << 20, 0, 1 << 20, 4, None, ctypes.byref(i), None, ctypes.byref(o), ctypes.byref(h), ctypes.byref(kept), None) == 2   # FL_LAYOUT_COUNT
+    assert lib.fl_column_pair_alloc(1 << 20, 0, 1 << 20, -1, None, ctypes.byref(i), None, ctypes.byref(o), ctypes.byref(h), ctypes.byref(kept), None) == 2
     assert lib.fl_column_pair_free(None) == 0
     Z, I = ctypes.c_size_t, ctypes.c_int
     iu, au, ou, nt, wv, wn, bpu = Z(), Z(), Z(), I(), I(), I(), ctypes.c_uint()

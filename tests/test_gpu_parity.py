@@ -1845,9 +1845,9 @@ def test_column_pair_alloc_and_the_bare_stream(fl, oracle):
     n, W = 20011, 7
     pk = values("u32", n * packed_len("u32", W), 9100)
     want = oracle.batch("unpack", "u32", W, pk)
-    for layout in ("separate", "zoned", "auto"):
+    for layout in ("separate", "zoned", "auto", "interleaved"):      # (a pair this small is plain allocations under "interleaved")
         pair = pl.ColumnPair(n * 128 * W, n * 4096, "cuda:0", aux_bytes=n * 128, layout=layout)
-        assert pair.layout in ("separate", "zoned") and (layout == "auto" or pair.layout == layout)
+        assert pair.layout in ("separate", "zoned", "interleaved") and (layout == "auto" or pair.layout == layout)
         for t, nb in ((pair.input, n * 128 * W), (pair.aux, n * 128), (pair.output, n * 4096)):
             assert t.numel() == nb and t.data_ptr() % 256 == 0 and t.device.index == 0
         if pair.layout == "zoned":       # input at the start, aux behind it, the output centred on the 64-GiB multiple
@@ -1888,6 +1888,55 @@ def test_column_pair_alloc_and_the_bare_stream(fl, oracle):
     assert lib.fl_internal_bare_stream(big.data_ptr(), 8192, None, 0, small.data_ptr(), 0, 1000, 1, 8, 31, None) == 0
     torch.cuda.synchronize()
     assert not small.any().item()
+
+
+@pytest.mark.parametrize("n_blocks", [500_000, 2_000_000])
+def test_interleaved_column_pair_is_constructed_from_measured_chunks(fl, oracle, n_blocks):
+    """FL_LAYOUT_INTERLEAVED (round 6): the pair is built from physical chunks (256 MiB below 8 GiB, 1 GiB above) whose class of memory
+    was measured; input + aux inside one class, the output alternating between the other two.  The codec decodes in it exactly as in
+    plain allocations (oracle on the blocks around every chunk boundary, the whole output against a plain-allocation decode), a second
+    pair never gets the first one's addresses (this ROCm keeps stale translations for re-used ranges: tools/exp_vmm remap), and
+    "auto" reports the constructed layout's figure next to the others."""
+    import torch
+    from fastlanes_amd import placement as pl
+    n, W = n_blocks, 7
+    ib, ob, ab = n * 128 * W, n * 4096, n * 128
+    chunk = (1 << 30) if ib + ab + ob >= (8 << 30) else (256 << 20)
+    g = torch.Generator(device="cuda:0").manual_seed(n)
+    pk = torch.randint(0, 1 << 31, (ib // 4,), dtype=torch.int32, device="cuda:0", generator=g).view(torch.uint32)
+    plain = fl.BitPacking.unpack(W, pk)
+    pairs = []
+    for rep in range(2):
+        pair = pl.ColumnPair(ib, ob, "cuda:0", aux_bytes=ab, layout="interleaved")
+        assert pair.layout == "interleaved" and pair.probe_GBps is None
+        n_out = -(-ob // chunk)
+        n_in = -(-(((ib + 255) // 256 * 256) + ((ab + 255) // 256 * 256)) // chunk)
+        assert len(pair.classes) == min(95, n_in + n_out), (pair.classes, n_in, n_out)
+        assert pair.output.data_ptr() - pair.input.data_ptr() == n_in * chunk and pair.aux.data_ptr() - pair.input.data_ptr() == (ib + 255) // 256 * 256
+        cin, cout = pair.classes[:n_in], pair.classes[n_in:]
+        if set(pair.classes) >= {"A", "B", "C"}:           # three classes seen: the construction the header promises
+            assert len(set(cin)) == 1 and cin[0] not in cout[:max(1, len(cout) * 2 // 3)], pair.classes
+            assert len(set(cout)) >= 2, pair.classes
+        pair.input.view(torch.uint32).copy_(pk)
+        pair.output.fill_(0xEE)
+        got = fl.BitPacking.unpack(W, pair.input.view(torch.uint32), output=pair.output.view(torch.uint32))
+        assert torch.equal(got, plain)
+        # the oracle on the blocks either side of every chunk boundary of the output, and of the input
+        edges = sorted({0, n - 1} | {min(n - 1, max(0, (k * chunk) // 4096 + d)) for k in range(1, n_out + 1) for d in (-1, 0)}
+                       | {min(n - 1, max(0, (k * chunk) // (128 * W) + d)) for k in range(1, n_in + 1) for d in (-1, 0, 1)})
+        host_pk = to_np(pk, "u32").reshape(n, 32 * W)
+        host_out = to_np(got, "u32").reshape(n, 1024)
+        want = oracle.batch("unpack", "u32", W, np.ascontiguousarray(host_pk[edges]).reshape(-1)).reshape(len(edges), 1024)
+        assert np.array_equal(host_out[edges], want)
+        pairs.append((pair.input.data_ptr(), pair.output.data_ptr() + ob))
+        pair.free()
+    (a0, a1), (b0, b1) = pairs
+    assert b0 >= a1 or b1 <= a0, "an interleaved pair re-used a freed pair's addresses"
+    auto = pl.ColumnPair(ib, ob, "cuda:0", layout="auto")
+    assert "interleaved" in auto.probe_GBps and "separate" in auto.probe_GBps and all(v > 1000 for v in auto.probe_GBps.values())
+    best = max(auto.probe_GBps.values())
+    assert auto.probe_GBps[auto.layout] >= 0.98 * best / 1.02, (auto.layout, auto.probe_GBps)
+    auto.free()
 
 
 def test_zero_copy_host_calls_under_load_never_fall_back(fl, oracle):
