@@ -952,45 +952,64 @@ hipError_t reserve_fresh_range(size_t bytes, char** out)
     return *out ? hipSuccess : e;
 }
 
-// which chunks of a classified pool form the pair: the input inside ONE class, the output alternating between the OTHER two in runs of
+// which chunks of a classified pool form the pair: the input inside ONE class, the output spread EVENLY over the other two in runs of
 // `run` chunks (reads together, writes spread, reads and writes apart: profiles/r06_vmm_placement.txt -- in A | out BC 0.864-0.866, out
-// ABC 0.860, out AB 0.855, out B 0.80, out A 0.78 of the peak at u32 W=7).  Falls back to creation order (short class runs by nature:
-// 0.854-0.861) when the probe saw one level only or no class can hold the input.
+// ABC 0.860, out AB 0.855, out B 0.80, out A 0.78 of the peak at u32 W=7).  Where the other two classes cannot cover the output, left-over
+// chunks of the input's class (then unclassified ones) join the rotation -- every stretch of the output still mixes classes, which is what
+// the eight XCDs' concurrent write positions need.  Falls back to creation order (short class runs by nature: 0.854-0.861) when the
+// probe saw one level only or no class can hold the input.
 void choose_chunks(const std::vector<int>& cls, size_t n_in, size_t n_out, size_t run, std::vector<int>& order)
 {
     const size_t n = cls.size();
     order.clear();
     std::vector<int> by[4];                                    // 0..2 = classes, 3 = unclassified
     for (size_t g = 0; g < n; ++g) by[cls[g] < 0 || cls[g] > 2 ? 3 : cls[g]].push_back((int)g);
+    // quota[k] = how many output chunks come from source k for input class c; sources: the two other classes, c's left-overs, unclassified
+    auto quotas = [&](int c, size_t q[4], int src[4]) {
+        src[0] = (c + 1) % 3; src[1] = (c + 2) % 3; src[2] = c; src[3] = 3;
+        if (by[src[1]].size() > by[src[0]].size()) std::swap(src[0], src[1]);
+        const size_t a = by[src[0]].size(), b = by[src[1]].size(), l = by[c].size() - n_in, u = by[3].size();
+        q[1] = std::min(b, n_out / 2);                              // the scarcer of the two, at most half
+        q[0] = std::min(a, n_out - q[1]);
+        q[1] = std::min(b, n_out - q[0]);
+        size_t rest = n_out - q[0] - q[1];
+        q[2] = std::min(l, rest);
+        q[3] = std::min(u, rest - q[2]);
+        return q[0] + q[1] + q[2] + q[3] == n_out;
+    };
     int best_c = -1;
     size_t best_score = 0;
     for (int c = 0; c < 3; ++c) {
         if (by[c].size() < n_in) continue;
-        const size_t a = by[(c + 1) % 3].size(), b = by[(c + 2) % 3].size();
-        const size_t balanced = std::min(std::min(a, b) * 2, n_out), others = std::min(a + b, n_out);
-        const size_t score = 2 * balanced + others + 1;
+        size_t q[4];
+        int src[4];
+        if (!quotas(c, q, src)) continue;
+        // first: how much of the output does NOT come from its dominant source (what can alternate); then: how much avoids the input's class
+        const size_t score = 4 * (n_out - std::max(std::max(q[0], q[1]), std::max(q[2], q[3]))) + (q[0] + q[1]) + 1;
         if (score > best_score) { best_score = score; best_c = c; }
     }
-    if (best_c < 0 || by[(best_c + 1) % 3].size() + by[(best_c + 2) % 3].size() == 0) {
+    size_t q[4] = {0, 0, 0, 0};
+    int src[4] = {0, 1, 2, 3};
+    if (best_c >= 0) quotas(best_c, q, src);
+    if (best_c < 0) {                                           // no class can hold the input: as created
         for (size_t g = 0; g < n_in + n_out && g < n; ++g) order.push_back((int)g);
         return;
     }
     size_t next[4] = {0, 0, 0, 0};
     for (size_t i = 0; i < n_in; ++i) order.push_back(by[best_c][next[best_c]++]);
-    int cur = (best_c + 1) % 3, other = (best_c + 2) % 3;
-    if (by[other].size() > by[cur].size()) std::swap(cur, other);
-    size_t in_run = 0;
-    while (order.size() < n_in + n_out) {
-        auto left = [&](int c) { return by[c].size() - next[c]; };
-        if (in_run >= run && left(other)) { std::swap(cur, other); in_run = 0; }
-        if (!left(cur)) {
-            if (left(other)) { std::swap(cur, other); in_run = 0; }
-            else if (left(3)) { order.push_back(by[3][next[3]++]); continue; }
-            else if (left(best_c)) { order.push_back(by[best_c][next[best_c]++]); continue; }
-            else break;
+    // even spreading, `run` chunks at a time: the source furthest behind its share of the output so far goes next
+    size_t used[4] = {0, 0, 0, 0}, placed = 0;
+    while (placed < n_out) {
+        int k_best = -1;
+        double lag_best = -1e300;
+        for (int k = 0; k < 4; ++k) {
+            if (used[k] >= q[k]) continue;
+            const double lag = (double)q[k] * (double)(placed + run) / (double)n_out - (double)used[k];
+            if (lag > lag_best) { lag_best = lag; k_best = k; }
         }
-        order.push_back(by[cur][next[cur]++]);
-        ++in_run;
+        if (k_best < 0) break;
+        for (size_t r = 0; r < run && used[k_best] < q[k_best] && placed < n_out; ++r, ++used[k_best], ++placed)
+            order.push_back(by[src[k_best]][next[src[k_best]]++]);
     }
 }
 
@@ -1005,9 +1024,9 @@ hipError_t pair_alloc_interleaved(size_t in_bytes, size_t aux_bytes, size_t out_
     const size_t in_span = pair_pad(in_bytes) + pair_pad(aux_bytes), total = in_span + pair_pad(out_bytes);
     const size_t chunk = total >= 8 * PAIR_GIB ? PAIR_GIB : 256 * PAIR_MIB;     // the probe needs >= 40 us of reading per piece to be binary
     const size_t n_in = std::max<size_t>(1, (in_span + chunk - 1) / chunk), n_out = std::max<size_t>(1, (pair_pad(out_bytes) + chunk - 1) / chunk);
-    // enough chunks that a third of them holds the input and the other two thirds hold half the output each, + 30 % for uneven classes
-    size_t n_pool = std::max(3 * n_in, (3 * n_out + 1) / 2);
-    n_pool = std::max(n_pool + (3 * n_pool + 9) / 10, n_in + n_out);
+    // enough chunks that a third of them holds the input and the other two thirds hold half the output each -- and twice the pair, because
+    // the classes come in clusters of 4 .. 16 chunks (profiles/r06_vmm_placement.txt): a pool of just the pair's size often lacks one class
+    size_t n_pool = std::max(std::max(3 * n_in, (3 * n_out + 1) / 2), 2 * (n_in + n_out));
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 3 * PAIR_GIB) n_pool = std::min(n_pool, (free_b - 2 * PAIR_GIB) / chunk);
     if (n_pool < n_in + n_out) return hipErrorOutOfMemory;

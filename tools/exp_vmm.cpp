@@ -886,6 +886,21 @@ int main(int argc, char** argv)
         CK(hipMemAddressFree(big, span + extra));
         fflush(stdout);
     }
+    if (getenv("EXP_LIBRARY_PAIR")) {                           // the product's own constructed pair, next to this tool's layouts
+        for (int rep = 0; rep < 2; ++rep) {
+            void *li = nullptr, *la = nullptr, *lo = nullptr, *lh = nullptr;
+            int kept = -1;
+            FL(fl_column_pair_alloc(in_bytes, 0, out_bytes, FL_LAYOUT_INTERLEAVED, nullptr, &li, &la, &lo, &lh, &kept, nullptr));
+            fill_in(li);
+            double k, s2;
+            run(li, lo, k, s2);
+            printf("fl_column_pair_alloc(FL_LAYOUT_INTERLEAVED), pool still held by this tool: %5.0f (%.3f) stream %5.0f  classes %s\n", k, k / 8000, s2,
+                   fl_internal_column_pair_classes(lh));
+            CK(hipDeviceSynchronize());
+            FL(fl_column_pair_free(lh));
+        }
+        fflush(stdout);
+    }
     printf("%-40s %s\n", "layout (classes by chunk; /n = run length)", "kernel GB/s (of 8 TB/s) per round | bare stream GB/s per round");
     for (size_t li = 0; li < res.size(); ++li) {
         const char* name = li < layouts.size() ? layouts[li].name.c_str() : li == layouts.size() ? "creation order (VMM, no choice)" : "two hipMallocs";
