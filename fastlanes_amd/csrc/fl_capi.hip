@@ -892,6 +892,7 @@ int fl_internal_probe_memory_classes(void* slab, size_t slab_bytes, int* classes
 // ---- fl_column_pair_alloc / _free: the OPTIONAL allocation helper of fastlanes_amd.h ------------------------------------------------
 namespace {
 constexpr size_t PAIR_ALIGN = 256, PAIR_ZONE = (size_t)64 << 30, PAIR_MIB = (size_t)1 << 20, PAIR_GIB = (size_t)1 << 30;
+constexpr size_t PAIR_INTERLEAVED_MIN = 8 * PAIR_GIB;       // below that a pair is a handful of chunks: nothing to arrange
 inline size_t pair_pad(size_t b) { return (b + PAIR_ALIGN - 1) & ~(PAIR_ALIGN - 1); }
 
 struct ColumnPair {
@@ -1022,11 +1023,12 @@ hipError_t pair_alloc_interleaved(size_t in_bytes, size_t aux_bytes, size_t out_
     if (e != hipSuccess) return e;
     if (!vmm) return hipErrorNotSupported;
     const size_t in_span = pair_pad(in_bytes) + pair_pad(aux_bytes), total = in_span + pair_pad(out_bytes);
-    const size_t chunk = total >= 8 * PAIR_GIB ? PAIR_GIB : 256 * PAIR_MIB;     // the probe needs >= 40 us of reading per piece to be binary
+    const size_t chunk = PAIR_GIB;        // the class probe reads a whole piece: 0.17 ms per GiB is cleanly binary, 256-MiB pieces (45 us) are not
     const size_t n_in = std::max<size_t>(1, (in_span + chunk - 1) / chunk), n_out = std::max<size_t>(1, (pair_pad(out_bytes) + chunk - 1) / chunk);
     // enough chunks that a third of them holds the input and the other two thirds hold half the output each -- and twice the pair, because
     // the classes come in clusters of 4 .. 16 chunks (profiles/r06_vmm_placement.txt): a pool of just the pair's size often lacks one class
-    size_t n_pool = std::max(std::max(3 * n_in, (3 * n_out + 1) / 2), 2 * (n_in + n_out));
+    // ... and never less than 48 GiB of them: a small pair's pool would otherwise lie inside one or two clusters
+    size_t n_pool = std::max(std::max(std::max(3 * n_in, (3 * n_out + 1) / 2), 2 * (n_in + n_out)), 48 * PAIR_GIB / chunk);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 3 * PAIR_GIB) n_pool = std::min(n_pool, (free_b - 2 * PAIR_GIB) / chunk);
     if (n_pool < n_in + n_out) return hipErrorOutOfMemory;
@@ -1090,7 +1092,7 @@ hipError_t pair_alloc_interleaved(size_t in_bytes, size_t aux_bytes, size_t out_
 hipError_t pair_alloc(int layout, size_t in_bytes, size_t aux_bytes, size_t out_bytes, hipStream_t s, ColumnPair& p, int& rc)
 {
     rc = FL_OK;
-    if (layout == FL_LAYOUT_INTERLEAVED && pair_pad(in_bytes) + pair_pad(aux_bytes) + pair_pad(out_bytes) >= 2 * PAIR_GIB)
+    if (layout == FL_LAYOUT_INTERLEAVED && pair_pad(in_bytes) + pair_pad(aux_bytes) + pair_pad(out_bytes) >= PAIR_INTERLEAVED_MIN)
         return pair_alloc_interleaved(in_bytes, aux_bytes, out_bytes, s, p, rc);
     if (layout == FL_LAYOUT_SEPARATE || layout == FL_LAYOUT_INTERLEAVED) {
         hipError_t e = hipMalloc(&p.bufs[0], in_bytes ? in_bytes : PAIR_ALIGN);
@@ -1177,7 +1179,7 @@ int fl_column_pair_alloc(size_t in_bytes, size_t aux_bytes, size_t out_bytes, in
         // (ZONED pins ~64 GiB: 2 %).  The contents of the buffers are whatever the stream left there.
         double best = -1.0;
         kept_layout = -1;
-        const bool large = pair_pad(in_bytes) + pair_pad(aux_bytes) + pair_pad(out_bytes) >= 2 * PAIR_GIB;
+        const bool large = pair_pad(in_bytes) + pair_pad(aux_bytes) + pair_pad(out_bytes) >= PAIR_INTERLEAVED_MIN;
         for (int cand : {FL_LAYOUT_INTERLEAVED, FL_LAYOUT_SEPARATE, FL_LAYOUT_ZONED}) {
             if (cand == FL_LAYOUT_INTERLEAVED && !large) continue;      // would be the SEPARATE candidate twice
             ColumnPair p;

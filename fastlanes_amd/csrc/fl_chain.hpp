@@ -60,10 +60,13 @@ struct ChainArgs {
 // c = 0..7, same rows) fall into 8 distinct 16-byte slots of the 128-byte bank window.
 template <typename T> struct OriginalImage {
     static constexpr unsigned BLOCK_BYTES = WaveBlock<T>::BLOCK_BYTES;
-    // u8 / u16 gather single elements (below) and keep the image linear
+    // u8 / u16 gather elements (below).  u16: +16 bytes per KiB -- a lane group's gather reads dword 32k + 4 FL_ORDER[c/2] + i of KiB
+    // c%2 (k = element, c = cell column, i = lane group): the two KiB would share every bank (2-way conflict on each of the reads,
+    // 38 % of the LDS time of transpose_delta_pack u16 in round 5: profiles/r05_sq_mixed_final.txt); 4 dwords apart they interleave.
+    // u8 keeps the image linear (its lanes read bytes of shared dwords).
     __host__ __device__ static constexpr unsigned pad(unsigned a)
     {
-        return sizeof(T) == 4 ? a + 16u * (a >> 7) + 32u * (a >> 10) : sizeof(T) == 8 ? a + 16u * (a >> 10) : a;
+        return sizeof(T) == 4 ? a + 16u * (a >> 7) + 32u * (a >> 10) : sizeof(T) == 8 ? a + 16u * (a >> 10) : sizeof(T) == 2 ? a + 16u * (a >> 10) : a;
     }
     static constexpr unsigned BYTES = (pad(BLOCK_BYTES - 16u) + 16u + 255u) & ~255u;
     // byte offset (unpadded) of the original-order cell holding rows [n*q, n*q+n) of FL lane l  (transpose.rs:29-36 inverted)
@@ -77,6 +80,9 @@ template <typename T> struct OriginalImage {
 // The transposition is done by the LDS itself: 16 single-element reads per lane per block, each element fetched from where
 // the OTHER layout keeps it, packed into the cell.
 //   original position p of the block  <->  (FL lane l, row r):  p = lane_base(l) + r  (transpose.rs:29-36; runs of T rows)
+// (The rows image a u16 block is GATHERED from, SNK_ORIGINAL, has the same 2-way conflict -- lanes o and o + 1 read rows k and k + 8,
+// 128 bytes apart -- but padding it (+16 bytes per 128-byte row) LOST 3 .. 9 % on undelta_pack_untranspose u16, uniform and mixed widths:
+// profiles/r06_ab_u16_chain.txt; the padded ds_write_b128 of the rows costs more than the gathers' conflicts.  It stays linear.)
 template <typename T> __device__ __forceinline__ unsigned rows_image_byte_of_position(unsigned p)
 {
     constexpr unsigned TB = sizeof(T) * 8;
@@ -104,13 +110,26 @@ template <typename T> __device__ __forceinline__ Cell<T> gather_original_cell(co
     for (int k = 0; k < N; ++k) e[k] = *reinterpret_cast<const T*>(lds_rows + rows_image_byte_of_position<T>(N * o + k));
     return pack_elements<T>(e);
 }
-// cell (logical row r, lane group c) of the TRANSPOSED rows, gathered from the linear LDS image of the original order
+// cell (logical row r, lane group c) of the TRANSPOSED rows, gathered from the LDS image of the original order
 template <typename T> __device__ __forceinline__ Cell<T> gather_row_cell(const char* lds_original, unsigned r, unsigned c)
 {
     constexpr int N = 16 / (int)sizeof(T);
     uint32_t e[N];
-    for (int k = 0; k < N; ++k) e[k] = *reinterpret_cast<const T*>(lds_original + (lane_base(N * c + k) + r) * (unsigned)sizeof(T));
+    for (int k = 0; k < N; ++k) e[k] = *reinterpret_cast<const T*>(lds_original + OriginalImage<T>::pad((lane_base(N * c + k) + r) * (unsigned)sizeof(T)));
     return pack_elements<T>(e);
+}
+// u16: a lane's TWO rows r0 (even), r0 + 1 of cell column c at once -- along an FL lane the rows are consecutive in the original
+// order (tau(index(r, l)) = lane_base(l) + r), so one 32-bit read per FL lane fetches both rows' elements: 8 reads instead of 16,
+// the halves sorted into the two cells by v_perm
+__device__ __forceinline__ void gather_row_pair_cells(const char* lds_original, unsigned r0, unsigned c, Cell<uint16_t>& lo, Cell<uint16_t>& hi)
+{
+    uint32_t e[8];
+    for (int k = 0; k < 8; ++k)
+        e[k] = *reinterpret_cast<const uint32_t*>(lds_original + OriginalImage<uint16_t>::pad((lane_base(8u * c + k) + r0) * 2u));
+    for (int m = 0; m < 4; ++m) {
+        lo.x[m] = __builtin_amdgcn_perm(e[2 * m + 1], e[2 * m], 0x05040100u);     // low halves:  e[2m].lo | e[2m+1].lo << 16
+        hi.x[m] = __builtin_amdgcn_perm(e[2 * m + 1], e[2 * m], 0x07060302u);     // high halves: e[2m].hi | e[2m+1].hi << 16
+    }
 }
 
 // bytes of LDS one wavefront needs for a (source, sink) pair
@@ -222,7 +241,9 @@ __device__ __forceinline__ void chain_stage_source(const ChainArgs& a, uint64_t 
     } else {
         static_for<G::GROUPS>([&](auto Gi) {
             constexpr int g = decltype(Gi)::value;
-            if (8u * g < w_in) dma_1k_to_lds<DMA ? RD : 0, g * 1024>(in_rs, lds, lane);
+            // (the instruction offset advances the memory and the LDS side alike: a padded image shifts the LDS base instead)
+            constexpr unsigned shift = SRC == SRC_ORIGINAL ? OriginalImage<T>::pad(g * 1024u) - g * 1024u : 0u;
+            if (8u * g < w_in) dma_1k_to_lds<DMA ? RD : 0, g * 1024>(in_rs, lds + shift, lane);
         });
         if constexpr (BODY != CHAIN_NONE)
             base = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(a.bases + blk * 128u + c16 + opaque_zero()));
@@ -259,6 +280,8 @@ __device__ __forceinline__ void chain_stage_rows(unsigned w, const char* lds, un
         static_for<R>([&](auto J) {
             x[decltype(J)::value] = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(lds + G::row_cell_rt(r0 + decltype(J)::value) * 16u + c16));
         });
+    } else if constexpr (sizeof(T) == 2) {
+        gather_row_pair_cells(lds, r0, c, x[0], x[1]);                                                                  // transpose.rs:12-14
     } else if constexpr (sizeof(T) < 4) {
         static_for<R>([&](auto J) { x[decltype(J)::value] = gather_row_cell<T>(lds, r0 + decltype(J)::value, c); });   // transpose.rs:12-14
     } else {
@@ -427,7 +450,8 @@ __device__ __forceinline__ void chain_blocks_lockstep(const ChainArgs& a, uint64
             const unsigned w_in = SRC == SRC_PACKED ? w[j] : (unsigned)G::TB;
             static_for<G::GROUPS>([&](auto Gi) {
                 constexpr int g = decltype(Gi)::value;
-                if (8u * g < w_in) dma_1k_to_lds<RD_DMA_NT, g * 1024>(in_rs, lds + j * WAVE_LDS, lane);
+                constexpr unsigned shift = SRC == SRC_ORIGINAL ? OriginalImage<T>::pad(g * 1024u) - g * 1024u : 0u;
+                if (8u * g < w_in) dma_1k_to_lds<RD_DMA_NT, g * 1024>(in_rs, lds + j * WAVE_LDS + shift, lane);
             });
         }
     });

@@ -471,6 +471,14 @@ __device__ __forceinline__ void pack_narrow_from_lds_image(char* lds, unsigned w
     __builtin_amdgcn_raw_buffer_store_b128(out, rs, lane * 16u, 0, STORE_AUX);   // cells past 128*w bytes are dropped by the descriptor
 }
 
+// ceil(2^20 / w): floor(n / w) = (n * RECIP20[w]) >> 20 for every n < 4160 and w >= 8 (the error term n * (RECIP20[w] * w - 2^20) / (2^20 * w)
+// stays below 1/252 < 1/w) -- a lane's row index without an integer division (two ~12-instruction sequences per packed word otherwise)
+__device__ constexpr uint32_t RECIP20[65] = {
+    0,      1048576, 524288, 349526, 262144, 209716, 174763, 149797, 131072, 116509, 104858, 95326, 87382, 80660, 74899, 69906, 65536,
+    61681,  58255,   55189,  52429,  49933,  47663,  45591,  43691,  41944,  40330,  38837, 37450, 36158, 34953, 33826, 32768,
+    31776,  30841,   29960,  29128,  28340,  27595,  26887,  26215,  25576,  24967,  24386, 23832, 23302, 22796, 22311, 21846,
+    21400,  20972,   20561,  20165,  19785,  19419,  19066,  18725,  18397,  18079,  17773, 17477, 17190, 16913, 16645, 16384};
+
 template <typename T>
 __device__ __forceinline__ void pack_from_lds_image(char* lds, unsigned w, char* packed_block, unsigned lane)
 {
@@ -483,13 +491,14 @@ __device__ __forceinline__ void pack_from_lds_image(char* lds, unsigned w, char*
     }
     const unsigned c16 = (lane & 7u) * 16u, i = lane >> 3;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(packed_block, 0, 128u * w, 0x00020000);
+    const uint32_t recip = RECIP20[w];                        // wave-uniform
     for (unsigned m8 = 0; m8 < w; m8 += 8) {                  // wave-uniform trip count: ceil(w/8) groups of 8 packed rows
         const unsigned wd = m8 + i;                           // this lane's packed word-row
         Cell<T> acc = Cell<T>::zero();
         if (wd < w) {
             const unsigned lo_bit = wd * TB;
-            unsigned r = lo_bit / w;                          // first row with bits in this word
-            const unsigned r_end = (lo_bit + TB - 1u) / w;    // last such row (inclusive)
+            unsigned r = (lo_bit * recip) >> 20;              // = lo_bit / w: first row with bits in this word
+            const unsigned r_end = ((lo_bit + TB - 1u) * recip) >> 20;   // last such row (inclusive)
             for (; r <= r_end; ++r) {
                 const Cell<T> s = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(lds + G::row_cell_rt(r) * 16u + c16));
                 const unsigned fb = r * w;                    // first stream bit of row r's field

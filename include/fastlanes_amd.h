@@ -141,7 +141,7 @@ int fl_fill_random(void *dst, size_t n_bytes, uint64_t seed, void *stream);
  *                          class), `in` (and `aux`) get chunks of one class, `out` alternates between the other two in 2-GiB runs, the
  *                          rest is released.  u32 W=7 unpack at 10 M blocks: 0.864-0.866 of the 8 TB/s on every box, where two hipMallocs
  *                          give anything from 0.78 (both buffers in one class) to 0.86.  Transient cost: up to ~1.5 x the pair for a
- *                          second or so; pairs below 2 GiB are allocated as FL_LAYOUT_SEPARATE (placement does not matter there);
+ *                          second or so; pairs below 8 GiB are allocated as FL_LAYOUT_SEPARATE (a handful of chunks: nothing to arrange);
  *                          FL_ERR_HIP with hipErrorNotSupported where the device has no virtual-memory management.
  *   FL_LAYOUT_PROBE        the candidates are allocated one after the other -- INTERLEAVED, SEPARATE, and ZONED where its slab still fits --
  *                          a bare read/write stream of in_bytes : out_bytes (no codec work; fl_stream.hpp) is timed on each for a few

@@ -5,7 +5,9 @@ consumers, occupancy of the narrow types' cell-column kernels).
     python tools/ablibs.py <rounds> <ops> <cases> lib_a.so lib_b.so ...
       ops    comma list of: unpack pack undelta_pack undelta_pack_untranspose undelta compare sums   (undelta ignores the width)
       cases  comma list of type:width, e.g. u8:3,u8:6,u16:3   (or "consumers" = round 3's consumer sweep)
-      ops    also: unpack_widths (the width of the case is ignored: width[b] = 1 + b mod T, BASELINE config 5's ramp)
+      ops    also: unpack_widths (the width of the case is ignored: width[b] = 1 + b mod T, BASELINE config 5's ramp),
+             undelta_pack_widths undelta_pack_untranspose_widths transpose_delta_pack_widths (the same ramp), transpose_delta_pack,
+             transpose, untranspose
     FL_AB_BLOCKS=<n> in the environment: that many blocks per case instead of ~8 GB of traffic (BASELINE sizes: 10000000).
 GB/s of algorithmic bytes, median and best."""
 import ctypes
@@ -38,15 +40,24 @@ for ty, W in cases:
                "undelta_pack_untranspose": 128 * W + 128 + 128 * T, "undelta": 2 * 128 * T + 128}.get(op, 128 * W + 128 * T)
         n = int(os.environ.get("FL_AB_BLOCKS", 0)) or int(8e9 / bpb)
         widths = offsets = None
-        if op == "unpack_widths":
+        if op.endswith("_widths"):
             widths = (1 + torch.arange(n, dtype=torch.int64, device=dev) % T).to(torch.uint8)
             offsets = torch.cumsum(widths.to(torch.int64) * 128, 0) - widths.to(torch.int64) * 128
             pbytes = int(offsets[-1].item()) + 128 * int(widths[-1].item())
             bpb = (pbytes + n * 128 * T) / n
-        pk = rand_u8(pbytes if op == "unpack_widths" else n * 128 * W, 2, dev).view(tdt)
-        un = rand_u8(n * 128 * T, 3, dev).view(tdt) if op in ("pack", "undelta") else None
-        bases = rand_u8(n * 128, 4, dev).view(tdt) if op.startswith("undelta") else None
-        out_bytes = {"compare": n * 128, "sums": n * 8, "pack": n * 128 * W}.get(op, n * 128 * T)
+        if op.endswith("_widths") and "delta" in op:
+            bpb += 128
+        if op in ("transpose", "untranspose"):
+            bpb = 2 * 128 * T
+        if op == "transpose_delta_pack":
+            bpb = 128 * W + 128 + 128 * T
+        encode = op in ("pack", "undelta", "transpose", "untranspose", "transpose_delta_pack", "transpose_delta_pack_widths", "pack_widths")
+        pk = rand_u8(pbytes if op.endswith("_widths") else n * 128 * W, 2, dev).view(tdt)
+        un = rand_u8(n * 128 * T, 3, dev).view(tdt) if encode else None
+        bases = rand_u8(n * 128, 4, dev).view(tdt) if "delta" in op else None
+        out_bytes = {"compare": n * 128, "sums": n * 8, "pack": n * 128 * W, "transpose_delta_pack": n * 128 * W}.get(op, n * 128 * T)
+        if op in ("transpose_delta_pack_widths", "pack_widths"):
+            out_bytes = pbytes
         out = torch.empty(max(out_bytes, 16) // 4, dtype=torch.int32, device=dev)
         fns = []
         for _, lib in libs:
@@ -59,6 +70,21 @@ for ty, W in cases:
             elif op == "unpack_widths":
                 f = getattr(lib, f"fl_{ty}_unpack_widths"); f.argtypes = [P, P, P, Z, P, Z, P, P]
                 fns.append(lambda f=f: f(widths.data_ptr(), offsets.data_ptr(), pk.data_ptr(), pbytes, out.data_ptr(), n, None, None))
+            elif op in ("undelta_pack_widths", "undelta_pack_untranspose_widths"):
+                f = getattr(lib, f"fl_{ty}_{op}"); f.argtypes = [P, P, P, Z, P, P, Z, P, P]
+                fns.append(lambda f=f: f(widths.data_ptr(), offsets.data_ptr(), pk.data_ptr(), pbytes, bases.data_ptr(), out.data_ptr(), n, None, None))
+            elif op == "pack_widths":
+                f = getattr(lib, f"fl_{ty}_pack_widths"); f.argtypes = [P, P, P, P, Z, Z, P, P]
+                fns.append(lambda f=f: f(widths.data_ptr(), offsets.data_ptr(), un.data_ptr(), out.data_ptr(), pbytes, n, None, None))
+            elif op == "transpose_delta_pack_widths":
+                f = getattr(lib, f"fl_{ty}_{op}"); f.argtypes = [P, P, P, P, P, Z, Z, P, P]
+                fns.append(lambda f=f: f(widths.data_ptr(), offsets.data_ptr(), un.data_ptr(), bases.data_ptr(), out.data_ptr(), pbytes, n, None, None))
+            elif op == "transpose_delta_pack":
+                f = getattr(lib, f"fl_{ty}_{op}"); f.argtypes = [U, P, P, P, Z, P]
+                fns.append(lambda f=f: f(W, un.data_ptr(), bases.data_ptr(), out.data_ptr(), n, None))
+            elif op in ("transpose", "untranspose"):
+                f = getattr(lib, f"fl_{ty}_{op}"); f.argtypes = [P, P, Z, P]
+                fns.append(lambda f=f: f(un.data_ptr(), out.data_ptr(), n, None))
             elif op == "unpack":
                 f = getattr(lib, f"fl_{ty}_unpack"); f.argtypes = [U, P, P, Z, P]
                 fns.append(lambda f=f: f(W, pk.data_ptr(), out.data_ptr(), n, None))

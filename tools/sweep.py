@@ -16,7 +16,7 @@ import fastlanes_amd as fl  # noqa: E402
 ALLWIDTH_OPS = ("unpack", "pack", "unfor_pack", "for_pack", "undelta_pack", "undelta_pack_untranspose", "transpose_delta_pack")
 WINDOW_AB = "--window-ab" in sys.argv
 BARE = "--bare" in sys.argv or ("--cases" in sys.argv and sys.argv[sys.argv.index("--cases") + 1] == "allwidths")
-PLACEMENT = "separate" if "--placement" in sys.argv and sys.argv[sys.argv.index("--placement") + 1] == "separate" else "zoned"
+PLACEMENT = sys.argv[sys.argv.index("--placement") + 1] if "--placement" in sys.argv else "zoned"
 ESZ = {"u8": 1, "u16": 2, "u32": 4, "u64": 8}
 TDT = {"u8": torch.uint8, "u16": torch.uint16, "u32": torch.uint32, "u64": torch.uint64}
 dev = torch.device("cuda:0")
@@ -228,7 +228,9 @@ def main():
     ap.add_argument("--reps", type=int, default=7)
     ap.add_argument("--cases", default="quick")
     ap.add_argument("--json", default=None)
-    ap.add_argument("--placement", default="zoned", choices=("zoned", "separate"))
+    ap.add_argument("--placement", default="zoned", choices=("zoned", "separate", "interleaved"),
+                    help="interleaved (--cases mixed only): the column's buffers from fl_column_pair_alloc(FL_LAYOUT_INTERLEAVED) -- packed sides in one "
+                         "class of memory, the unpacked side alternating between the other two")
     ap.add_argument("--window-ab", action="store_true", help="every row also under the whole-column tile map and under 2^16-block windows")
     ap.add_argument("--bare", action="store_true", help="pack / unpack / FoR / undelta_pack rows: also a bare stream of the row's bytes on the row's buffers (always on for allwidths)")
     ap.add_argument("--batch-all", action="store_true", help="--cases batch: every element type and the pack direction too")
@@ -516,20 +518,37 @@ def main():
             widths = torch.randint(1, T, (n,), dtype=torch.int64, device=dev, generator=g).to(torch.uint8)
             offsets, total = fl.widths_to_offsets(ty, widths)
             pbytes = int(total.item())
-            col = rnd(pbytes, 1).view(TDT[ty])
+            pair = None
+            if PLACEMENT == "interleaved":
+                from fastlanes_amd import placement as pl
+                # one constructed pair per DIRECTION: the decoders read `col` (one class) and write `un` (the other two), the encoders
+                # read `un_enc` (one class) and write `back` (the other two)
+                pair = pl.ColumnPair(pbytes, n * 128 * T, dev, aux_bytes=n * 128, layout="interleaved")
+                pair_enc = pl.ColumnPair(n * 128 * T, pbytes, dev, aux_bytes=n * 128, layout="interleaved")
+                print(f"# {ty}: constructed pairs, measured classes (input + bases first): decode {pair.classes} | encode {pair_enc.classes}", flush=True)
+                col, un = pair.input.view(TDT[ty]), pair.output.view(TDT[ty])
+                un_enc, back = pair_enc.input.view(TDT[ty]), pair_enc.output.view(TDT[ty])
+                col.view(torch.uint8).copy_(rnd(pbytes, 1))
+                bases = pair.aux.view(TDT[ty])
+                bases.view(torch.uint8).copy_(rnd(n * 128, 3))
+                bases_enc = pair_enc.aux.view(TDT[ty])
+                bases_enc.copy_(bases)
+            else:
+                col = rnd(pbytes, 1).view(TDT[ty])
+                bases = rnd(n * 128, 3).view(TDT[ty])
+                un = torch.empty(n * 1024, dtype=TDT[ty], device=dev)
+                back = torch.empty_like(col)
+                un_enc, bases_enc, pair_enc = un, bases, None
             # references with the top bit clear: reference + field never wraps, so the encoder below finds widths <= the decoder's
             refs = (rnd(n * 8, 2).view(torch.int64) & ((1 << (T - 1)) - 1)).view(torch.uint8).view(-1, 8)[:, :esz].contiguous().view(TDT[ty]).reshape(-1)
-            bases = rnd(n * 128, 3).view(TDT[ty])
-            un = torch.empty(n * 1024, dtype=TDT[ty], device=dev)
-            back = torch.empty_like(col)
             mm = (torch.empty(n, dtype=TDT[ty], device=dev), torch.empty(n, dtype=TDT[ty], device=dev))
-            fl.unfor_pack_widths(widths, offsets, col, refs, output=un)       # the values every encoder row below reads
+            fl.unfor_pack_widths(widths, offsets, col, refs, output=un_enc)       # the values every encoder row below reads
 
             def encoder_chain():
-                lo, hi = fl.BitPacking.block_min_max(un, output=mm)
+                lo, hi = fl.BitPacking.block_min_max(un_enc, output=mm)
                 w2 = fl.for_widths(lo, hi)
                 o2, _ = fl.widths_to_offsets(ty, w2)
-                fl.for_pack_widths(w2, o2, un, lo, back, check=False)
+                fl.for_pack_widths(w2, o2, un_enc, lo, back, check=False)
 
             two_sided = pbytes + n * 128 * T
             rows = (
@@ -538,10 +557,10 @@ def main():
                 ("undelta_pack_widths", two_sided + n * 128, lambda: fl.undelta_pack_widths(widths, offsets, col, bases, output=un, check=False)),
                 ("undelta_pack_untranspose_widths", two_sided + n * 128,
                  lambda: fl.undelta_pack_widths(widths, offsets, col, bases, output=un, check=False, untranspose=True)),
-                ("restore", 0, lambda: fl.unfor_pack_widths(widths, offsets, col, refs, output=un, check=False)),
-                ("pack_widths", two_sided, lambda: fl.pack_widths(widths, offsets, un, back, check=False)),
-                ("for_pack_widths", two_sided, lambda: fl.for_pack_widths(widths, offsets, un, refs, back, check=False)),
-                ("transpose_delta_pack_widths", two_sided + n * 128, lambda: fl.transpose_delta_pack_widths(widths, offsets, un, bases, back, check=False)),
+                ("restore", 0, lambda: fl.unfor_pack_widths(widths, offsets, col, refs, output=un_enc, check=False)),
+                ("pack_widths", two_sided, lambda: fl.pack_widths(widths, offsets, un_enc, back, check=False)),
+                ("for_pack_widths", two_sided, lambda: fl.for_pack_widths(widths, offsets, un_enc, refs, back, check=False)),
+                ("transpose_delta_pack_widths", two_sided + n * 128, lambda: fl.transpose_delta_pack_widths(widths, offsets, un_enc, bases_enc, back, check=False)),
                 ("FoR encoder chain (4 launches)", 2 * n * 128 * T + pbytes, encoder_chain),
             )
             for name, nbytes, f in rows:
@@ -557,7 +576,10 @@ def main():
                 med = sorted(ms)[len(ms) // 2]
                 print(f"{name:32s} {ty:4s} n={n:>9d} {med:9.4f} ms {nbytes / med / 1e6:8.1f} GB/s {nbytes / med / 8e9:.3f} "
                       f"{n * 1024 / med / 1e6:8.1f} Gint/s", flush=True)
-            del col, un, back, refs, bases, mm
+            del col, un, back, refs, bases, mm, un_enc, bases_enc
+            if pair is not None:
+                pair.free()
+                pair_enc.free()
             torch.cuda.empty_cache()
         return
     if args.cases == "single":
