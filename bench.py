@@ -847,6 +847,32 @@ def bare_stream(w, launches=9):
                      f"{'whole-column tile map' if wn.value >= 31 else '2^%d-block windows' % wn.value} (the shape of the library's kernel for this call)"}
 
 
+def dispatch_check(w, gib=1.0):
+    """Is the generated dispatch table's choice for this call a loser on THIS box?  fl_internal_selftune_check (fastlanes_amd_internal.h)
+    times the table's kernel against every alternative the library could launch -- the cell-column kernel where it is built, the
+    wave-per-block kernel at 3 / 4 / 5 / 6 / 8 wavefronts per SIMD -- on about `gib` GiB of the workload's own buffers, after the timed region
+    and the checks (it overwrites the output).  Reported, never acted on: what gets timed is the shipped table."""
+    import ctypes
+    import fastlanes_amd as fl
+    lib = fl.load()
+    op = {"unpack": 0, "pack": 1, "undelta_pack": 2}.get(w.op)
+    if op is None:
+        return None
+    n = max(1024, min(w.n, int(gib * (1 << 30) / WORKLOADS[w.name][3])))
+    t, o, pol = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int(0)
+    aux = w.bases.data_ptr() if w.bases is not None else None
+    rc = lib.fl_internal_selftune_check(op, 8 * ESZ[w.ty], w.width, w.src.data_ptr(), aux, w.dst.data_ptr(), n, ctypes_stream(w.dst.device),
+                                        ctypes.byref(t), ctypes.byref(o), ctypes.byref(pol))
+    if rc != 0 or t.value <= 0:
+        return None
+    other = "none" if not pol.value else "cell-column" if pol.value == 1 else f"wave-per-block at {pol.value >> 8} waves/SIMD"
+    behind = (t.value / o.value - 1) * 100 if o.value > 0 else 0.0
+    return {"blocks": n, "table_ms": round(t.value, 4), "best_alternative_ms": round(o.value, 4), "best_alternative": other,
+            "table_behind_pct": round(behind, 2), "table_loses_by_more_than_3pct": bool(behind > 3.0),
+            "note": "fl_internal_selftune_check on ~%.0f GiB of this workload's buffers after the timed region; the table "
+                    "(fl_dispatch_table.inc) was measured at BASELINE sizes -- small launches favour other occupancies" % gib}
+
+
 def placed_workload(name, n, first, rank, dev, args, single_device=False):
     """(workload, the placement probe's figures or None).  Where a column lives in HBM moves the same kernel by a few per cent,
     differently per workload and per box, and nothing in an address tells: --placement auto asks the LIBRARY
@@ -981,6 +1007,12 @@ def main():
     flags, n_checked, verified = run_check(w, args, ctl)       # every rank, its own slice, outside the timed region
     placed, classes = w.placement, getattr(w, "classes", "")
     bare = bare_stream(w) if rank == 0 else None     # after the checks (it overwrites the output), same buffers, same run
+    tune = None
+    if rank == 0 and world == 1:
+        try:
+            tune = dispatch_check(w, gib=8.0)
+        except Exception as e:                       # measurement tooling must never take the bench line down
+            print(f"dispatch_check failed: {e!r}", file=sys.stderr)
     release(w)                                       # leg 1 is measured and checked: its column can go
 
     # ---- rank 0, N=1: the cpu_baseline leg (with the checks, the only place bench.py touches oracle/)
@@ -1048,6 +1080,8 @@ def main():
         if probe:
             out["roofline"]["placement_probe_GBps"] = probe
         out.update(control)
+        if tune is not None:
+            out["dispatch_check"] = tune
         if cpu is not None:
             out["cpu_baseline"] = cpu
 

@@ -1213,6 +1213,71 @@ int fl_column_pair_free(void* handle)
     return FL_OK;
 }
 
+int fl_internal_selftune_check(int op, unsigned type_bits, unsigned width, const void* in, const void* aux, void* out, size_t n_blocks, void* stream,
+                               float* table_ms, float* best_other_ms, int* best_other_policy)
+{
+    if (!table_ms || !best_other_ms || !best_other_policy) return FL_ERR_NULL;
+    if (op < 0 || op > 2 || (type_bits != 8 && type_bits != 16 && type_bits != 32 && type_bits != 64)) return FL_ERR_INDEX;
+    if (width > type_bits) return FL_ERR_WIDTH;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    auto call = [&]() -> int {
+        switch (type_bits * 4 + (unsigned)op) {
+        case 8 * 4 + 0: return fl_u8_unpack(width, (const uint8_t*)in, (uint8_t*)out, n_blocks, stream);
+        case 8 * 4 + 1: return fl_u8_pack(width, (const uint8_t*)in, (uint8_t*)out, n_blocks, stream);
+        case 8 * 4 + 2: return fl_u8_undelta_pack(width, (const uint8_t*)in, (const uint8_t*)aux, (uint8_t*)out, n_blocks, stream);
+        case 16 * 4 + 0: return fl_u16_unpack(width, (const uint16_t*)in, (uint16_t*)out, n_blocks, stream);
+        case 16 * 4 + 1: return fl_u16_pack(width, (const uint16_t*)in, (uint16_t*)out, n_blocks, stream);
+        case 16 * 4 + 2: return fl_u16_undelta_pack(width, (const uint16_t*)in, (const uint16_t*)aux, (uint16_t*)out, n_blocks, stream);
+        case 32 * 4 + 0: return fl_u32_unpack(width, (const uint32_t*)in, (uint32_t*)out, n_blocks, stream);
+        case 32 * 4 + 1: return fl_u32_pack(width, (const uint32_t*)in, (uint32_t*)out, n_blocks, stream);
+        case 32 * 4 + 2: return fl_u32_undelta_pack(width, (const uint32_t*)in, (const uint32_t*)aux, (uint32_t*)out, n_blocks, stream);
+        case 64 * 4 + 0: return fl_u64_unpack(width, (const uint64_t*)in, (uint64_t*)out, n_blocks, stream);
+        case 64 * 4 + 1: return fl_u64_pack(width, (const uint64_t*)in, (uint64_t*)out, n_blocks, stream);
+        default: return fl_u64_undelta_pack(width, (const uint64_t*)in, (const uint64_t*)aux, (uint64_t*)out, n_blocks, stream);
+        }
+    };
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    hipError_t e = hipEventCreate(&t0);
+    if (e == hipSuccess) e = hipEventCreate(&t1);
+    if (e != hipSuccess) { if (t0) (void)hipEventDestroy(t0); return hip_fail(e); }
+    const int saved = fl_internal_get_kernel_policy();
+    int rc = FL_OK;
+    auto timed = [&](int policy, float& ms) {
+        fl_internal_set_kernel_policy(policy);
+        float t[3] = {0.f, 0.f, 0.f};
+        for (int i = -1; i < 3 && rc == FL_OK; ++i) {
+            hipError_t h = hipEventRecord(t0, s);
+            if (h == hipSuccess) rc = call();
+            if (h == hipSuccess && rc == FL_OK) h = hipEventRecord(t1, s);
+            if (h == hipSuccess && rc == FL_OK) h = hipEventSynchronize(t1);
+            float x = 0.f;
+            if (h == hipSuccess && rc == FL_OK) h = hipEventElapsedTime(&x, t0, t1);
+            if (h != hipSuccess) rc = hip_fail(h);
+            if (i >= 0) t[i] = x;
+        }
+        std::sort(t, t + 3);
+        ms = t[1];
+    };
+    timed(0, *table_ms);
+    *best_other_ms = 0.f;
+    *best_other_policy = 0;
+    const fl::WaveOp wop = op == 1 ? fl::WAVE_PACK : op == 2 ? fl::WAVE_UNDELTA_PACK : fl::WAVE_UNPACK;
+    int tab = fl::wave_policy(type_bits, width, wop);
+    if (tab >= fl::TWO_BLOCKS) tab -= fl::TWO_BLOCKS;
+    for (int policy : {1, 2 + 256 * 3, 2 + 256 * 4, 2 + 256 * 5, 2 + 256 * 6, 2 + 256 * 8}) {
+        if (rc != FL_OK) break;
+        if (policy == 1 && (tab == 0 || !fl::cell_column_built(type_bits, width, wop))) continue;   // the table's own choice, or not built
+        if (policy != 1 && (policy >> 8) == tab && fl::wave_policy(type_bits, width, wop) < fl::TWO_BLOCKS) continue;   // the table's own choice
+        float ms = 0.f;
+        timed(policy, ms);
+        if (rc == FL_OK && ms > 0.f && (*best_other_ms == 0.f || ms < *best_other_ms)) { *best_other_ms = ms; *best_other_policy = policy; }
+    }
+    fl_internal_set_kernel_policy(saved);
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    return rc;
+}
+
 const char* fl_internal_column_pair_classes(const void* handle)
 {
     return handle ? static_cast<const ColumnPair*>(handle)->class_map : "";

@@ -216,6 +216,15 @@ __device__ __forceinline__ void chain_stage_source(const ChainArgs& a, uint64_t 
 {
     using G = WaveBlock<T>;
     constexpr int TB = G::TB;
+    if constexpr (RD == RD_AUTO) {
+        // what fl_widths.hpp's RD_AUTO does for plain unpack (profiles/ab_ldsdma_r03.txt): packed input that is a sizeable share of the
+        // traffic (2 W >= T, or a mixed-width column) streams NON-TEMPORALLY by LDS-DMA, narrow widths through VGPRs.  Round 6: the
+        // Delta decoders read their packed rows with the default policy at every width until now -- 3-6 % behind unpack of the same
+        // column at wide widths at every occupancy, in both kernel designs (profiles/r06_undelta_occupancy.txt).
+        if (SRC == SRC_PACKED && (a.widths || 2u * w >= (unsigned)TB)) chain_stage_source<T, SRC, BODY, RD_DMA_NT>(a, blk, w, packed_at, lds, lane, base);
+        else chain_stage_source<T, SRC, BODY, RD_VGPR>(a, blk, w, packed_at, lds, lane, base);
+        return;
+    }
     const unsigned c16 = (lane & 7u) * 16u;
     const __amdgpu_buffer_rsrc_t in_rs = chain_source<T, SRC>(a, blk, w, packed_at);
     const unsigned w_in = SRC == SRC_PACKED ? w : (unsigned)TB;
@@ -822,19 +831,21 @@ __global__ __launch_bounds__(64) void k_chain_columns_pipelined(ChainArgs a)
 template <auto KERNEL>
 inline hipError_t persistent_grid(unsigned lds, int per_cu, unsigned& grid)
 {
-    struct Slot { std::atomic<int> dev{-1}; std::atomic<int> cus{0}; std::atomic<int> fit{0}; };
-    static Slot slot;                                       // one per instantiation = per kernel (KERNEL is a non-type parameter)
+    // one slot per (kernel, device id): threads that drive different devices (examples/multi_gpu_decode.c) do not evict each other's
+    // entry, and a reader can never pair one device's figures with another's id.  packed = 1 + cus + (fit << 16); 0 = not queried yet
+    constexpr int MAX_DEVICES = 16;
+    static std::atomic<uint64_t> slots[MAX_DEVICES];         // one array per instantiation = per kernel (KERNEL is a non-type parameter)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    int cus = slot.cus.load(std::memory_order_relaxed), fit = slot.fit.load(std::memory_order_relaxed);
-    if (slot.dev.load(std::memory_order_acquire) != dev || cus <= 0 || fit <= 0) {
+    const bool cached = dev >= 0 && dev < MAX_DEVICES;
+    uint64_t packed = cached ? slots[dev].load(std::memory_order_relaxed) : 0;
+    int cus = (int)((packed - 1) & 0xffffu), fit = (int)((packed - 1) >> 16);
+    if (packed == 0) {
         e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, KERNEL, 64, lds);
         if (e != hipSuccess) return e;
-        slot.cus.store(cus, std::memory_order_relaxed);
-        slot.fit.store(fit, std::memory_order_relaxed);
-        slot.dev.store(dev, std::memory_order_release);
+        if (cached && cus > 0 && cus < 0xffff && fit > 0) slots[dev].store(1u + (uint64_t)cus + ((uint64_t)fit << 16), std::memory_order_relaxed);
     }
     if (fit > 0 && per_cu > fit) per_cu = fit;              // a persistent grid must be resident at once to be worth anything
     const uint64_t resident = ((uint64_t)cus * (unsigned)per_cu + 7) / 8 * 8;          // a multiple of 8: a workgroup stays on its XCD

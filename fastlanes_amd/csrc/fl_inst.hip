@@ -66,12 +66,12 @@ template <> batch_launch_t batch_chain_launcher<T>(int op)
 template <> chain_launch_t chain_launcher<T>(int op)
 {
     switch (op) {
-    case OP_UNDELTA_PACK: return &launch_chain<T, SRC_PACKED, CHAIN_UNDELTA, SNK_ROWS>;
+    case OP_UNDELTA_PACK: return &launch_chain<T, SRC_PACKED, CHAIN_UNDELTA, SNK_ROWS, RD_AUTO>;
     case OP_UNDELTA: return &launch_chain<T, SRC_ROWS, CHAIN_UNDELTA, SNK_ROWS>;
     case OP_DELTA: return &launch_chain<T, SRC_ROWS, CHAIN_DELTA, SNK_ROWS>;
     case OP_UNTRANSPOSE: return &launch_chain<T, SRC_ROWS, CHAIN_NONE, SNK_ORIGINAL>;
     case OP_TRANSPOSE: return &launch_chain<T, SRC_ORIGINAL, CHAIN_NONE, SNK_ROWS>;
-    case OP_UNDELTA_PACK_UNTRANSPOSE: return &launch_chain<T, SRC_PACKED, CHAIN_UNDELTA, SNK_ORIGINAL>;
+    case OP_UNDELTA_PACK_UNTRANSPOSE: return &launch_chain<T, SRC_PACKED, CHAIN_UNDELTA, SNK_ORIGINAL, RD_AUTO>;
     case OP_TRANSPOSE_DELTA_PACK: return &launch_chain<T, SRC_ORIGINAL, CHAIN_DELTA, SNK_PACKED>;
     default: return nullptr;
     }

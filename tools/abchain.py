@@ -33,25 +33,53 @@ if "--gb" in sys.argv:             # bytes moved per launch; BASELINE's config 4
     GB = int(sys.argv[sys.argv.index("--gb") + 1])
 print("GB/s, median of %d; cc = cell-column, then wave-per-block at %s waves/SIMD" % (ROUNDS, " ".join(map(str, WAVES))))
 seen_plain = set()
+CONSTRUCTED = {}
 for ty, W in cases:
     tdt, T = TD[ty]
     esz = T // 8
     n = min(10_000_000, (GB << 30) // (128 * W + 128 * T + 128))
-    pk = rand_u8(n * 128 * W, 2, dev).view(tdt)
-    un = rand_u8(n * 1024 * esz, 1, dev).view(tdt)
-    out = torch.empty(n * 1024, dtype=tdt, device=dev)
-    bases = rand_u8(n * 128, 3, dev).view(tdt)
+    if "--constructed" in sys.argv:
+        # round 6: the buffers of each DIRECTION in a constructed layout (fl_column_pair_alloc: FL_LAYOUT_INTERLEAVED), one pair per
+        # direction and element type, sized for the type's largest case and sliced per width -- in memory of one class every variant
+        # reads the same figure (the memory is the bound) and the sweep decides nothing
+        from fastlanes_amd import placement as pl
+        if CONSTRUCTED.get("ty") != ty:
+            for q in CONSTRUCTED.get("pairs", []):
+                q.free()
+            torch.cuda.empty_cache()
+            n_of = lambda w: min(10_000_000, (GB << 30) // (128 * w + 128 * T + 128))
+            n_max = n_of(0)
+            pk_max = max(n_of(w) * 128 * w for w in range(T + 1))
+            dec = pl.ColumnPair(pk_max, n_max * 128 * T, dev, aux_bytes=n_max * 128, layout="interleaved")
+            enc = pl.ColumnPair(n_max * 128 * T, 2 * pk_max, dev, aux_bytes=n_max * 128, layout="interleaved")
+            print(f"# {ty}: constructed pairs, measured classes (input + bases first): decode {dec.classes} | encode {enc.classes}", flush=True)
+            dec.input.copy_(rand_u8(pk_max, 2, dev))
+            dec.aux.copy_(rand_u8(n_max * 128, 3, dev))
+            enc.input.copy_(rand_u8(n_max * 128 * T, 1, dev))
+            enc.aux.copy_(dec.aux)
+            CONSTRUCTED.update(ty=ty, pairs=[dec, enc], pk_max=pk_max)
+        dec, enc = CONSTRUCTED["pairs"]
+        pk, out, bases = dec.input[:n * 128 * W].view(tdt), dec.output[:n * 128 * T].view(tdt), dec.aux[:n * 128].view(tdt)
+        un, bases_enc = enc.input[:n * 128 * T].view(tdt), enc.aux[:n * 128].view(tdt)
+        pk_out_c, pk_for_c = enc.output[:n * 128 * W].view(tdt), enc.output[CONSTRUCTED["pk_max"]:][:n * 128 * W].view(tdt)
+    else:
+        pk = rand_u8(n * 128 * W, 2, dev).view(tdt)
+        un = rand_u8(n * 1024 * esz, 1, dev).view(tdt)
+        out = torch.empty(n * 1024, dtype=tdt, device=dev)
+        bases = rand_u8(n * 128, 3, dev).view(tdt)
+        bases_enc = bases
+        pk_out_c = pk_for_c = None
     refs = bases[:n]
     ops = {}
     if "--for" in sys.argv or ALL:      # FoR's bodies (rows of their own in the dispatch table since round 5)
-        pk_for = torch.empty_like(pk)
+        pk_for = torch.empty_like(pk) if pk_for_c is None else pk_for_c
         ops["unfor_pack"] = (lambda: fl.FoR.unfor_pack(W, pk, refs, output=out), n * (128 * W + 128 * T))
         ops["for_pack"] = (lambda: fl.FoR.for_pack(W, un, refs, output=pk_for), n * (128 * W + 128 * T))
     ops.update({"undelta_pack": (lambda: fl.Delta.undelta_pack(W, pk, bases, output=out), n * (128 * W + 128 + 128 * T))})
     if True:
-        pk_out = torch.empty_like(pk)
+        pk_out = torch.empty_like(pk) if pk_out_c is None else pk_out_c
         ops["undelta_pack_untr"] = (lambda: fl.Delta.undelta_pack_untranspose(W, pk, bases, output=out), n * (128 * W + 128 + 128 * T))
-        ops["transp_delta_pack"] = (lambda: fl.Delta.transpose_delta_pack(W, un, bases, output=pk_out), n * (128 * W + 128 + 128 * T))
+        ops["transp_delta_pack"] = (lambda: fl.Delta.transpose_delta_pack(W, un, bases_enc, output=pk_out), n * (128 * W + 128 + 128 * T))
     if ty not in seen_plain:
         ops["transpose"] = (lambda: fl.Transpose.transpose(un, output=out), n * 256 * T)
         ops["untranspose"] = (lambda: fl.Transpose.untranspose(un, output=out), n * 256 * T)
@@ -90,6 +118,6 @@ for ty, W in cases:
     lib.fl_internal_set_kernel_policy(0)
     # the lambdas in `ops` hold every buffer of the case: drop them with the buffers, or the caching allocator fragments until a
     # 45-GB case no longer fits (round 5: both boxes died at u64 W=64)
-    del ops, f, pk, un, out, bases, refs
-    pk_out = pk_for = res_t = None
+    del ops, f, pk, un, out, bases, refs, bases_enc
+    pk_out = pk_for = res_t = pk_out_c = pk_for_c = None
     torch.cuda.empty_cache()
