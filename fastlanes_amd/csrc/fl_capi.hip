@@ -976,6 +976,13 @@ void choose_chunks(const std::vector<int>& cls, size_t n_in, size_t n_out, size_
         size_t rest = n_out - q[0] - q[1];
         q[2] = std::min(l, rest);
         q[3] = std::min(u, rest - q[2]);
+        // one class must not carry (much) more than half of the output: where the other one is scarce, left-overs of the INPUT's class
+        // take its place in the rotation (in A | out A and B alternating 0.855, out B alone 0.80: profiles/r06_vmm_placement.txt)
+        if (q[0] > (n_out + 1) / 2 && l > q[2]) {
+            const size_t shift = std::min(l - q[2], q[0] - (n_out + 1) / 2);
+            q[0] -= shift;
+            q[2] += shift;
+        }
         return q[0] + q[1] + q[2] + q[3] == n_out;
     };
     int best_c = -1;
