@@ -1285,6 +1285,15 @@ int fl_internal_selftune_check(int op, unsigned type_bits, unsigned width, const
     return rc;
 }
 
+size_t fl_internal_choose_chunks(const int* classes, size_t n_pool, size_t n_in, size_t n_out, size_t run, int* order)
+{
+    if (!classes || !order || n_pool == 0) return 0;
+    std::vector<int> cls(classes, classes + n_pool), chosen;
+    choose_chunks(cls, n_in, n_out, run ? run : 1, chosen);
+    for (size_t i = 0; i < chosen.size(); ++i) order[i] = chosen[i];
+    return chosen.size();
+}
+
 const char* fl_internal_column_pair_classes(const void* handle)
 {
     return handle ? static_cast<const ColumnPair*>(handle)->class_map : "";

@@ -33,7 +33,7 @@ def _header_symbols():
 def test_every_declared_symbol_is_exported(lib):
     import fastlanes_amd
     syms = _header_symbols()
-    assert len(syms) == 4 * 42 + 23
+    assert len(syms) == 4 * 42 + 24
     assert sorted(fastlanes_amd.exported_symbols()) == syms
     for s in syms:
         assert hasattr(lib, s), s
@@ -305,3 +305,50 @@ def test_zone_aware_placement_helper_arithmetic():
         assert k == 1 or (k - 1) * Z - ob // 2 < in_end                       # ... the first one that leaves room for the input
     with pytest.raises(ValueError):
         pl.column_pair(9 * Z, 4096, torch.device("meta"))
+
+
+def test_constructed_layout_chooses_chunks_by_class(lib):
+    """fl_internal_choose_chunks = the arrangement FL_LAYOUT_INTERLEAVED makes from a measured class map (a pure host function): the input
+    inside ONE class, the output spread over the others so that no class carries much more than half where that can be avoided, no chunk
+    used twice; creation order where no class can hold the input (in A | out B/C alternating 0.865, out A/B 0.855,
+    out B alone 0.80, out A 0.78 of the peak)."""
+    import random
+
+    def choose(classes, n_in, n_out, run=2):
+        m = {"A": 0, "B": 1, "C": 2, "?": -1}
+        c = (ctypes.c_int * len(classes))(*[m[x] for x in classes])
+        o = (ctypes.c_int * (n_in + n_out))()
+        k = lib.fl_internal_choose_chunks(c, len(classes), n_in, n_out, run, o)
+        idx = list(o[:k])
+        assert len(set(idx)) == len(idx) and all(0 <= i < len(classes) for i in idx)
+        return "".join(classes[i] for i in idx[:n_in]), "".join(classes[i] for i in idx[n_in:]), idx
+
+    # a balanced pool: the input in one class, the output alternating between the other two in runs of 2
+    cin, cout, _ = choose("AAAABBBBCCCC" * 8, 9, 39)
+    assert len(set(cin)) == 1 and cin[0] not in cout and abs(cout.count(cout[0]) - (39 - cout.count(cout[0]))) <= 2
+    assert all(len(set(cout[i:i + 4])) == 2 for i in range(0, 36, 2))
+    # one class scarce (what a box handed out in round 6): the input's left-overs join the rotation, no class carries > half + 1
+    cin, cout, _ = choose("B" * 38 + "C" * 50 + "AAA" + "C" * 14, 9, 39)
+    assert len(set(cin)) == 1 and max(cout.count(x) for x in "ABC") <= 20 and len(set(cout)) == 3
+    assert all(len(set(cout[i:i + 6])) >= 2 for i in range(0, 33))          # every stretch of the output mixes classes
+    # two classes only
+    cin, cout, _ = choose("A" * 80 + "B" * 16, 9, 39)
+    assert set(cin) == {"A"} and cout.count("B") == 16 and all(len(set(cout[i:i + 8])) == 2 for i in range(0, 31))
+    # one class only / nothing classified / input larger than any class: creation order
+    for classes in ("A" * 60, "?" * 60, "ABC" * 20):
+        n_in = 30 if classes.startswith("ABC") else 9
+        _, _, idx = choose(classes, n_in, 20)
+        if classes != "A" * 60:
+            assert idx == list(range(n_in + 20)), classes
+    # a pool that is too small yields fewer indices, never a repeated one
+    _, _, idx = choose("ABCABC", 3, 9)
+    assert len(idx) <= 6
+    # seeded fuzz: never a duplicate, the input single-class whenever some class can hold it
+    rnd = random.Random(6)
+    for _ in range(200):
+        n = rnd.randint(8, 160)
+        classes = "".join(rnd.choice("AAABBC?") for _ in range(n))
+        n_in, n_out = rnd.randint(1, n // 3), rnd.randint(1, n // 2)
+        cin, cout, idx = choose(classes, n_in, n_out, rnd.choice((1, 2, 4)))
+        if len(idx) == n_in + n_out and any(classes.count(x) >= n_in for x in "ABC") and idx != list(range(n_in + n_out)):
+            assert len(set(cin)) == 1
