@@ -92,8 +92,10 @@ template <> chain_launch_t chain_widths_launcher<T>(int op)
         if (op == OP_TRANSPOSE_DELTA_PACK) return &launch_chain_columns_encode_pipelined<T>;
     }
     switch (op) {
-    case OP_UNDELTA_PACK: return &launch_chain<T, SRC_PACKED, CHAIN_UNDELTA, SNK_ROWS, RD_VGPR, B>;
-    case OP_UNDELTA_PACK_UNTRANSPOSE: return &launch_chain<T, SRC_PACKED, CHAIN_UNDELTA, SNK_ORIGINAL, RD_VGPR, B>;
+    // (one block per wavefront -- u32 / u64 -- goes through chain_stage_source: RD_AUTO = a mixed-width column's packed rows stream
+    // non-temporally by LDS-DMA, as in unpack_widths; the lockstep form of the narrow types always did)
+    case OP_UNDELTA_PACK: return &launch_chain<T, SRC_PACKED, CHAIN_UNDELTA, SNK_ROWS, RD_AUTO, B>;
+    case OP_UNDELTA_PACK_UNTRANSPOSE: return &launch_chain<T, SRC_PACKED, CHAIN_UNDELTA, SNK_ORIGINAL, RD_AUTO, B>;
     case OP_TRANSPOSE_DELTA_PACK: return &launch_chain<T, SRC_ORIGINAL, CHAIN_DELTA, SNK_PACKED, RD_VGPR, B>;
     default: return nullptr;
     }
