@@ -821,6 +821,8 @@ def bare_stream(w, launches=9):
     iu, au, ou, nt, wv, wn, bpu = Z(), Z(), Z(), I(), I(), I(), ctypes.c_uint()
     if lib.fl_internal_bare_stream_shape(op, 8 * ESZ[w.ty], 33 if op == 3 else w.width, *[ctypes.byref(x) for x in (iu, au, ou, nt, wv, wn, bpu)]) != 0:
         return None
+    if getattr(w, "pair", None) is not None and getattr(w.pair, "classes", ""):
+        wn.value = 31                # buffers inside a constructed pair: the library launches under the whole-column tile map (fl_kernels.hpp)
     n = w.n // bpu.value             # units of bpu consecutive blocks (u8: 4, u16: 2): a wavefront's share in the library's kernels too
     in_unit = iu.value
     if op == 3:                      # a mixed-width column: units of the column's mean packed block, rounded down to a cell

@@ -156,7 +156,7 @@ def load():
     lib.fl_internal_selftune_check.argtypes = [ctypes.c_int, _U, _U, _P, _P, _P, _Z, _P, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                                                ctypes.POINTER(ctypes.c_int)]
     lib.fl_internal_choose_chunks.restype = ctypes.c_size_t
-    lib.fl_internal_choose_chunks.argtypes = [ctypes.POINTER(ctypes.c_int), _Z, _Z, _Z, _Z, ctypes.POINTER(ctypes.c_int)]
+    lib.fl_internal_choose_chunks.argtypes = [ctypes.POINTER(ctypes.c_int), _Z, _Z, _Z, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     lib.fl_internal_column_pair_classes.restype = ctypes.c_char_p
     lib.fl_internal_column_pair_classes.argtypes = [_P]
     lib.fl_widths_to_offsets.restype = ctypes.c_int

@@ -54,6 +54,7 @@ inline int hip_fail(hipError_t e)
     return FL_ERR_HIP;
 }
 
+bool fl_in_constructed_pair(std::initializer_list<const void*> ptrs);   // below, next to fl_column_pair_alloc
 inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 
 // FL_CHECK_DEVICE=1 (fastlanes_amd.h "Threading and device selection"): before a device-tier launch, every pointer must be
@@ -85,7 +86,10 @@ int device_check(void* stream, std::initializer_list<const void*> ptrs)
     }
     return FL_OK;
 }
-#define FL_DEVICE_TIER(stream, ...) do { if (const int rc_ = device_check(stream, {__VA_ARGS__})) return rc_; } while (0)
+// (every device-tier entry also tells the launchers whether its buffers lie inside one live FL_LAYOUT_INTERLEAVED pair: fl_kernels.hpp,
+// constructed_pair_this_thread -- one relaxed load while no such pair exists)
+#define FL_DEVICE_TIER(stream, ...) do { if (const int rc_ = device_check(stream, {__VA_ARGS__})) return rc_; \
+                                         fl::constructed_pair_this_thread() = fl_in_constructed_pair({__VA_ARGS__}); } while (0)
 
 template <typename T>
 int run_stream(stream_launch_t fn, const T* in, T* out, const void* aux, size_t aux_stride,
@@ -505,6 +509,7 @@ int host_run(const T* in, size_t in_elems, const T* aux, size_t aux_elems, T* ou
     const size_t o_aux = pad256(ib), o_out = o_aux + pad256(ab), total = o_out + pad256(ob);
     HostCtx& c = g_host;
     FL_HIP(c.bind());
+    fl::constructed_pair_this_thread() = false;             // the host tier's own staging buffers (a device-tier call may have left it set)
     if (total <= HOST_ZERO_COPY_LIMIT) {
         FL_HIP(c.need_pinned(total));
         if (ib) memcpy(c.pin, in, ib);
@@ -895,6 +900,8 @@ constexpr size_t PAIR_ALIGN = 256, PAIR_ZONE = (size_t)64 << 30, PAIR_MIB = (siz
 constexpr size_t PAIR_INTERLEAVED_MIN = 8 * PAIR_GIB;       // below that a pair is a handful of chunks: nothing to arrange
 inline size_t pair_pad(size_t b) { return (b + PAIR_ALIGN - 1) & ~(PAIR_ALIGN - 1); }
 
+void live_pair_remove(const char* va);                   // the launchers' registry of live constructed pairs, below
+
 struct ColumnPair {
     void* bufs[3] = {nullptr, nullptr, nullptr};       // separate: in, aux, out; zoned: the slab only
     void *in = nullptr, *aux = nullptr, *out = nullptr;
@@ -913,6 +920,7 @@ struct ColumnPair {
         n_mapped = 0;
         for (auto h : chunks) (void)hipMemRelease(h);
         chunks.clear();
+        if (va) live_pair_remove(va);
         if (va) (void)hipMemAddressFree(va, va_bytes);
         va = nullptr;
     }
@@ -953,72 +961,139 @@ hipError_t reserve_fresh_range(size_t bytes, char** out)
     return *out ? hipSuccess : e;
 }
 
-// which chunks of a classified pool form the pair: the input inside ONE class, the output spread EVENLY over the other two in runs of
-// `run` chunks (reads together, writes spread, reads and writes apart: profiles/r06_vmm_placement.txt -- in A | out BC 0.864-0.866, out
-// ABC 0.860, out AB 0.855, out B 0.80, out A 0.78 of the peak at u32 W=7).  Where the other two classes cannot cover the output, left-over
-// chunks of the input's class (then unclassified ones) join the rotation -- every stretch of the output still mixes classes, which is what
-// the eight XCDs' concurrent write positions need.  Falls back to creation order (short class runs by nature: 0.854-0.861) when the
-// probe saw one level only or no class can hold the input.
-void choose_chunks(const std::vector<int>& cls, size_t n_in, size_t n_out, size_t run, std::vector<int>& order)
+// which chunks of a classified pool form the pair (profiles/r06_vmm_placement.txt, r06_vmm_output_rotation.txt; fractions of the 8 TB/s):
+//  * the input (+ aux) inside ONE class (reads spread over classes under the whole-column tile map: 0.80 where one class gives 0.84-0.86);
+//  * the output rotating through `out_classes` classes: the OTHER TWO for a write-dominated pair (u32 W=7 unpack: out BC 0.864-0.866, out
+//    ABC 0.860, out AB 0.855, out B 0.80, out A 0.78), ALL THREE otherwise (pack u32 W=7: out ABC 0.859, out AB 0.85, out BC 0.84, out B
+//    0.83; transpose: ABC 0.880, BC 0.870-0.879; unpack u32 W=20: equal);
+//  * the rotation by POSITION, not by a fixed run length: under the whole-column tile map XCD x walks the x-th eighth of the output, all
+//    eight at the same pace, so the k-th chunk of eighth x takes letter (x + k) -- at every moment the eight write positions cycle through
+//    the classes.  A fixed run length resonates with the eighth's size for some column lengths (runs of 2 GiB at 8 M blocks: seven of the
+//    eight positions in one class, 0.840 where the positional rotation gives 0.864; runs of 1 GiB with three classes at 6.5 M: 0.829 / 0.859).
+// Where a class cannot cover its share, the positions it misses (spread evenly) go to the class with the largest surplus, classes outside
+// the rotation first -- left-overs of the input's class, as in round 6's first version: in A | out A and B alternating is 0.855, out B alone
+// 0.80 -- then unclassified chunks.  Creation order (short class runs by nature: 0.854-0.861) when no class can hold the input.
+void choose_chunks(const std::vector<int>& cls, size_t n_in, size_t n_out, int out_classes, std::vector<int>& order)
 {
     const size_t n = cls.size();
     order.clear();
+    if (out_classes != 2) out_classes = 3;
     std::vector<int> by[4];                                    // 0..2 = classes, 3 = unclassified
     for (size_t g = 0; g < n; ++g) by[cls[g] < 0 || cls[g] > 2 ? 3 : cls[g]].push_back((int)g);
-    // quota[k] = how many output chunks come from source k for input class c; sources: the two other classes, c's left-overs, unclassified
-    auto quotas = [&](int c, size_t q[4], int src[4]) {
-        src[0] = (c + 1) % 3; src[1] = (c + 2) % 3; src[2] = c; src[3] = 3;
-        if (by[src[1]].size() > by[src[0]].size()) std::swap(src[0], src[1]);
-        const size_t a = by[src[0]].size(), b = by[src[1]].size(), l = by[c].size() - n_in, u = by[3].size();
-        q[1] = std::min(b, n_out / 2);                              // the scarcer of the two, at most half
-        q[0] = std::min(a, n_out - q[1]);
-        q[1] = std::min(b, n_out - q[0]);
-        size_t rest = n_out - q[0] - q[1];
-        q[2] = std::min(l, rest);
-        q[3] = std::min(u, rest - q[2]);
-        // one class must not carry (much) more than half of the output: where the other one is scarce, left-overs of the INPUT's class
-        // take its place in the rotation (in A | out A and B alternating 0.855, out B alone 0.80: profiles/r06_vmm_placement.txt)
-        if (q[0] > (n_out + 1) / 2 && l > q[2]) {
-            const size_t shift = std::min(l - q[2], q[0] - (n_out + 1) / 2);
-            q[0] -= shift;
-            q[2] += shift;
+    // letter of every output position for input class c, before scarcity: S[(x + k) mod |S|], S = the other two classes (+ c)
+    auto position_step = [&](size_t j) {
+        const size_t x = j * 8 / n_out, first = (x * n_out + 7) / 8;
+        return x + (j >= first ? j - first : 0);
+    };
+    auto plan = [&](int c, std::vector<int>& want) -> size_t {    // returns the plan's score (see the end)
+        const int S[3] = {(c + 1) % 3, (c + 2) % 3, c};
+        size_t avail[4] = {by[0].size(), by[1].size(), by[2].size(), by[3].size()};
+        avail[c] -= n_in;
+        want.assign(n_out, -1);
+        std::vector<size_t> pos[3];
+        for (size_t j = 0; j < n_out; ++j) {
+            want[j] = S[position_step(j) % (size_t)out_classes];
+            pos[want[j]].push_back(j);
         }
-        return q[0] + q[1] + q[2] + q[3] == n_out;
+        size_t kept = 0;
+        std::vector<size_t> orphans;                           // positions whose class is short, evenly spaced within that class's positions
+        for (int k = 0; k < 3; ++k) {
+            const size_t need = pos[k].size(), have = std::min(need, avail[k]);
+            kept += have;
+            avail[k] -= have;
+            const size_t miss = need - have;
+            for (size_t m = 0; m < miss; ++m) orphans.push_back(pos[k][(2 * m + 1) * need / (2 * miss)]);
+        }
+        std::sort(orphans.begin(), orphans.end());
+        for (size_t j : orphans) {
+            // the largest surplus, classes outside the rotation first (an orphan of B given to C would put C next to C), unclassified last
+            int best = -1;
+            for (int pass = 0; pass < 3 && best < 0; ++pass)
+                for (int k = 0; k < 3; ++k) {
+                    const bool in_rotation = out_classes == 3 || k != c;
+                    if (pass == 0 && in_rotation) continue;
+                    if (pass == 1 && k == want[j]) continue;
+                    if (avail[k] && (best < 0 || avail[k] > avail[best])) best = k;
+                }
+            if (best < 0 && avail[3]) best = 3;
+            want[j] = best;                                    // -1: the pool is too small
+            if (best >= 0) --avail[best];
+        }
+        // the plan's worth: every position filled, then the most crowded class as small as possible (what is left of the alternation
+        // when a class is scarce: in A | out A and B alternating 0.855, out mostly B 0.80), then positions that kept their letter
+        size_t count[4] = {0, 0, 0, 0}, filled = 0;
+        for (int k : want) if (k >= 0) { ++count[k]; ++filled; }
+        const size_t crowd = std::max(std::max(count[0], count[1]), std::max(count[2], count[3]));
+        return (filled << 40) + ((n_out - crowd) << 20) + kept;
     };
     int best_c = -1;
     size_t best_score = 0;
+    std::vector<int> want, best_want;
     for (int c = 0; c < 3; ++c) {
         if (by[c].size() < n_in) continue;
-        size_t q[4];
-        int src[4];
-        if (!quotas(c, q, src)) continue;
-        // first: how much of the output does NOT come from its dominant source (what can alternate); then: how much avoids the input's class
-        const size_t score = 4 * (n_out - std::max(std::max(q[0], q[1]), std::max(q[2], q[3]))) + (q[0] + q[1]) + 1;
-        if (score > best_score) { best_score = score; best_c = c; }
+        const size_t score = plan(c, want) + 1;
+        if (score > best_score || (score == best_score && by[c].size() > by[best_c].size())) { best_score = score; best_c = c; best_want = want; }
     }
-    size_t q[4] = {0, 0, 0, 0};
-    int src[4] = {0, 1, 2, 3};
-    if (best_c >= 0) quotas(best_c, q, src);
     if (best_c < 0) {                                           // no class can hold the input: as created
         for (size_t g = 0; g < n_in + n_out && g < n; ++g) order.push_back((int)g);
         return;
     }
     size_t next[4] = {0, 0, 0, 0};
     for (size_t i = 0; i < n_in; ++i) order.push_back(by[best_c][next[best_c]++]);
-    // even spreading, `run` chunks at a time: the source furthest behind its share of the output so far goes next
-    size_t used[4] = {0, 0, 0, 0}, placed = 0;
-    while (placed < n_out) {
-        int k_best = -1;
-        double lag_best = -1e300;
-        for (int k = 0; k < 4; ++k) {
-            if (used[k] >= q[k]) continue;
-            const double lag = (double)q[k] * (double)(placed + run) / (double)n_out - (double)used[k];
-            if (lag > lag_best) { lag_best = lag; k_best = k; }
-        }
-        if (k_best < 0) break;
-        for (size_t r = 0; r < run && used[k_best] < q[k_best] && placed < n_out; ++r, ++used[k_best], ++placed)
-            order.push_back(by[src[k_best]][next[src[k_best]]++]);
+    for (size_t j = 0; j < n_out; ++j) {
+        const int k = best_want[j];
+        if (k < 0 || next[k] >= by[k].size()) break;
+        order.push_back(by[k][next[k]++]);
     }
+}
+
+// Live FL_LAYOUT_INTERLEAVED pairs, for the launchers: a call whose buffers lie inside ONE constructed pair runs under the whole-column tile
+// map whatever fl_window_table.inc says -- the table's windows (pack, the transposes, delta ...) are what plain allocations want (a window
+// keeps the eight XCDs' reads inside one class of memory), while a constructed pair already has its input inside one class and wants the
+// eight write positions spread over the output's rotation: w=31 never loses there and gains 1-3 % on every row the table windows
+// (profiles/r06_window_matrix_constructed.txt; pack u32 W=7 0.821 -> 0.836, then 0.859 with the three-class output rotation).
+constexpr int LIVE_PAIRS = 32;
+std::atomic<uintptr_t> g_live_lo[LIVE_PAIRS], g_live_hi[LIVE_PAIRS];
+std::atomic<int> g_live_count{0};
+void live_pair_add(const char* va, size_t bytes)
+{
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(va);
+    for (int i = 0; i < LIVE_PAIRS; ++i) {
+        uintptr_t none = 0;
+        if (g_live_hi[i].load(std::memory_order_relaxed) == 0 && g_live_lo[i].compare_exchange_strong(none, lo, std::memory_order_acq_rel)) {
+            g_live_hi[i].store(lo + bytes, std::memory_order_release);
+            g_live_count.fetch_add(1, std::memory_order_release);
+            return;
+        }
+    }                                                           // more than 32 live pairs: the later ones launch by the table
+}
+void live_pair_remove(const char* va)
+{
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(va);
+    for (int i = 0; i < LIVE_PAIRS; ++i)
+        if (g_live_lo[i].load(std::memory_order_acquire) == lo && g_live_hi[i].load(std::memory_order_acquire) != 0) {
+            g_live_hi[i].store(0, std::memory_order_release);
+            g_live_lo[i].store(0, std::memory_order_release);
+            g_live_count.fetch_sub(1, std::memory_order_release);
+            return;
+        }
+}
+
+// at least two of a call's pointers inside one live constructed pair (its input and its output; widths[] / offsets[] / references may live anywhere)
+bool fl_in_constructed_pair(std::initializer_list<const void*> ptrs)
+{
+    if (g_live_count.load(std::memory_order_acquire) == 0) return false;
+    for (int i = 0; i < LIVE_PAIRS; ++i) {
+        const uintptr_t hi = g_live_hi[i].load(std::memory_order_acquire), lo = g_live_lo[i].load(std::memory_order_acquire);
+        if (!hi) continue;
+        int inside = 0;
+        for (const void* p : ptrs) {
+            const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+            inside += (a >= lo && a < hi);
+        }
+        if (inside >= 2) return true;
+    }
+    return false;
 }
 
 hipError_t pair_alloc_interleaved(size_t in_bytes, size_t aux_bytes, size_t out_bytes, hipStream_t s, ColumnPair& p, int& rc)
@@ -1035,7 +1110,9 @@ hipError_t pair_alloc_interleaved(size_t in_bytes, size_t aux_bytes, size_t out_
     // enough chunks that a third of them holds the input and the other two thirds hold half the output each -- and twice the pair, because
     // the classes come in clusters of 4 .. 16 chunks (profiles/r06_vmm_placement.txt): a pool of just the pair's size often lacks one class
     // ... and never less than 48 GiB of them: a small pair's pool would otherwise lie inside one or two clusters
-    size_t n_pool = std::max(std::max(std::max(3 * n_in, (3 * n_out + 1) / 2), 2 * (n_in + n_out)), 48 * PAIR_GIB / chunk);
+    // (with the output rotating through all three classes the input's class carries n_in + n_out / 3 of them)
+    const int out_classes = pair_pad(out_bytes) >= 3 * in_span ? 2 : 3;
+    size_t n_pool = std::max(std::max(std::max(3 * n_in + (out_classes == 3 ? n_out : 0), (3 * n_out + 1) / 2), 2 * (n_in + n_out)), 48 * PAIR_GIB / chunk);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 3 * PAIR_GIB) n_pool = std::min(n_pool, (free_b - 2 * PAIR_GIB) / chunk);
     if (n_pool < n_in + n_out) return hipErrorOutOfMemory;
@@ -1071,7 +1148,7 @@ hipError_t pair_alloc_interleaved(size_t in_bytes, size_t aux_bytes, size_t out_
     if (e != hipSuccess || rc != FL_OK) { drop_pool(); return e; }
     // 2. the pair's chunks in their final order, mapped ONCE into the address range the caller gets
     std::vector<int> order;
-    choose_chunks(cls, n_in, n_out, std::max<size_t>(1, 2 * PAIR_GIB / chunk), order);
+    choose_chunks(cls, n_in, n_out, out_classes, order);
     if (order.size() < n_in + n_out) { drop_pool(); return hipErrorOutOfMemory; }
     std::vector<char> keep(pool.size(), 0);
     for (int g : order) keep[g] = 1;
@@ -1093,6 +1170,7 @@ hipError_t pair_alloc_interleaved(size_t in_bytes, size_t aux_bytes, size_t out_
     p.in = p.va;
     p.aux = aux_bytes ? p.va + pair_pad(in_bytes) : nullptr;
     p.out = p.va + n_in * chunk;
+    live_pair_add(p.va, p.va_bytes);
     return hipSuccess;
 }
 
@@ -1285,11 +1363,11 @@ int fl_internal_selftune_check(int op, unsigned type_bits, unsigned width, const
     return rc;
 }
 
-size_t fl_internal_choose_chunks(const int* classes, size_t n_pool, size_t n_in, size_t n_out, size_t run, int* order)
+size_t fl_internal_choose_chunks(const int* classes, size_t n_pool, size_t n_in, size_t n_out, int out_classes, int* order)
 {
     if (!classes || !order || n_pool == 0) return 0;
     std::vector<int> cls(classes, classes + n_pool), chosen;
-    choose_chunks(cls, n_in, n_out, run ? run : 1, chosen);
+    choose_chunks(cls, n_in, n_out, out_classes, chosen);
     for (size_t i = 0; i < chosen.size(); ++i) order[i] = chosen[i];
     return chosen.size();
 }

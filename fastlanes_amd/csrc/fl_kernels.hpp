@@ -83,12 +83,21 @@ inline int& window_override_this_thread()
     static thread_local int v = 0;
     return v;
 }
+// set by every device-tier entry point of the C ABI (fl_capi.hip: FL_DEVICE_TIER) for the launches it makes: the call's buffers lie
+// inside one live FL_LAYOUT_INTERLEAVED pair.  Such a pair has its input inside one class of memory and its output rotating through
+// classes by the whole-column map's write positions; the table's windows are for plain allocations (they keep the eight XCDs' reads
+// inside one class) and lose 1-4 % here on every row that has one (profiles/r06_window_matrix_constructed.txt).
+inline bool& constructed_pair_this_thread()
+{
+    static thread_local bool v = false;
+    return v;
+}
 // window_shift of a launch: the (op, type)'s window from the generated table (or the override) in blocks -> tiles of `tile_blocks` blocks
 inline unsigned tile_window_shift(WindowOp op, unsigned type_bits, unsigned tile_blocks)
 {
     const int mine = window_override_this_thread();
     const int ov = mine ? mine : window_override().load(std::memory_order_relaxed);
-    const int lg = ov ? ov : window_log2_blocks(op, type_bits);
+    const int lg = ov ? ov : constructed_pair_this_thread() ? (int)WINDOW_WHOLE : window_log2_blocks(op, type_bits);
     if (lg >= WINDOW_WHOLE) return 63u;
     int tl = 0;
     while ((2u << tl) <= tile_blocks) ++tl;                  // floor(log2(tile_blocks))

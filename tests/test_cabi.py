@@ -309,27 +309,45 @@ def test_zone_aware_placement_helper_arithmetic():
 
 def test_constructed_layout_chooses_chunks_by_class(lib):
     """fl_internal_choose_chunks = the arrangement FL_LAYOUT_INTERLEAVED makes from a measured class map (a pure host function): the input
-    inside ONE class, the output spread over the others so that no class carries much more than half where that can be avoided, no chunk
-    used twice; creation order where no class can hold the input (in A | out B/C alternating 0.865, out A/B 0.855,
-    out B alone 0.80, out A 0.78 of the peak)."""
+    inside ONE class; the output rotating through the other two classes (a write-dominated pair) or through all three, by POSITION -- the
+    k-th chunk of the x-th eighth takes letter (x + k), so that the eight XCDs' write positions under the whole-column tile map cycle
+    through the classes at every moment; a scarce class's positions go to the largest surplus, classes outside the rotation first; no
+    chunk used twice; creation order where no class can hold the input (unpack u32 W=7 in A | out B/C 0.865, out
+    A/B/C 0.860, out A/B 0.855, out B alone 0.80, out A 0.78 of the peak; pack u32 W=7 out A/B/C 0.859, out B/C 0.84)."""
     import random
 
-    def choose(classes, n_in, n_out, run=2):
+    def choose(classes, n_in, n_out, out_classes=2):
         m = {"A": 0, "B": 1, "C": 2, "?": -1}
         c = (ctypes.c_int * len(classes))(*[m[x] for x in classes])
         o = (ctypes.c_int * (n_in + n_out))()
-        k = lib.fl_internal_choose_chunks(c, len(classes), n_in, n_out, run, o)
+        k = lib.fl_internal_choose_chunks(c, len(classes), n_in, n_out, out_classes, o)
         idx = list(o[:k])
         assert len(set(idx)) == len(idx) and all(0 <= i < len(classes) for i in idx)
         return "".join(classes[i] for i in idx[:n_in]), "".join(classes[i] for i in idx[n_in:]), idx
 
-    # a balanced pool: the input in one class, the output alternating between the other two in runs of 2
-    cin, cout, _ = choose("AAAABBBBCCCC" * 8, 9, 39)
-    assert len(set(cin)) == 1 and cin[0] not in cout and abs(cout.count(cout[0]) - (39 - cout.count(cout[0]))) <= 2
-    assert all(len(set(cout[i:i + 4])) == 2 for i in range(0, 36, 2))
-    # one class scarce (what a box handed out in round 6): the input's left-overs join the rotation, no class carries > half + 1
+    def positions(cout, t):
+        """classes under the eight XCDs' write positions when every XCD is a fraction t through its eighth of the output"""
+        n = len(cout)
+        return [cout[min(n - 1, int((x + t) * n / 8))] for x in range(8)]
+
+    # a balanced pool, write-dominated pair: the input in one class, the output over the other two, 4 + 4 under the eight positions at all times
+    for n_out in (31, 39, 48, 27):
+        cin, cout, _ = choose("AAAABBBBCCCC" * 10, 9, n_out)
+        assert len(set(cin)) == 1 and cin[0] not in cout and abs(cout.count(cout[0]) - (n_out - cout.count(cout[0]))) <= 3
+        for t in (0.0, 0.26, 0.5, 0.77, 0.99):
+            ps = positions(cout, t)
+            assert 3 <= ps.count(ps[0]) <= 5, (n_out, t, cout, ps)
+    # ... the same pool, read-dominated pair: all three classes under the eight positions at all times, none more than 4 times
+    for n_in, n_out in ((31, 7), (39, 9), (20, 20), (16, 25)):
+        cin, cout, _ = choose("AAAABBBBCCCC" * 14, n_in, n_out, 3)
+        assert len(set(cin)) == 1 and len(set(cout)) == 3
+        assert max(cout.count(x) for x in "ABC") - min(cout.count(x) for x in "ABC") <= 3
+        for t in (0.0, 0.3, 0.6, 0.95):
+            ps = positions(cout, t)
+            assert len(set(ps)) == 3 and max(ps.count(x) for x in "ABC") <= 4, (n_in, n_out, t, cout, ps)
+    # one class scarce (what a box handed out in round 6): the input's left-overs take the missing positions, no class carries > half + 1
     cin, cout, _ = choose("B" * 38 + "C" * 50 + "AAA" + "C" * 14, 9, 39)
-    assert len(set(cin)) == 1 and max(cout.count(x) for x in "ABC") <= 20 and len(set(cout)) == 3
+    assert len(set(cin)) == 1 and max(cout.count(x) for x in "ABC") <= 21 and len(set(cout)) == 3
     assert all(len(set(cout[i:i + 6])) >= 2 for i in range(0, 33))          # every stretch of the output mixes classes
     # two classes only
     cin, cout, _ = choose("A" * 80 + "B" * 16, 9, 39)
@@ -343,12 +361,13 @@ def test_constructed_layout_chooses_chunks_by_class(lib):
     # a pool that is too small yields fewer indices, never a repeated one
     _, _, idx = choose("ABCABC", 3, 9)
     assert len(idx) <= 6
-    # seeded fuzz: never a duplicate, the input single-class whenever some class can hold it
+    # seeded fuzz: never a duplicate, the input single-class whenever some class can hold it, every index delivered while the pool has chunks
     rnd = random.Random(6)
-    for _ in range(200):
+    for _ in range(300):
         n = rnd.randint(8, 160)
         classes = "".join(rnd.choice("AAABBC?") for _ in range(n))
         n_in, n_out = rnd.randint(1, n // 3), rnd.randint(1, n // 2)
-        cin, cout, idx = choose(classes, n_in, n_out, rnd.choice((1, 2, 4)))
-        if len(idx) == n_in + n_out and any(classes.count(x) >= n_in for x in "ABC") and idx != list(range(n_in + n_out)):
+        cin, cout, idx = choose(classes, n_in, n_out, rnd.choice((2, 3)))
+        assert len(idx) == n_in + n_out
+        if any(classes.count(x) >= n_in for x in "ABC") and idx != list(range(n_in + n_out)):
             assert len(set(cin)) == 1

@@ -1932,6 +1932,26 @@ def test_interleaved_column_pair_is_constructed_from_measured_chunks(fl, oracle,
         pair.free()
     (a0, a1), (b0, b1) = pairs
     assert b0 >= a1 or b1 <= a0, "an interleaved pair re-used a freed pair's addresses"
+    # the encode direction: a read-dominated pair's output rotates through ALL three classes, and calls whose buffers lie inside one live
+    # constructed pair launch under the whole-column tile map (fl_kernels.hpp: constructed_pair_this_thread) -- the same bytes as in plain
+    # tensors, for pack and for a 1 : 1 stream (transpose), and the plain-tensor calls in between are unaffected
+    vals = fl.BitPacking.unpack(W, pk)
+    want_pk, want_tr = fl.BitPacking.pack(W, vals), fl.Transpose.transpose(vals)
+    enc = pl.ColumnPair(ob, ib, "cuda:0", layout="interleaved")
+    assert enc.layout == "interleaved" and len(enc.classes) == n_out + -(-ib // chunk)
+    if set(enc.classes) >= {"A", "B", "C"}:
+        assert len(set(enc.classes[:n_out])) == 1, enc.classes
+    enc.input.view(torch.uint32).copy_(vals)
+    enc.output.fill_(0xEE)
+    assert torch.equal(fl.BitPacking.pack(W, enc.input.view(torch.uint32), output=enc.output.view(torch.uint32)), want_pk)
+    assert torch.equal(fl.BitPacking.pack(W, vals), want_pk)
+    enc.free()
+    tr = pl.ColumnPair(ob, ob, "cuda:0", layout="interleaved")
+    tr.input.view(torch.uint32).copy_(vals)
+    assert torch.equal(fl.Transpose.transpose(tr.input.view(torch.uint32), output=tr.output.view(torch.uint32)), want_tr)
+    assert torch.equal(fl.Transpose.untranspose(tr.output.view(torch.uint32), output=tr.input.view(torch.uint32)), vals)
+    tr.free()
+    del vals, want_pk, want_tr
     auto = pl.ColumnPair(ib, ob, "cuda:0", layout="auto")
     assert "interleaved" in auto.probe_GBps and "separate" in auto.probe_GBps and all(v > 1000 for v in auto.probe_GBps.values())
     best = max(auto.probe_GBps.values())

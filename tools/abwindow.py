@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of the tile-map window (fl_kernels.hpp: xcd_tile) for every kernel family, same buffers, launches interleaved round-robin.
-    python tools/abwindow.py [--reps 9] [--gb 48] [--windows 31,12,14,16,18,20]
+    python tools/abwindow.py [--reps 9] [--gb 48] [--windows 31,12,14,16,18,20] [--cases matrix] [--ops pack,delta] [--constructed]
 Window = log2 of the window in 1024-value blocks (fastlanes_amd_internal.h: policy bits 25-29); 31 = one window = the whole-column
 map of rounds 1-3; 0 = the library's own choice per kernel.  Prints GB/s of algorithmic bytes per (op, window)."""
 import argparse
@@ -25,6 +25,26 @@ def filled(nbytes, seed):
     return t
 
 
+CONSTRUCTED = False
+_pairs = []
+
+
+def buffers(in_bytes, out_bytes, aux_bytes=0):
+    """(input filled with random bits, aux likewise, output) -- plain tensors, or with --constructed one fl_column_pair_alloc(INTERLEAVED)
+    pair per case (the input + aux inside one class of memory, the output alternating between the other two: DESIGN.md section 4)"""
+    if not CONSTRUCTED:
+        return filled(in_bytes, 1), (filled(aux_bytes, 2) if aux_bytes else None), torch.empty(out_bytes, dtype=torch.uint8, device=dev)
+    from fastlanes_amd import placement as pl
+    while _pairs:
+        _pairs.pop().free()
+    pair = pl.ColumnPair(in_bytes, out_bytes, dev, aux_bytes=aux_bytes, layout="interleaved")
+    _pairs.append(pair)
+    assert lib.fl_fill_random(pair.input.data_ptr(), in_bytes & ~7, 1, None) == 0
+    if aux_bytes:
+        assert lib.fl_fill_random(pair.aux.data_ptr(), aux_bytes & ~7, 2, None) == 0
+    return pair.input, (pair.aux if aux_bytes else None), pair.output
+
+
 def case(op, ty, w, gb):
     """(label, algorithmic bytes per launch, callable)"""
     T, esz = ESZ[ty] * 8, ESZ[ty]
@@ -35,26 +55,29 @@ def case(op, ty, w, gb):
     n = min(10_000_000, int(gb * 1e9 / per))
     v = lambda t: t.view(TDT[ty])
     if op in ("unpack", "undelta_pack", "undelta_pack_untranspose"):
-        src, dst = v(filled(n * pk, 1)), v(torch.empty(n * un, dtype=torch.uint8, device=dev))
+        src, bases, dst = buffers(n * pk, n * un, 0 if op == "unpack" else n * 128)
+        src, dst = v(src), v(dst)
         if op == "unpack":
             f = lambda: fl.BitPacking.unpack(w, src, output=dst)
         else:
-            bases = v(filled(n * 128, 2))
+            bases = v(bases)
             g = getattr(fl.Delta, op)
             f = lambda: g(w, src, bases, output=dst)
     elif op in ("pack", "transpose_delta_pack"):
-        src, dst = v(filled(n * un, 1)), v(torch.empty(n * pk, dtype=torch.uint8, device=dev))
+        src, bases, dst = buffers(n * un, n * pk, 0 if op == "pack" else n * 128)
+        src, dst = v(src), v(dst)
         if op == "pack":
             f = lambda: fl.BitPacking.pack(w, src, output=dst)
         else:
-            bases = v(filled(n * 128, 2))
+            bases = v(bases)
             f = lambda: fl.Delta.transpose_delta_pack(w, src, bases, output=dst)
     elif op in ("delta", "undelta"):
-        src, bases, dst = v(filled(n * un, 1)), v(filled(n * 128, 2)), v(torch.empty(n * un, dtype=torch.uint8, device=dev))
+        src, bases, dst = (v(t) for t in buffers(n * un, n * un, n * 128))
         g = getattr(fl.Delta, op)
         f = lambda: g(src, bases, output=dst)
     elif op in ("transpose", "untranspose"):
-        src, dst = v(filled(n * un, 1)), v(torch.empty(n * un, dtype=torch.uint8, device=dev))
+        src, _, dst = buffers(n * un, n * un)
+        src, dst = v(src), v(dst)
         g = getattr(fl.Transpose, op)
         f = lambda: g(src, output=dst)
     elif op == "unpack_compare":
@@ -82,7 +105,12 @@ def main():
     ap.add_argument("--gb", type=float, default=48.0)
     ap.add_argument("--windows", default="31,12,14,16,18,20")
     ap.add_argument("--cases", default="all")
+    ap.add_argument("--ops", default="", help="keep only these ops of the chosen cases")
+    ap.add_argument("--constructed", action="store_true",
+                    help="every materialising case's buffers from fl_column_pair_alloc(FL_LAYOUT_INTERLEAVED) instead of plain tensors")
     args = ap.parse_args()
+    global CONSTRUCTED
+    CONSTRUCTED = args.constructed
     windows = [int(x) for x in args.windows.split(",")]
     cases = [("unpack", "u32", 7), ("pack", "u32", 7), ("unpack", "u64", 17), ("pack", "u64", 17), ("undelta_pack", "u32", 12),
              ("unpack_mixed", "u32", 0), ("unpack", "u16", 3), ("pack", "u16", 3), ("unpack", "u8", 3), ("pack", "u8", 3),
@@ -103,7 +131,9 @@ def main():
     elif args.cases != "all":
         keep = args.cases.split(",")
         cases = [c for c in cases if c[0] in keep]
-    print(f"# {lib.fl_version().decode()}\n# GB/s of algorithmic bytes (fraction of 8 TB/s), median of {args.reps} round-robin launches per window; window = log2 blocks, "
+    if args.ops:
+        cases = [c for c in cases if c[0] in args.ops.split(",")]
+    print(f"# {lib.fl_version().decode()}" + ("  [buffers: constructed pairs]" if CONSTRUCTED else "") + f"\n# GB/s of algorithmic bytes (fraction of 8 TB/s), median of {args.reps} round-robin launches per window; window = log2 blocks, "
           "31 = whole column (rounds 1-3), 0 = the library's per-kernel default", flush=True)
     print(f"{'case':58s} " + " ".join(f"{('w=' + str(x)):>13s}" for x in [0] + windows), flush=True)
     for op, ty, w in cases:

@@ -683,6 +683,18 @@ int main(int argc, char** argv)
     print_classes(p.cls);
     std::vector<std::vector<int>> by_class(n_classes + 1);
     for (size_t g = 0; g < n_chunks; ++g) by_class[p.cls[g] < 0 ? n_classes : p.cls[g]].push_back((int)g);
+    if (getenv("EXP_LAYOUTS")) {                               // letters by plenty: 'A' = the class with the most chunks (a layout's big side fits)
+        std::vector<int> perm(n_classes);
+        for (int c = 0; c < n_classes; ++c) perm[c] = c;
+        std::sort(perm.begin(), perm.end(), [&](int a, int b) { return by_class[a].size() > by_class[b].size(); });
+        std::vector<std::vector<int>> sorted(n_classes + 1);
+        for (int c = 0; c < n_classes; ++c) sorted[c] = by_class[perm[c]];
+        sorted[n_classes] = by_class[n_classes];
+        by_class.swap(sorted);
+        for (int c = 0; c < n_classes; ++c) for (int g : by_class[c]) p.cls[g] = c;
+        printf("classes relabelled by plenty:\n");
+        print_classes(p.cls);
+    }
     for (int c = 0; c < n_classes; ++c) printf("class %c: %zu chunks; ", 'A' + c, by_class[c].size());
     printf("unclassified: %zu\n", by_class[n_classes].size());
     unmap_chunks(va, p, n_chunks);
@@ -695,8 +707,10 @@ int main(int argc, char** argv)
     size_t in_bytes, out_bytes;
     unsigned W = 7;
     bool mixed = false, pack = false;
-    if (workload == "unpack32w7") { in_bytes = n_blocks * 128 * W; out_bytes = n_blocks * 4096; }
-    else if (workload == "pack32w7") { pack = true; in_bytes = n_blocks * 4096; out_bytes = n_blocks * 128 * W; }
+    bool transpose = false;
+    if (workload.rfind("unpack32w", 0) == 0) { W = (unsigned)atoi(workload.c_str() + 9); in_bytes = n_blocks * 128 * W; out_bytes = n_blocks * 4096; }
+    else if (workload.rfind("pack32w", 0) == 0) { pack = true; W = (unsigned)atoi(workload.c_str() + 7); in_bytes = n_blocks * 4096; out_bytes = n_blocks * 128 * W; }
+    else if (workload == "transpose32") { transpose = true; W = 32; in_bytes = out_bytes = n_blocks * 4096; }
     else if (workload == "mixed32") { mixed = true; in_bytes = 0; out_bytes = n_blocks * 4096; }
     else { printf("unknown workload\n"); return 1; }
     uint8_t* d_widths = nullptr;
@@ -737,6 +751,7 @@ int main(int argc, char** argv)
         const double bytes = (double)in_bytes + out_bytes;
         float k = median_ms(9, [&] {
             if (mixed) FL(fl_u32_unpack_widths(d_widths, d_offsets, (const uint32_t*)in, in_bytes, (uint32_t*)out, n_blocks, d_err, nullptr));
+            else if (transpose) FL(fl_u32_transpose((const uint32_t*)in, (uint32_t*)out, n_blocks, nullptr));
             else if (pack) FL(fl_u32_pack(W, (const uint32_t*)in, (uint32_t*)out, n_blocks, nullptr));
             else FL(fl_u32_unpack(W, (const uint32_t*)in, (uint32_t*)out, n_blocks, nullptr));
         });
@@ -746,7 +761,11 @@ int main(int argc, char** argv)
     };
 
     // a layout = class pattern of the input chunks + class pattern of the output chunks + run length (chunks per letter)
-    struct Layout { std::string name, in_pat, out_pat; int run; };
+    struct Layout { std::string name, in_pat, out_pat; int run; int in_run = 1; };
+    if (const char* pol = getenv("EXP_POLICY")) {              // fl_internal_set_kernel_policy for every launch (e.g. 31 << 25 = whole-column tile map)
+        fl_internal_set_kernel_policy(atoi(pol));
+        printf("kernel policy %d (fastlanes_amd_internal.h)\n", fl_internal_get_kernel_policy());
+    }
     std::vector<Layout> layouts = {
         {"in A   | out A", "A", "A", 1},       {"in A   | out B", "A", "B", 1},         {"in A   | out AB/1", "A", "AB", 1},
         {"in A   | out BC/1", "A", "BC", 1},   {"in A   | out ABC/1", "A", "ABC", 1},   {"in A   | out BC/4", "A", "BC", 4},
@@ -754,13 +773,37 @@ int main(int argc, char** argv)
         {"in BC  | out BC/1", "BC", "BC", 1},  {"in A   | out BCB then CBC eighths", "A", "BC", -8},
         {"in A   | out B then A", "A", "BA", -1}, {"in A   | out ABC/2", "A", "ABC", 2}, {"in A   | out ABC thirds", "A", "ABC", -3},
     };
+    if (const char* spec = getenv("EXP_LAYOUTS")) {            // "inpat,inrun,outpat,outrun;..." (run > 0: chunks per letter; < 0: |run| equal stretches)
+        layouts.clear();
+        std::string all = spec;
+        size_t at = 0;
+        while (at < all.size()) {
+            size_t end = all.find(';', at);
+            if (end == std::string::npos) end = all.size();
+            const std::string one = all.substr(at, end - at);
+            char ip[32] = {0}, op[32] = {0};
+            int ir = 1, orun = 1;
+            if (sscanf(one.c_str(), "%31[A-C],%d,%31[A-C],%d", ip, &ir, op, &orun) == 4 && ir && orun) {
+                Layout L{"in " + std::string(ip) + "/" + std::to_string(ir) + " | out " + op + "/" + std::to_string(orun), ip, op, orun};
+                L.in_run = ir;
+                layouts.push_back(L);
+            } else printf("EXP_LAYOUTS: cannot read '%s'\n", one.c_str());
+            at = end + 1;
+        }
+    }
     struct Result { std::vector<double> k, s; bool ok = true; };
     std::vector<Result> res(layouts.size() + 2);
     // take chunks of the asked class round-robin from per-class free lists; run < 0: |run| equal stretches over the buffer
     auto build = [&](const std::string& pat, int run, size_t n, std::vector<size_t>& next, std::vector<int>& idx) -> bool {
         idx.clear();
         for (size_t i = 0; i < n; ++i) {
-            const size_t step = run > 0 ? i / run : i * (size_t)(-run) / n;
+            // run 99 = by POSITION under the whole-column tile map: XCD x walks the x-th eighth of the buffer, all eight at the same pace, so
+            // chunk i = the k-th chunk of eighth x gets letter (x + k): at any moment the eight write positions cycle through the letters
+            size_t step = run > 0 ? i / run : i * (size_t)(-run) / n;
+            if (run == 99) {
+                const size_t x = i * 8 / n, first = (x * n + 7) / 8;
+                step = x + (i >= first ? i - first : 0);
+            }
             const int c = pat[step % pat.size()] - 'A';
             if (c >= n_classes || next[c] >= by_class[c].size()) return false;
             idx.push_back(by_class[c][next[c]++]);
@@ -805,7 +848,7 @@ int main(int argc, char** argv)
             const Layout& L = layouts[li];
             std::vector<size_t> next(n_classes, 0);
             std::vector<int> idx_in, idx_out;
-            if (!build(L.in_pat, 1, n_in, next, idx_in) || !build(L.out_pat, L.run, n_out, next, idx_out)) { res[li].ok = false; continue; }
+            if (!build(L.in_pat, L.in_run, n_in, next, idx_in) || !build(L.out_pat, L.run, n_out, next, idx_out)) { res[li].ok = false; continue; }
             // a FRESH pair of address ranges for every layout: on this ROCm (7.2) hipMemUnmap + hipMemMap of OTHER chunks at an address that
             // was mapped before leaves the device reading and writing the FIRST chunks (exp_vmm remap; profiles/r06_vmm_remap.txt)
             CK(hipMemAddressReserve((void**)&va_in, n_in * chunk, va_align, nullptr, 0));
