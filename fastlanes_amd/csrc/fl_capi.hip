@@ -973,8 +973,9 @@ hipError_t reserve_fresh_range(size_t bytes, char** out)
 // Where a class cannot cover its share, the positions it misses (spread evenly) go to the class with the largest surplus, classes outside
 // the rotation first -- left-overs of the input's class, as in round 6's first version: in A | out A and B alternating is 0.855, out B alone
 // 0.80 -- then unclassified chunks.  Creation order (short class runs by nature: 0.854-0.861) when no class can hold the input.
-void choose_chunks(const std::vector<int>& cls, size_t n_in, size_t n_out, int out_classes, std::vector<int>& order)
+void choose_chunks(const std::vector<int>& cls, size_t n_in, size_t n_out, int out_classes, std::vector<int>& order, size_t* kept_out = nullptr)
 {
+    if (kept_out) *kept_out = 0;
     const size_t n = cls.size();
     order.clear();
     if (out_classes != 2) out_classes = 3;
@@ -985,6 +986,7 @@ void choose_chunks(const std::vector<int>& cls, size_t n_in, size_t n_out, int o
         const size_t x = j * 8 / n_out, first = (x * n_out + 7) / 8;
         return x + (j >= first ? j - first : 0);
     };
+    size_t last_kept = 0, best_kept = 0;
     auto plan = [&](int c, std::vector<int>& want) -> size_t {    // returns the plan's score (see the end)
         const int S[3] = {(c + 1) % 3, (c + 2) % 3, c};
         size_t avail[4] = {by[0].size(), by[1].size(), by[2].size(), by[3].size()};
@@ -1024,6 +1026,7 @@ void choose_chunks(const std::vector<int>& cls, size_t n_in, size_t n_out, int o
         size_t count[4] = {0, 0, 0, 0}, filled = 0;
         for (int k : want) if (k >= 0) { ++count[k]; ++filled; }
         const size_t crowd = std::max(std::max(count[0], count[1]), std::max(count[2], count[3]));
+        last_kept = kept;
         return (filled << 40) + ((n_out - crowd) << 20) + kept;
     };
     int best_c = -1;
@@ -1032,12 +1035,13 @@ void choose_chunks(const std::vector<int>& cls, size_t n_in, size_t n_out, int o
     for (int c = 0; c < 3; ++c) {
         if (by[c].size() < n_in) continue;
         const size_t score = plan(c, want) + 1;
-        if (score > best_score || (score == best_score && by[c].size() > by[best_c].size())) { best_score = score; best_c = c; best_want = want; }
+        if (score > best_score || (score == best_score && by[c].size() > by[best_c].size())) { best_score = score; best_c = c; best_want = want; best_kept = last_kept; }
     }
     if (best_c < 0) {                                           // no class can hold the input: as created
         for (size_t g = 0; g < n_in + n_out && g < n; ++g) order.push_back((int)g);
         return;
     }
+    if (kept_out) *kept_out = best_kept;
     size_t next[4] = {0, 0, 0, 0};
     for (size_t i = 0; i < n_in; ++i) order.push_back(by[best_c][next[best_c]++]);
     for (size_t j = 0; j < n_out; ++j) {
@@ -1124,32 +1128,48 @@ hipError_t pair_alloc_interleaved(size_t in_bytes, size_t aux_bytes, size_t out_
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
     std::vector<hipMemGenericAllocationHandle_t> pool;
-    pool.reserve(n_pool);
-    for (size_t i = 0; i < n_pool; ++i) {
-        hipMemGenericAllocationHandle_t h;
-        if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
-        pool.push_back(h);
-    }
     auto drop_pool = [&] { for (auto h : pool) (void)hipMemRelease(h); pool.clear(); };
-    if (pool.size() < n_in + n_out) { drop_pool(); return hipErrorOutOfMemory; }
-    // 1. every chunk's class, measured through a scratch address range (used once, never again)
-    std::vector<int> cls(pool.size(), -1);
-    char* scratch = nullptr;
-    e = reserve_fresh_range(pool.size() * chunk, &scratch);
-    if (e != hipSuccess) { drop_pool(); return e; }
-    size_t mapped = 0;
-    for (; mapped < pool.size() && e == hipSuccess; ++mapped) e = hipMemMap(scratch + mapped * chunk, chunk, 0, pool[mapped], 0);
-    if (e != hipSuccess) --mapped;
-    if (e == hipSuccess) e = hipMemSetAccess(scratch, pool.size() * chunk, &acc, 1);
-    if (e == hipSuccess) rc = probe_classes(scratch, pool.size(), chunk, cls.data(), s);
-    if (e == hipSuccess && rc == FL_OK) e = hipStreamSynchronize(s);
-    for (size_t i = 0; i < mapped; ++i) (void)hipMemUnmap(scratch + i * chunk, chunk);
-    (void)hipMemAddressFree(scratch, pool.size() * chunk);
-    if (e != hipSuccess || rc != FL_OK) { drop_pool(); return e; }
-    // 2. the pair's chunks in their final order, mapped ONCE into the address range the caller gets
-    std::vector<int> order;
-    choose_chunks(cls, n_in, n_out, out_classes, order);
-    if (order.size() < n_in + n_out) { drop_pool(); return hipErrorOutOfMemory; }
+    const size_t pool_cap = free_b > 3 * PAIR_GIB ? (free_b - 2 * PAIR_GIB) / chunk : n_pool;
+    std::vector<int> cls, order;
+    // The pool GROWS while the arrangement it allows is poor: the classes come in clusters of 4 .. 32 chunks, so a pool of the first size
+    // is sometimes two thirds one class (a box of round 6: in A x10 | out BAAAABBCAAABBAA -- Delta over a u8 column at 0.77 where a
+    // balanced pool gives 0.80).  A round = more chunks (half as many again, three rounds at most, never beyond three times the pair or the free memory), ALL of
+    // them classified again through a fresh scratch range (2.4 ms per chunk), the arrangement chosen again; "poor" = fewer than nine in
+    // ten output positions got the class the rotation asks for.
+    for (int round = 0;; ++round) {
+        pool.reserve(n_pool);
+        while (pool.size() < n_pool) {
+            hipMemGenericAllocationHandle_t h;
+            if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
+            pool.push_back(h);
+        }
+        if (pool.size() < n_in + n_out) { drop_pool(); return hipErrorOutOfMemory; }
+        // 1. every chunk's class, measured through a scratch address range (used once, never again)
+        cls.assign(pool.size(), -1);
+        char* scratch = nullptr;
+        e = reserve_fresh_range(pool.size() * chunk, &scratch);
+        if (e != hipSuccess) { drop_pool(); return e; }
+        size_t mapped = 0;
+        for (; mapped < pool.size() && e == hipSuccess; ++mapped) e = hipMemMap(scratch + mapped * chunk, chunk, 0, pool[mapped], 0);
+        if (e != hipSuccess) --mapped;
+        if (e == hipSuccess) e = hipMemSetAccess(scratch, pool.size() * chunk, &acc, 1);
+        if (e == hipSuccess) rc = probe_classes(scratch, pool.size(), chunk, cls.data(), s);
+        if (e == hipSuccess && rc == FL_OK) e = hipStreamSynchronize(s);
+        for (size_t i = 0; i < mapped; ++i) (void)hipMemUnmap(scratch + i * chunk, chunk);
+        (void)hipMemAddressFree(scratch, pool.size() * chunk);
+        if (e != hipSuccess || rc != FL_OK) { drop_pool(); return e; }
+        // 2. the pair's chunks in their final order
+        size_t kept = 0;
+        choose_chunks(cls, n_in, n_out, out_classes, order, &kept);
+        const bool complete = order.size() == n_in + n_out;
+        const size_t bigger = std::min(std::min(pool_cap, std::max<size_t>(3 * (n_in + n_out), 96)), pool.size() + std::max<size_t>(pool.size() / 2, 8));
+        if ((complete && 10 * kept >= 9 * n_out) || round == 3 || pool.size() < n_pool || bigger <= pool.size()) {
+            if (!complete) { drop_pool(); return hipErrorOutOfMemory; }
+            break;
+        }
+        n_pool = bigger;
+    }
+    // ... mapped ONCE into the address range the caller gets
     std::vector<char> keep(pool.size(), 0);
     for (int g : order) keep[g] = 1;
     p.chunk_bytes = chunk;

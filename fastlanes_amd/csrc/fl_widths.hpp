@@ -91,17 +91,20 @@ template <typename T> struct WaveBlock {
             for (int i = 0; i < 2; ++i) r.x[i] = ((cur.x[i] >> sh) | ((nxt.x[i] << 1) << (63u - sh))) & m;
         } else if constexpr (sizeof(T) == 4) {
             for (int i = 0; i < 4; ++i) r.x[i] = __builtin_amdgcn_alignbit(nxt.x[i], cur.x[i], sh) & m;
-        } else if constexpr (sizeof(T) == 2) {
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t lo = __builtin_amdgcn_perm(nxt.x[i], cur.x[i], 0x05040100u);   // nxt.h0 : cur.h0
-                const uint32_t hi = __builtin_amdgcn_perm(nxt.x[i], cur.x[i], 0x07060302u);   // nxt.h1 : cur.h1
-                r.x[i] = ((lo >> sh) & m) | (((hi >> sh) & m) << 16);
-            }
         } else {
+            // u16 / u8, all elements of a 32-bit word at once (round 6; was: even / odd elements split with two v_perm, 8 ops per word):
+            //   field = rep(mask(W)) & ((cur >> sh) | (nxt << (T - sh)))  per element
+            // with 32-bit shifts the neighbouring elements' bits bleed in, but only ABOVE bit T - sh of an element (from cur >> sh) and
+            // BELOW it (from nxt << (T - sh)), exactly where the other term's bits belong: `low` = the low T - sh bits of every element
+            // selects between the two (v_bfi_b32), the field mask is wave-uniform -- 4 VALU per word + 3 per cell for the lane's masks
+            constexpr uint32_t ALL = TB == 8 ? 0xffu : 0xffffu;
+            const uint32_t rm = TB == 8 ? (m | (m << 8)) : (m | (m << 16));        // field_mask(W) -> every element (wave-uniform)
+            const uint32_t b = ALL >> sh;
+            const uint32_t low = __builtin_amdgcn_perm(b, b, TB == 8 ? 0x00000000u : 0x01000100u);
+            const unsigned k = (unsigned)TB - sh;                                   // 1 .. T
             for (int i = 0; i < 4; ++i) {
-                const uint32_t ev = __builtin_amdgcn_perm(nxt.x[i], cur.x[i], 0x06020400u);   // nxt.b2:cur.b2 | nxt.b0:cur.b0
-                const uint32_t od = __builtin_amdgcn_perm(nxt.x[i], cur.x[i], 0x07030501u);   // nxt.b3:cur.b3 | nxt.b1:cur.b1
-                r.x[i] = ((ev >> sh) & m) | (((od >> sh) & m) << 8);
+                const uint32_t lo_part = cur.x[i] >> sh, hi_part = nxt.x[i] << k;
+                r.x[i] = rm & (((lo_part ^ hi_part) & low) ^ hi_part);              // v_bfi_b32(low, lo_part, hi_part)
             }
         }
         return r;
@@ -307,7 +310,7 @@ __device__ __forceinline__ void unpack_lds_image_to_global(const WidthsArgs& a, 
     const unsigned out_base = lane * 16u;
     const unsigned c16 = (lane & 7u) * 16u;
     const typename G::word_t m = G::field_mask(w);
-    unsigned bit = G::row_base(lane >> 3) * w;
+    unsigned bit = __umul24(G::row_base(lane >> 3), w);   // both < 2^7: the full-rate 24-bit multiply
     const unsigned step = G::KSTEP * w;
     const unsigned last = (w - 1u) * 128u;
     static_for<G::GROUPS>([&](auto K) {
@@ -373,6 +376,82 @@ __device__ __forceinline__ void unpack_blocks_wave_prefetched(const WidthsArgs& 
     }
 }
 
+// The same with the block count known at compile time and every block of the wavefront known to be valid (round 6).  A narrow type's
+// wavefront lives on instructions as much as on memory: per 6 KiB of traffic the u8 kernel above issued 223 VALU + 334 SALU + 79 branches
+// where u32's one-block wavefront issues 145 + 182 + 31, every instruction costs a wavefront ~7 cycles of its life, and with all eight
+// wave slots taken nothing else hides it (profiles/r06_wavelife_mixed.txt).  Here the preconditions of all BPW blocks are ONE per-lane
+// test and a ballot (any failure -> `false`: the caller runs the general function, which skips and reports block by block), the loops
+// are unrolled with the blocks' widths / offsets in SGPRs across the wait, one store descriptor serves the wavefront's BPW consecutive
+// output blocks, W = 0 needs no path of its own (an empty descriptor fetches nothing and the field mask is 0), and FoR's `+ reference`
+// is a template parameter instead of a branch per cell.
+template <typename T, unsigned BPW, bool REFS>
+__device__ __forceinline__ void unpack_images_to_global(const WidthsArgs& a, uint64_t first, const unsigned (&w)[BPW], const char* lds, unsigned lane, T rv)
+{
+    using G = WaveBlock<T>;
+    constexpr int TB = G::TB;
+    static_assert(BPW * G::BLOCK_BYTES <= 4096, "the blocks' store offsets must fit the 12-bit instruction offset");
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(a.unpacked + first * G::BLOCK_BYTES, 0, BPW * G::BLOCK_BYTES, 0x00020000);
+    const unsigned out_base = lane * 16u, c16 = (lane & 7u) * 16u, rb = G::row_base(lane >> 3);
+    static_for<(int)BPW>([&](auto J) {
+        constexpr unsigned j = decltype(J)::value;
+        const unsigned wj = w[j];
+        const char* img = lds + j * G::BLOCK_BYTES;
+        const typename G::word_t m = G::field_mask(wj);
+        unsigned bit = __umul24(rb, wj);
+        const unsigned step = G::KSTEP * wj, last = (wj - 1u) * 128u;         // W = 0: `last` wraps, the reads stay inside the image, m = 0
+        Cell<T> ref = Cell<T>::zero();
+        if constexpr (REFS) ref = Cell<T>::splat(readlane_elem<T>(rv, j));
+        static_for<G::GROUPS>([&](auto K) {
+            const unsigned word = bit >> G::LOG_TB, sh = bit & (TB - 1u);
+            const unsigned a0 = word * 128u;
+            const unsigned a1 = a0 + 128u < last ? a0 + 128u : last;        // the last row never reads past the end (macros.rs:156)
+            const Cell<T> cur = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(img + a0 + c16));
+            const Cell<T> nxt = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(img + a1 + c16));
+            Cell<T> v = G::funnel(cur, nxt, sh, m);
+            if constexpr (REFS) v = v.add(ref);                             // ffor.rs:46-48
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rs, out_base + (j * G::BLOCK_BYTES + decltype(K)::value * 1024u), 0,
+                                                   STORE_AUX);
+            bit += step;
+        });
+    });
+}
+
+template <typename T, unsigned BPW>
+__device__ __forceinline__ bool unpack_blocks_wave_static(const WidthsArgs& a, uint64_t first, char* lds, unsigned lane)
+{
+    using G = WaveBlock<T>;
+    constexpr int TB = G::TB;
+    const bool owner = lane < BPW;
+    const uint64_t mine = first + (owner ? lane : 0u);
+    unsigned wv = a.uniform_width;
+    if (a.widths) wv = a.widths[mine];
+    uint64_t ov = mine * (uint64_t)(128u * wv);
+    if (a.offsets) ov = a.offsets[mine];
+    T rv = 0;                                                 // FoR: lane j holds block first+j's reference, fetched with the metadata
+    if (a.refs) rv = static_cast<const T*>(a.refs)[mine * a.ref_stride];
+    // bitpacking.rs:126 unreachable!(), :111-113 -- all BPW blocks at once, lane j judging block first + j
+    if (__builtin_amdgcn_ballot_w64(block_precondition(a, wv, ov, TB) != 0u)) return false;
+    unsigned w[BPW];
+    static_for<(int)BPW>([&](auto J) {
+        constexpr unsigned j = decltype(J)::value;
+        w[j] = (unsigned)__builtin_amdgcn_readlane((int)wv, (int)j);
+        const uint64_t off = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ov >> 32), (int)j) << 32) |
+                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ov, (int)j);
+        // wave-uniform descriptor over exactly this block's 128*w bytes: cells past it read as 0, no fault; W = 0 fetches nothing
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.packed) + off, 0, 128u * w[j], 0x00020000);
+        char* img = lds + j * G::BLOCK_BYTES;
+        static_for<G::GROUPS>([&](auto Gi) {
+            constexpr int g = decltype(Gi)::value;
+            if (8u * g < w[j]) dma_1k_to_lds<RD_DMA_NT, g * 1024>(rs, img, lane);
+        });
+    });
+    wait_lds_dma();
+    wave_lds_fence();
+    if (a.refs) unpack_images_to_global<T, BPW, true>(a, first, w, lds, lane, rv);      // wave-uniform
+    else unpack_images_to_global<T, BPW, false>(a, first, w, lds, lane, rv);
+    return true;
+}
+
 // Wavefront -> blocks: workgroup `tile` (XCD-contiguous map) owns 4*bpw consecutive blocks, wavefront `wave` the bpw
 // consecutive ones starting at tile*4*bpw + wave*bpw.
 template <typename T, typename F>
@@ -400,6 +479,14 @@ __global__ __launch_bounds__(WG) void k_unpack_widths(WidthsArgs a)
 {
     for_each_block_of_wave<T>(a, [&](uint64_t first, unsigned count, char* lds, unsigned lane) {
         if (a.prefetch && count > 1) {
+            if constexpr (sizeof(T) <= 2) {                  // the shipped shapes of the narrow types, every block valid: the unrolled form
+                if (count == a.bpw) {
+                    if constexpr (sizeof(T) == 1) {
+                        if (a.bpw == 4 && unpack_blocks_wave_static<T, 4>(a, first, lds, lane)) return;
+                    }
+                    if (a.bpw == 2 && unpack_blocks_wave_static<T, 2>(a, first, lds, lane)) return;
+                }
+            }
             unpack_blocks_wave_prefetched<T>(a, first, count, lds, lane);
             return;
         }
@@ -417,8 +504,8 @@ __global__ __launch_bounds__(WG) void k_unpack_widths(WidthsArgs a)
 // contiguous chunk of R*w <= T bits of every FL lane's stream, starting at bit R*i*w: the lane splices its chunk together,
 // and the chunks of the lanes that share a packed word are merged with LDS atomic ORs (ds_or_b32) into a zeroed image of the
 // packed block (re-using the first KiB of the unpacked image, which is dead once every lane holds its rows).
-template <typename T>
-__device__ __forceinline__ void pack_narrow_from_lds_image(char* lds, unsigned w, char* packed_block, unsigned lane)
+template <typename T, bool REFS = false>
+__device__ __forceinline__ void pack_narrow_from_lds_image(char* lds, unsigned w, char* packed_block, unsigned lane, const Cell<T>& ref = Cell<T>::zero())
 {
     using G = WaveBlock<T>;
     using word_t = typename G::word_t;
@@ -431,7 +518,8 @@ __device__ __forceinline__ void pack_narrow_from_lds_image(char* lds, unsigned w
     word_t chunk[NW];
     for (int x = 0; x < NW; ++x) chunk[x] = 0;
     static_for<R>([&](auto J) {
-        const Cell<T> s = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(lds + G::row_cell_rt(R * i + decltype(J)::value) * 16u + c16));
+        Cell<T> s = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(lds + G::row_cell_rt(R * i + decltype(J)::value) * 16u + c16));
+        if constexpr (REFS) s = s.sub(ref);                   // ffor.rs:32-34 (before the mask of macros.rs:73)
         for (int x = 0; x < NW; ++x) chunk[x] |= (s.x[x] & mw) << (decltype(J)::value * w);
     });
     wave_lds_fence();                                         // every lane holds its rows: the image may be overwritten
@@ -479,14 +567,16 @@ __device__ constexpr uint32_t RECIP20[65] = {
     31776,  30841,   29960,  29128,  28340,  27595,  26887,  26215,  25576,  24967,  24386, 23832, 23302, 22796, 22311, 21846,
     21400,  20972,   20561,  20165,  19785,  19419,  19066,  18725,  18397,  18079,  17773, 17477, 17190, 16913, 16645, 16384};
 
-template <typename T>
-__device__ __forceinline__ void pack_from_lds_image(char* lds, unsigned w, char* packed_block, unsigned lane)
+// REFS: FoR's `input[idx] - reference` (ffor.rs:32-34) applied to every cell as it is read from the image (a cell is read by the one or two
+// lanes whose packed words hold bits of its row) -- for images that arrived by LDS-DMA and were never in registers
+template <typename T, bool REFS = false>
+__device__ __forceinline__ void pack_from_lds_image(char* lds, unsigned w, char* packed_block, unsigned lane, const Cell<T>& ref = Cell<T>::zero())
 {
     using G = WaveBlock<T>;
     using word_t = typename G::word_t;
     constexpr int TB = G::TB;
     if (w < 8u) {                                             // wave-uniform
-        pack_narrow_from_lds_image<T>(lds, w, packed_block, lane);
+        pack_narrow_from_lds_image<T, REFS>(lds, w, packed_block, lane, ref);
         return;
     }
     const unsigned c16 = (lane & 7u) * 16u, i = lane >> 3;
@@ -500,7 +590,8 @@ __device__ __forceinline__ void pack_from_lds_image(char* lds, unsigned w, char*
             unsigned r = (lo_bit * recip) >> 20;              // = lo_bit / w: first row with bits in this word
             const unsigned r_end = ((lo_bit + TB - 1u) * recip) >> 20;   // last such row (inclusive)
             for (; r <= r_end; ++r) {
-                const Cell<T> s = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(lds + G::row_cell_rt(r) * 16u + c16));
+                Cell<T> s = __builtin_bit_cast(Cell<T>, *reinterpret_cast<const u32x4*>(lds + G::row_cell_rt(r) * 16u + c16));
+                if constexpr (REFS) s = s.sub(ref);
                 const unsigned fb = r * w;                    // first stream bit of row r's field
                 if (fb >= lo_bit) {                           // field starts in this word: (src & mask(keep)) << shift  (macros.rs:73,79)
                     const unsigned sh = fb - lo_bit;
@@ -560,8 +651,9 @@ __device__ __forceinline__ void pack_block_wave(const WidthsArgs& a, uint64_t bl
 }
 
 // pack's counterpart of unpack_blocks_wave_prefetched: the `count` unpacked blocks of the wavefront arrive by LDS-DMA, one
-// image each, before the first one is packed.  FoR's `input[idx] - reference` (ffor.rs:32-34) is applied to the image in
-// place -- every lane to the cells it would have written on the VGPR route -- before any lane reads another lane's cells.
+// image each, before the first one is packed.  FoR's `input[idx] - reference` (ffor.rs:32-34) is applied by the packer as it reads
+// the image's cells (round 6; an in-place pass over the image -- one more LDS read, write and fence per block -- cost for_pack_widths u8
+// 6 % against pack_widths).
 template <typename T>
 __device__ __forceinline__ void pack_blocks_wave_prefetched(const WidthsArgs& a, uint64_t first, unsigned count, char* lds, unsigned lane)
 {
@@ -581,17 +673,6 @@ __device__ __forceinline__ void pack_blocks_wave_prefetched(const WidthsArgs& a,
         static_for<G::GROUPS>([&](auto K) { dma_1k_to_lds<RD_DMA_NT, decltype(K)::value * 1024>(in_rs, img, lane); });
     }
     wait_lds_dma();
-    if (a.refs) {                                             // wave-uniform
-        wave_lds_fence();
-        for (unsigned j = 0; j < count; ++j) {
-            const Cell<T> ref = Cell<T>::splat(readlane_elem<T>(rv, j));
-            char* img = lds + j * G::BLOCK_BYTES;
-            static_for<G::GROUPS>([&](auto K) {
-                u32x4* at = reinterpret_cast<u32x4*>(img + lane * 16u + decltype(K)::value * 1024u);
-                *at = __builtin_bit_cast(u32x4, __builtin_bit_cast(Cell<T>, *at).sub(ref));
-            });
-        }
-    }
     wave_lds_fence();
     for (unsigned j = 0; j < count; ++j) {
         const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)wv, (int)j);
@@ -602,7 +683,8 @@ __device__ __forceinline__ void pack_blocks_wave_prefetched(const WidthsArgs& a,
             continue;
         }
         if (w == 0) continue;                                 // macros.rs:52-53: W == 0 writes nothing
-        pack_from_lds_image<T>(lds + j * G::BLOCK_BYTES, w, const_cast<char*>(a.packed) + off, lane);
+        if (a.refs) pack_from_lds_image<T, true>(lds + j * G::BLOCK_BYTES, w, const_cast<char*>(a.packed) + off, lane, Cell<T>::splat(readlane_elem<T>(rv, j)));
+        else pack_from_lds_image<T>(lds + j * G::BLOCK_BYTES, w, const_cast<char*>(a.packed) + off, lane);
     }
 }
 
