@@ -77,7 +77,8 @@ def _signatures(ty):
 # include/fastlanes_amd_internal.h: test / measurement hooks, not part of the stable ABI
 INTERNAL_SYMBOLS = ["fl_internal_set_kernel_policy", "fl_internal_get_kernel_policy", "fl_internal_probe_memory_classes",
                     "fl_internal_bare_stream", "fl_internal_bare_stream_shape", "fl_internal_zero_copy_fallbacks",
-                    "fl_internal_column_pair_classes", "fl_internal_selftune_check", "fl_internal_choose_chunks"]
+                    "fl_internal_column_pair_classes", "fl_internal_selftune_check", "fl_internal_choose_chunks",
+                    "fl_internal_pair_chunk_cache"]
 
 
 def exported_symbols():
@@ -155,6 +156,8 @@ def load():
     lib.fl_internal_selftune_check.restype = ctypes.c_int
     lib.fl_internal_selftune_check.argtypes = [ctypes.c_int, _U, _U, _P, _P, _P, _Z, _P, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                                                ctypes.POINTER(ctypes.c_int)]
+    lib.fl_internal_pair_chunk_cache.restype = ctypes.c_size_t
+    lib.fl_internal_pair_chunk_cache.argtypes = [_Z]
     lib.fl_internal_choose_chunks.restype = ctypes.c_size_t
     lib.fl_internal_choose_chunks.argtypes = [ctypes.POINTER(ctypes.c_int), _Z, _Z, _Z, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     lib.fl_internal_column_pair_classes.restype = ctypes.c_char_p

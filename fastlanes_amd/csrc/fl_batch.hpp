@@ -84,6 +84,7 @@ __global__ __launch_bounds__(WG) void k_batch(BatchArgs b)
     a.packed_bytes = 0;
     a.prefetch = b.prefetch;
     a.linear_map = 0;
+    a.nt_from = (unsigned)WaveBlock<T>::TB / 2u;
     // per-array preconditions the host cannot check (the pointers live in HBM): 16-byte alignment; the width check
     // (bitpacking.rs:93,126) is the block kernel's
     if (((d.packed | d.unpacked) & 15u) != 0 || !d.unpacked || (!d.packed && d.width != 0)) {
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(WG) void k_batch_chain(BatchArgs b)
     a.offsets = nullptr;
     a.err_flag = b.err_flag;
     a.packed_bytes = 0;
+    a.nt_from = (unsigned)WaveBlock<T>::TB / 2u;
     if constexpr (BPW == 1) {
         chain_one_block<T, SRC, BODY, SNK, RD_VGPR>(a, blk, lds_all + wave * WAVE_LDS, lane);
     } else {

@@ -20,6 +20,7 @@
 #include <cstring>
 #include <initializer_list>
 #include <new>
+#include <cmath>
 #include <vector>
 
 namespace {
@@ -152,6 +153,7 @@ int run_chain(int op, int waves, unsigned w, const T* in, const T* bases, T* out
     a.offsets = offsets;
     a.err_flag = err_flag;
     a.packed_bytes = packed_bytes;
+    a.nt_from = fl::nt_read_from(Elem<T>::BITS);
     hipError_t e = fn(a, waves, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? FL_OK : hip_fail(e);
 }
@@ -180,6 +182,7 @@ int run_wave_uniform(bool pack, int waves, unsigned w, const T* packed, T* unpac
     a.packed_bytes = 0;      // not read: uniform-width calls are validated here, on the host side
     a.prefetch = a.bpw > 1;
     a.linear_map = 0;
+    a.nt_from = fl::nt_read_from(Elem<T>::BITS);
     const int pol = g_kernel_policy.load(std::memory_order_relaxed);       // A/B tools: 2 + ... + 65536 * blocks-per-wavefront (+ 2^24: prefetch)
     if ((pol & 0xff) == 2 && ((pol >> 16) & 0xff)) { a.bpw = (pol >> 16) & 0xff; a.prefetch = (pol >> 24) & 1; }
     if (a.prefetch && (WG / 64) * a.bpw * WaveBlock<T>::BLOCK_BYTES > 64u * 1024u) a.prefetch = 0;   // images would not fit a workgroup's LDS
@@ -602,6 +605,7 @@ int run_widths(bool pack, const uint8_t* widths, const uint64_t* offsets, const 
     a.bpw = mixed_blocks_per_wave(Elem<T>::BITS, pack);
     a.prefetch = mixed_prefetch(Elem<T>::BITS);
     a.linear_map = 0;
+    a.nt_from = 0;           // a mixed-width column always streams
     int waves = mixed_waves(Elem<T>::BITS, pack);
     const int pol = g_kernel_policy.load(std::memory_order_relaxed);       // A/B tools: 2 + 256*waves + 65536*blocks-per-wavefront (+ 2^24: prefetch)
     if ((pol & 0xff) == 2 && ((pol >> 8) & 0xff)) waves = (pol >> 8) & 0xff;
@@ -805,7 +809,7 @@ int fl_internal_bare_stream_shape(int op, unsigned type_bits, unsigned width, si
     if (w >= TWO_BLOCKS) w -= TWO_BLOCKS;                           // two blocks per wavefront: same bytes per launch, the occupancy is what the table says
     if (w == 0) w = 8;       // a cell-column kernel gives a wavefront 8 blocks at 2-3 waves per SIMD: the one-unit-per-wavefront stream needs every slot to keep as many bytes in flight
     *waves = w < 3 ? 3 : w;
-    *nt_loads = op == 1 || op == 3 || 2 * width >= type_bits;       // fl_widths.hpp: RD_AUTO; pack reads non-temporally
+    *nt_loads = op == 1 || op == 3 || width >= fl::nt_read_from(type_bits);       // fl_widths.hpp: RD_AUTO; pack reads non-temporally
     *window_log2_units = window_log2_blocks(op == 1 ? WIN_PACK : op == 2 ? WIN_UNDELTA_PACK : WIN_UNPACK, type_bits);
     return FL_OK;
 }
@@ -902,6 +906,35 @@ inline size_t pair_pad(size_t b) { return (b + PAIR_ALIGN - 1) & ~(PAIR_ALIGN - 
 
 void live_pair_remove(const char* va);                   // the launchers' registry of live constructed pairs, below
 
+// A bounded cache of 1-GiB physical chunks (fl_internal_pair_chunk_cache: OFF unless a tool asks for it).  hipMemCreate costs ~30 ms per
+// GiB, so a constructed pair costs seconds, nearly all of it creating chunks that are released again a moment later; a sweep that builds a
+// pair per row keeps them instead.  Only the handles are kept -- every pool is classified afresh (2.4 ms per chunk), class labels do not
+// carry over from one probe to the next.
+constexpr int CACHE_DEVICES = 16;
+std::vector<hipMemGenericAllocationHandle_t> g_chunk_cache[CACHE_DEVICES];
+size_t g_chunk_cache_limit = 0;
+std::atomic_flag g_chunk_cache_lock = ATOMIC_FLAG_INIT;
+void recycle_chunk(hipMemGenericAllocationHandle_t h, int dev)
+{
+    bool kept = false;
+    if (dev >= 0 && dev < CACHE_DEVICES) {
+        while (g_chunk_cache_lock.test_and_set(std::memory_order_acquire)) {}
+        if (g_chunk_cache[dev].size() < g_chunk_cache_limit) { g_chunk_cache[dev].push_back(h); kept = true; }
+        g_chunk_cache_lock.clear(std::memory_order_release);
+    }
+    if (!kept) (void)hipMemRelease(h);
+}
+bool cached_chunk(int dev, hipMemGenericAllocationHandle_t& h)
+{
+    bool got = false;
+    if (dev >= 0 && dev < CACHE_DEVICES) {
+        while (g_chunk_cache_lock.test_and_set(std::memory_order_acquire)) {}
+        if (!g_chunk_cache[dev].empty()) { h = g_chunk_cache[dev].back(); g_chunk_cache[dev].pop_back(); got = true; }
+        g_chunk_cache_lock.clear(std::memory_order_release);
+    }
+    return got;
+}
+
 struct ColumnPair {
     void* bufs[3] = {nullptr, nullptr, nullptr};       // separate: in, aux, out; zoned: the slab only
     void *in = nullptr, *aux = nullptr, *out = nullptr;
@@ -909,6 +942,7 @@ struct ColumnPair {
     std::vector<hipMemGenericAllocationHandle_t> chunks;
     char* va = nullptr;
     size_t va_bytes = 0, chunk_bytes = 0, n_mapped = 0;
+    int dev = -1;                                        // the device the chunks belong to
     char class_map[96] = {0};                            // 'A' 'B' 'C' '?' per mapped chunk (first 95), input first
     void release()
     {
@@ -918,7 +952,7 @@ struct ColumnPair {
         }
         for (size_t i = 0; i < n_mapped; ++i) (void)hipMemUnmap(va + i * chunk_bytes, chunk_bytes);
         n_mapped = 0;
-        for (auto h : chunks) (void)hipMemRelease(h);
+        for (auto h : chunks) recycle_chunk(h, dev);
         chunks.clear();
         if (va) live_pair_remove(va);
         if (va) (void)hipMemAddressFree(va, va_bytes);
@@ -929,10 +963,10 @@ struct ColumnPair {
 // Address ranges for FL_LAYOUT_INTERLEAVED.  On this ROCm (7.2) an address range that held a mapping, was unmapped and is mapped AGAIN --
 // even after hipMemAddressFree + hipMemAddressReserve -- keeps translating to the chunks it held FIRST (tools/exp_vmm remap,
 // profiles/r06_vmm_placement.txt): kernels would silently read and write memory that is no longer ours.  So no range is ever used twice
-// within a process: ranges are asked for at monotonically growing addresses of a private stretch of the address space (32 .. 64 TiB), and
+// within a process: ranges are asked for at monotonically growing addresses of a private stretch of the address space (16 .. 80 TiB: enough for several hundred pairs -- a pair uses its own size plus its pool's, once; then hipErrorOutOfMemory), and
 // whatever the runtime returns is checked against every range this library used before.
-std::atomic<uintptr_t> g_va_next{(uintptr_t)0x200000000000ull};
-constexpr uintptr_t VA_ARENA_END = (uintptr_t)0x400000000000ull;
+std::atomic<uintptr_t> g_va_next{(uintptr_t)0x100000000000ull};
+constexpr uintptr_t VA_ARENA_END = (uintptr_t)0x500000000000ull;
 std::atomic_flag g_va_lock = ATOMIC_FLAG_INIT;
 std::vector<std::pair<uintptr_t, uintptr_t>> g_va_used;
 
@@ -961,18 +995,22 @@ hipError_t reserve_fresh_range(size_t bytes, char** out)
     return *out ? hipSuccess : e;
 }
 
-// which chunks of a classified pool form the pair (profiles/r06_vmm_placement.txt, r06_vmm_output_rotation.txt; fractions of the 8 TB/s):
+// which chunks of a classified pool form the pair (profiles/r06_vmm_placement.txt, r06_vmm/vmm_ratio_*.txt, vmm_pos_*.txt; fractions of 8 TB/s):
 //  * the input (+ aux) inside ONE class (reads spread over classes under the whole-column tile map: 0.80 where one class gives 0.84-0.86);
-//  * the output rotating through `out_classes` classes: the OTHER TWO for a write-dominated pair (u32 W=7 unpack: out BC 0.864-0.866, out
-//    ABC 0.860, out AB 0.855, out B 0.80, out A 0.78), ALL THREE otherwise (pack u32 W=7: out ABC 0.859, out AB 0.85, out BC 0.84, out B
-//    0.83; transpose: ABC 0.880, BC 0.870-0.879; unpack u32 W=20: equal);
-//  * the rotation by POSITION, not by a fixed run length: under the whole-column tile map XCD x walks the x-th eighth of the output, all
-//    eight at the same pace, so the k-th chunk of eighth x takes letter (x + k) -- at every moment the eight write positions cycle through
-//    the classes.  A fixed run length resonates with the eighth's size for some column lengths (runs of 2 GiB at 8 M blocks: seven of the
-//    eight positions in one class, 0.840 where the positional rotation gives 0.864; runs of 1 GiB with three classes at 6.5 M: 0.829 / 0.859).
-// Where a class cannot cover its share, the positions it misses (spread evenly) go to the class with the largest surplus, classes outside
-// the rotation first -- left-overs of the input's class, as in round 6's first version: in A | out A and B alternating is 0.855, out B alone
-// 0.80 -- then unclassified chunks.  Creation order (short class runs by nature: 0.854-0.861) when no class can hold the input.
+//  * the output over `out_classes` classes: the OTHER TWO for a write-dominated pair (u32 W=7 unpack: out BC 0.864-0.866, out ABC 0.860,
+//    out AB 0.855, out B 0.80, out A 0.78), ALL THREE otherwise (pack u32 W=7: out ABC 0.859, out AB 0.85, out BC 0.84, out B 0.83;
+//    transpose: ABC 0.880, BC 0.870-0.879; unpack u32 W=20: equal);
+//  * arranged for the WRITE POSITIONS, not in fixed runs: under the whole-column tile map XCD x walks the x-th eighth of the output, all
+//    eight at the same pace, so at progress t the eight positions are the chunks floor((x + t) * n_out / 8).  What the memory wants is
+//    those eight spread evenly over the classes AT EVERY t.  A fixed run length resonates with the eighth's size for some column lengths
+//    (runs of 2 GiB at 8 M blocks: seven of the eight positions in one class, 0.840 where a balanced arrangement gives 0.864; runs of 1 GiB
+//    with three classes at 6.5 M blocks: 0.829 / 0.859), and so does any closed formula once a chunk straddles two eighths (n_out = 20: the
+//    "k-th chunk of eighth x takes letter x + k" rule puts all eight positions into one class at t = 0 -- unpack u16 W=3 0.852 where runs of
+//    two had 0.868).  So the arrangement is SEARCHED: cost = mean over 64 values of t of the eight positions' cubed class
+//    counts (an even spread is cheapest), plus a large penalty per chunk a class does not have and a fee per chunk of a
+//    class outside the rotation (the input's own class: in A | out A and B alternating is 0.855, out B alone 0.80; unclassified chunks
+//    last); start = letters by the position of a chunk's centre, then single-chunk relabelling until nothing improves (n_out * 4 * 64 * 8
+//    operations per sweep: microseconds).  Creation order (short class runs by nature: 0.854-0.861) when no class can hold the input.
 void choose_chunks(const std::vector<int>& cls, size_t n_in, size_t n_out, int out_classes, std::vector<int>& order, size_t* kept_out = nullptr)
 {
     if (kept_out) *kept_out = 0;
@@ -981,72 +1019,105 @@ void choose_chunks(const std::vector<int>& cls, size_t n_in, size_t n_out, int o
     if (out_classes != 2) out_classes = 3;
     std::vector<int> by[4];                                    // 0..2 = classes, 3 = unclassified
     for (size_t g = 0; g < n; ++g) by[cls[g] < 0 || cls[g] > 2 ? 3 : cls[g]].push_back((int)g);
-    // letter of every output position for input class c, before scarcity: S[(x + k) mod |S|], S = the other two classes (+ c)
-    auto position_step = [&](size_t j) {
-        const size_t x = j * 8 / n_out, first = (x * n_out + 7) / 8;
-        return x + (j >= first ? j - first : 0);
-    };
-    size_t last_kept = 0, best_kept = 0;
-    auto plan = [&](int c, std::vector<int>& want) -> size_t {    // returns the plan's score (see the end)
-        const int S[3] = {(c + 1) % 3, (c + 2) % 3, c};
+    if (n_out == 0 || n_in + n_out > n) {                      // nothing to arrange / the pool is too small: as created, as far as it goes
+        for (size_t g = 0; g < n_in + n_out && g < n; ++g) order.push_back((int)g);
+        return;
+    }
+    constexpr int TS = 64;                                     // samples of the progress t
+    // pos[t][x] = the chunk under XCD x's write position at progress (t + 0.5) / TS
+    std::vector<unsigned> pos((size_t)TS * 8);
+    for (int t = 0; t < TS; ++t)
+        for (int x = 0; x < 8; ++x) {
+            const double p = (x + (t + 0.5) / TS) * (double)n_out / 8.0;
+            pos[(size_t)t * 8 + x] = (unsigned)std::min<double>((double)n_out - 1, p);
+        }
+    struct Plan { std::vector<int> label; double cost; size_t kept; };
+    auto plan = [&](int c) {
+        Plan P;
         size_t avail[4] = {by[0].size(), by[1].size(), by[2].size(), by[3].size()};
         avail[c] -= n_in;
-        want.assign(n_out, -1);
-        std::vector<size_t> pos[3];
-        for (size_t j = 0; j < n_out; ++j) {
-            want[j] = S[position_step(j) % (size_t)out_classes];
-            pos[want[j]].push_back(j);
-        }
-        size_t kept = 0;
-        std::vector<size_t> orphans;                           // positions whose class is short, evenly spaced within that class's positions
+        // cost = the mean over t of sum_k count_k^3 (8 positions: 4 + 4 + 0 costs 128, 8/3 each 57, all in one class 512) + a fee per
+        // FRACTION of the output taken from outside the rotation.  The cube and 300 for the input's own class rank the layouts as measured
+        // (unpack u32 W=7, input in A): out BC 128 (0.865) < ABC 157 (0.860) < AB 278 (0.855) < B alone 512 (0.80) < A alone 812 (0.78);
+        // with squares no fee ranks "in B | out four fifths A" behind "in A | out A and B alternating" AND keeps BC ahead of ABC.  300 is also
+        // more than the 288 / n_out a single chunk of the input's class gains by taking one of eight positions out of a 4 + 4 split.
+        double fee[4] = {0, 0, 0, 350.0};
+        bool in_rotation[3];
         for (int k = 0; k < 3; ++k) {
-            const size_t need = pos[k].size(), have = std::min(need, avail[k]);
-            kept += have;
-            avail[k] -= have;
-            const size_t miss = need - have;
-            for (size_t m = 0; m < miss; ++m) orphans.push_back(pos[k][(2 * m + 1) * need / (2 * miss)]);
+            in_rotation[k] = out_classes == 3 || k != c;
+            fee[k] = in_rotation[k] ? 0.0 : 300.0;
         }
-        std::sort(orphans.begin(), orphans.end());
-        for (size_t j : orphans) {
-            // the largest surplus, classes outside the rotation first (an orphan of B given to C would put C next to C), unclassified last
-            int best = -1;
-            for (int pass = 0; pass < 3 && best < 0; ++pass)
-                for (int k = 0; k < 3; ++k) {
-                    const bool in_rotation = out_classes == 3 || k != c;
-                    if (pass == 0 && in_rotation) continue;
-                    if (pass == 1 && k == want[j]) continue;
-                    if (avail[k] && (best < 0 || avail[k] > avail[best])) best = k;
+        const int S[3] = {(c + 1) % 3, (c + 2) % 3, c};
+        P.label.assign(n_out, 0);
+        for (size_t j = 0; j < n_out; ++j) {                   // start: by the position of the chunk's centre
+            const double at = (j + 0.5) * 8.0 / (double)n_out;
+            const size_t x = (size_t)at, k = (size_t)((at - (double)x) * (double)n_out / 8.0);
+            P.label[j] = S[(x + k) % (size_t)out_classes];
+        }
+        auto cost_of = [&](const std::vector<int>& lab) {
+            double cost = 0.0;
+            size_t used[4] = {0, 0, 0, 0};
+            for (int k : lab) { ++used[k]; cost += fee[k] / (double)n_out; }
+            for (int k = 0; k < 4; ++k) if (used[k] > avail[k]) cost += 10000.0 * (double)(used[k] - avail[k]);
+            for (int t = 0; t < TS; ++t) {
+                double cnt[4] = {0, 0, 0, 0};
+                for (int x = 0; x < 8; ++x) cnt[lab[pos[(size_t)t * 8 + x]]] += 1.0;
+                for (int k = 0; k < 4; ++k) cost += cnt[k] * cnt[k] * cnt[k] / TS;
+            }
+            return cost;
+        };
+        P.cost = cost_of(P.label);
+        for (int sweep = 0; sweep < 12; ++sweep) {
+            bool improved = false;
+            for (size_t j = 0; j < n_out; ++j) {
+                const int was = P.label[j];
+                int best = was;
+                for (int k = 0; k < 4; ++k) {
+                    if (k == was) continue;
+                    P.label[j] = k;
+                    const double cst = cost_of(P.label);
+                    if (cst < P.cost - 1e-9) { P.cost = cst; best = k; }
                 }
-            if (best < 0 && avail[3]) best = 3;
-            want[j] = best;                                    // -1: the pool is too small
-            if (best >= 0) --avail[best];
+                P.label[j] = best;
+                improved = improved || best != was;
+            }
+            if (!improved) break;
         }
-        // the plan's worth: every position filled, then the most crowded class as small as possible (what is left of the alternation
-        // when a class is scarce: in A | out A and B alternating 0.855, out mostly B 0.80), then positions that kept their letter
-        size_t count[4] = {0, 0, 0, 0}, filled = 0;
-        for (int k : want) if (k >= 0) { ++count[k]; ++filled; }
-        const size_t crowd = std::max(std::max(count[0], count[1]), std::max(count[2], count[3]));
-        last_kept = kept;
-        return (filled << 40) + ((n_out - crowd) << 20) + kept;
+        // "kept" = chunks of rotation classes, less what the class shares are out of balance by (the pool-growth criterion)
+        size_t used[4] = {0, 0, 0, 0};
+        for (int k : P.label) ++used[k];
+        double off = 0.0;
+        size_t outside = used[3];
+        for (int k = 0; k < 3; ++k) {
+            if (in_rotation[k]) off += std::max(0.0, std::fabs((double)used[k] - (double)n_out / out_classes) - 1.0);
+            else outside += used[k];
+        }
+        const double kept = (double)n_out - (double)outside - off;
+        P.kept = kept > 0.0 ? (size_t)kept : 0;
+        for (int k = 0; k < 4; ++k) if (used[k] > avail[k]) P.kept = 0;      // cannot even be filled
+        return P;
     };
     int best_c = -1;
-    size_t best_score = 0;
-    std::vector<int> want, best_want;
+    Plan best;
     for (int c = 0; c < 3; ++c) {
         if (by[c].size() < n_in) continue;
-        const size_t score = plan(c, want) + 1;
-        if (score > best_score || (score == best_score && by[c].size() > by[best_c].size())) { best_score = score; best_c = c; best_want = want; best_kept = last_kept; }
+        Plan P = plan(c);
+        if (best_c < 0 || P.cost < best.cost - 1e-9 || (std::fabs(P.cost - best.cost) <= 1e-9 && by[c].size() > by[best_c].size())) { best = std::move(P); best_c = c; }
     }
     if (best_c < 0) {                                           // no class can hold the input: as created
         for (size_t g = 0; g < n_in + n_out && g < n; ++g) order.push_back((int)g);
         return;
     }
-    if (kept_out) *kept_out = best_kept;
+    if (kept_out) *kept_out = best.kept;
     size_t next[4] = {0, 0, 0, 0};
     for (size_t i = 0; i < n_in; ++i) order.push_back(by[best_c][next[best_c]++]);
     for (size_t j = 0; j < n_out; ++j) {
-        const int k = best_want[j];
-        if (k < 0 || next[k] >= by[k].size()) break;
+        int k = best.label[j];
+        if (next[k] >= by[k].size()) {                          // (only if the penalty lost against the imbalance: any chunk that is left)
+            k = -1;
+            for (int q = 0; q < 4; ++q) if (next[q] < by[q].size() && (k < 0 || by[q].size() - next[q] > by[k].size() - next[k])) k = q;
+            if (k < 0) break;
+        }
         order.push_back(by[k][next[k]++]);
     }
 }
@@ -1128,7 +1199,8 @@ hipError_t pair_alloc_interleaved(size_t in_bytes, size_t aux_bytes, size_t out_
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
     std::vector<hipMemGenericAllocationHandle_t> pool;
-    auto drop_pool = [&] { for (auto h : pool) (void)hipMemRelease(h); pool.clear(); };
+    auto drop_pool = [&] { for (auto h : pool) recycle_chunk(h, dev); pool.clear(); };
+    p.dev = dev;
     const size_t pool_cap = free_b > 3 * PAIR_GIB ? (free_b - 2 * PAIR_GIB) / chunk : n_pool;
     std::vector<int> cls, order;
     // The pool GROWS while the arrangement it allows is poor: the classes come in clusters of 4 .. 32 chunks, so a pool of the first size
@@ -1140,7 +1212,7 @@ hipError_t pair_alloc_interleaved(size_t in_bytes, size_t aux_bytes, size_t out_
         pool.reserve(n_pool);
         while (pool.size() < n_pool) {
             hipMemGenericAllocationHandle_t h;
-            if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
+            if (!cached_chunk(dev, h) && hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
             pool.push_back(h);
         }
         if (pool.size() < n_in + n_out) { drop_pool(); return hipErrorOutOfMemory; }
@@ -1182,7 +1254,7 @@ hipError_t pair_alloc_interleaved(size_t in_bytes, size_t aux_bytes, size_t out_
     if (e == hipSuccess) e = hipMemSetAccess(p.va, p.va_bytes, &acc, 1);
     for (size_t g = 0; g < pool.size(); ++g) {
         if (keep[g]) p.chunks.push_back(pool[g]);
-        else (void)hipMemRelease(pool[g]);
+        else recycle_chunk(pool[g], dev);
     }
     pool.clear();
     if (e != hipSuccess) { p.release(); return e; }
@@ -1381,6 +1453,21 @@ int fl_internal_selftune_check(int op, unsigned type_bits, unsigned width, const
     (void)hipEventDestroy(t0);
     (void)hipEventDestroy(t1);
     return rc;
+}
+
+size_t fl_internal_pair_chunk_cache(size_t max_chunks)
+{
+    std::vector<hipMemGenericAllocationHandle_t> drop;
+    size_t held = 0;
+    while (g_chunk_cache_lock.test_and_set(std::memory_order_acquire)) {}
+    g_chunk_cache_limit = max_chunks;
+    for (auto& c : g_chunk_cache) {
+        while (c.size() > max_chunks) { drop.push_back(c.back()); c.pop_back(); }
+        held += c.size();
+    }
+    g_chunk_cache_lock.clear(std::memory_order_release);
+    for (auto h : drop) (void)hipMemRelease(h);
+    return held;
 }
 
 size_t fl_internal_choose_chunks(const int* classes, size_t n_pool, size_t n_in, size_t n_out, int out_classes, int* order)

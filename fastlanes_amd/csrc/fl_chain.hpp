@@ -53,6 +53,7 @@ struct ChainArgs {
     const uint64_t* offsets;
     uint32_t* err_flag;      // FL_DEVERR_* of skipped blocks (may be nullptr)
     uint64_t packed_bytes;   // size of the packed column (only read when widths != nullptr)
+    unsigned nt_from;        // RD_AUTO: uniform widths >= this stream non-temporally by LDS-DMA (fl_dispatch.hpp: nt_read_from)
 };
 
 // LDS image of a block in ORIGINAL order: byte a of the block lives at pad(a).  u32: +16 bytes per 128-byte line and +32 per
@@ -221,7 +222,7 @@ __device__ __forceinline__ void chain_stage_source(const ChainArgs& a, uint64_t 
         // traffic (2 W >= T, or a mixed-width column) streams NON-TEMPORALLY by LDS-DMA, narrow widths through VGPRs.  Round 6: the
         // Delta decoders read their packed rows with the default policy at every width until now -- 3-6 % behind unpack of the same
         // column at wide widths at every occupancy, in both kernel designs (profiles/r06_undelta_occupancy.txt).
-        if (SRC == SRC_PACKED && (a.widths || 2u * w >= (unsigned)TB)) chain_stage_source<T, SRC, BODY, RD_DMA_NT>(a, blk, w, packed_at, lds, lane, base);
+        if (SRC == SRC_PACKED && (a.widths || w >= a.nt_from)) chain_stage_source<T, SRC, BODY, RD_DMA_NT>(a, blk, w, packed_at, lds, lane, base);
         else chain_stage_source<T, SRC, BODY, RD_VGPR>(a, blk, w, packed_at, lds, lane, base);
         return;
     }

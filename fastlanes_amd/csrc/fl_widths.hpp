@@ -44,6 +44,7 @@ struct WidthsArgs {
     unsigned prefetch;         // bpw > 1: 1 = request all bpw blocks of the wavefront up front by LDS-DMA (one LDS image per block)
     unsigned linear_map;       // A/B tools: 1 = workgroup b takes tile b instead of the XCD-contiguous map
     unsigned window_shift;     // tile-map window (fl_kernels.hpp: xcd_tile); filled by the launcher
+    unsigned nt_from;          // RD_AUTO: uniform widths >= this stream non-temporally by LDS-DMA (fl_dispatch.hpp: nt_read_from)
 };
 
 template <typename T> struct WaveBlock {
@@ -274,7 +275,7 @@ __device__ __forceinline__ void unpack_block_wave(const WidthsArgs& a, uint64_t 
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.packed) + off, 0, 128u * w, 0x00020000);
     Cell<T> ref = Cell<T>::zero();
     if constexpr (RD == RD_AUTO) {
-        if (a.widths || 2u * w >= (unsigned)TB) packed_block_to_lds<T, RD_DMA_NT>(a, blk, rs, w, lds, lane, ref);   // wave-uniform
+        if (a.widths || w >= a.nt_from) packed_block_to_lds<T, RD_DMA_NT>(a, blk, rs, w, lds, lane, ref);   // wave-uniform
         else packed_block_to_lds<T, RD_VGPR>(a, blk, rs, w, lds, lane, ref);
     } else {
         packed_block_to_lds<T, RD>(a, blk, rs, w, lds, lane, ref);

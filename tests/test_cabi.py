@@ -33,7 +33,7 @@ def _header_symbols():
 def test_every_declared_symbol_is_exported(lib):
     import fastlanes_amd
     syms = _header_symbols()
-    assert len(syms) == 4 * 42 + 24
+    assert len(syms) == 4 * 42 + 25
     assert sorted(fastlanes_amd.exported_symbols()) == syms
     for s in syms:
         assert hasattr(lib, s), s
@@ -53,7 +53,9 @@ def test_column_pair_and_bare_stream_argument_checks_need_no_gpu(lib):
     iu, au, ou, nt, wv, wn, bpu = Z(), Z(), Z(), I(), I(), I(), ctypes.c_uint()
     refs = [ctypes.byref(x) for x in (iu, au, ou, nt, wv, wn, bpu)]
     assert lib.fl_internal_bare_stream_shape(0, 32, 7, *refs) == 0
-    assert (iu.value, au.value, ou.value, nt.value, wn.value) == (896, 0, 4096, 0, 31) and 3 <= wv.value <= 8
+    assert (iu.value, au.value, ou.value, nt.value, wn.value) == (896, 0, 4096, 1, 31) and 3 <= wv.value <= 8     # u32 streams from W = 4 (round 6)
+    assert lib.fl_internal_bare_stream_shape(0, 32, 3, *refs) == 0 and nt.value == 0
+    assert lib.fl_internal_bare_stream_shape(0, 16, 7, *refs) == 0 and nt.value == 0 and lib.fl_internal_bare_stream_shape(0, 16, 8, *refs) == 0 and nt.value == 1
     assert lib.fl_internal_bare_stream_shape(1, 64, 17, *refs) == 0
     assert (iu.value, au.value, ou.value, nt.value, wn.value) == (8192, 0, 2176, 1, 16)
     assert lib.fl_internal_bare_stream_shape(2, 32, 12, *refs) == 0 and (iu.value, au.value, ou.value) == (1536, 128, 4096)
@@ -333,10 +335,11 @@ def test_constructed_layout_chooses_chunks_by_class(lib):
     # a balanced pool, write-dominated pair: the input in one class, the output over the other two, 4 + 4 under the eight positions at all times
     for n_out in (31, 39, 48, 27):
         cin, cout, _ = choose("AAAABBBBCCCC" * 10, 9, n_out)
-        assert len(set(cin)) == 1 and cin[0] not in cout and abs(cout.count(cout[0]) - (n_out - cout.count(cout[0]))) <= 3
+        others = [x for x in "ABC" if x != cin[0]]
+        assert len(set(cin)) == 1 and cout.count(cin[0]) <= n_out // 8 and abs(cout.count(others[0]) - cout.count(others[1])) <= 4, (cin, cout)
         for t in (0.0, 0.26, 0.5, 0.77, 0.99):
             ps = positions(cout, t)
-            assert 3 <= ps.count(ps[0]) <= 5, (n_out, t, cout, ps)
+            assert max(ps.count(x) for x in "ABC") <= 5, (n_out, t, cout, ps)
     # ... the same pool, read-dominated pair: all three classes under the eight positions at all times, none more than 4 times
     for n_in, n_out in ((31, 7), (39, 9), (20, 20), (16, 25)):
         cin, cout, _ = choose("AAAABBBBCCCC" * 14, n_in, n_out, 3)
@@ -345,13 +348,13 @@ def test_constructed_layout_chooses_chunks_by_class(lib):
         for t in (0.0, 0.3, 0.6, 0.95):
             ps = positions(cout, t)
             assert len(set(ps)) == 3 and max(ps.count(x) for x in "ABC") <= 4, (n_in, n_out, t, cout, ps)
-    # one class scarce (what a box handed out in round 6): the input's left-overs take the missing positions, no class carries > half + 1
+    # one class scarce (what a box handed out in round 6): left-overs of the input's class join in, no class carries more than two thirds
     cin, cout, _ = choose("B" * 38 + "C" * 50 + "AAA" + "C" * 14, 9, 39)
-    assert len(set(cin)) == 1 and max(cout.count(x) for x in "ABC") <= 21 and len(set(cout)) == 3
-    assert all(len(set(cout[i:i + 6])) >= 2 for i in range(0, 33))          # every stretch of the output mixes classes
+    assert len(set(cin)) == 1 and max(cout.count(x) for x in "ABC") <= 26 and len(set(cout)) == 3, (cin, cout)
+    assert all(max(positions(cout, t).count(x) for x in "ABC") <= 6 for t in (0.0, 0.2, 0.4, 0.6, 0.8, 0.99)), cout     # the eight positions mix classes
     # two classes only
     cin, cout, _ = choose("A" * 80 + "B" * 16, 9, 39)
-    assert set(cin) == {"A"} and cout.count("B") == 16 and all(len(set(cout[i:i + 8])) == 2 for i in range(0, 31))
+    assert set(cin) == {"A"} and cout.count("B") == 16 and all(2 <= positions(cout, t).count("B") <= 5 for t in (0.0, 0.25, 0.5, 0.75, 0.99)), cout
     # one class only / nothing classified / input larger than any class: creation order
     for classes in ("A" * 60, "?" * 60, "ABC" * 20):
         n_in = 30 if classes.startswith("ABC") else 9

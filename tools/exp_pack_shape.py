@@ -2,7 +2,7 @@
 per wavefront (prefetched by LDS-DMA) x tile-map window, same buffers, policies round-robin.  The narrow types' encode got +6 % from
 two blocks in flight per wavefront (profiles/r06_exp_narrow_bpw.txt: u8 pack_widths 0.849 where u32's sits at 0.81 on the same
 read : write proportion); this asks whether the wide types' one-block wavefront is a bound of the same kind.
-    python tools/exp_pack_shape.py [cases: u32w7,u64w17,u32mixed,u64mixed] [--layout interleaved|separate] [--op pack|unpack] [--bpw 1,2,4]
+    python tools/exp_pack_shape.py [cases: u32w7,u64w17,u32mixed,u64mixed] [--layout interleaved|separate] [--op pack|unpack|undelta_pack] [--bpw 1,2,4]
 (--op unpack: the same matrix for the decode direction -- the narrow types' mixed-width kernels want every wave slot, the memory wants fewer)"""
 import sys, os, statistics, torch
 sys.path.insert(0, os.getcwd())
@@ -46,7 +46,10 @@ for case in cases:
         W = int(case.split("w")[1])
         n = int(40e9 / (128 * (T + W)))
         pb = n * 128 * W
-    pair = pl.ColumnPair(n * 128 * T, pb, dev, layout=layout) if OP == "pack" else pl.ColumnPair(pb, n * 128 * T, dev, layout=layout)
+    pair = pl.ColumnPair(n * 128 * T, pb, dev, layout=layout) if OP == "pack" else pl.ColumnPair(pb, n * 128 * T, dev, aux_bytes=n * 128, layout=layout)
+    if OP == "undelta_pack":
+        assert lib.fl_fill_random(pair.aux.data_ptr(), pair.aux.numel() & ~7, 6, None) == 0
+        bases = pair.aux.view(TDT[ty])
     assert lib.fl_fill_random(pair.input.data_ptr(), pair.input.numel() & ~7, 5, None) == 0
     un, col = (pair.input.view(TDT[ty]), pair.output.view(TDT[ty])) if OP == "pack" else (pair.output.view(TDT[ty]), pair.input.view(TDT[ty]))
     pols = policies(T)
@@ -61,6 +64,7 @@ for case in cases:
                 if OP == "pack":
                     if mixed: fl.pack_widths(widths, offsets, un, col, check=False)
                     else: fl.BitPacking.pack(W, un, output=col)
+                elif OP == "undelta_pack": fl.Delta.undelta_pack(W, col, bases, output=un)
                 elif mixed: fl.unpack_widths(widths, offsets, col, output=un, check=False)
                 else: fl.BitPacking.unpack(W, col, output=un)
                 b.record(); b.synchronize()

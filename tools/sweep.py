@@ -104,7 +104,15 @@ def run(op, ty, w, gb, reps):
         except ValueError:
             total = None
     slab = the_slab(max(total, (in_bytes // pl.GRANULE_BYTES + 3) * pl.GRANULE_BYTES)) if total is not None else None
-    if slab is not None and consumer and out_bytes <= pl.GRANULE_BYTES - (1 << 30):
+    pair = None
+    if PLACEMENT == "interleaved" and not consumer:
+        # a CONSTRUCTED pair per row (fl_column_pair_alloc(FL_LAYOUT_INTERLEAVED): the input + aux inside one class of memory, the output
+        # rotating through the others by position); the library keeps the 1-GiB chunks between rows (fl_internal_pair_chunk_cache)
+        lib.fl_internal_pair_chunk_cache(96)
+        pair = pl.ColumnPair(in_bytes, out_bytes, dev, aux_bytes=aux_bytes, layout="interleaved")
+        src8, aux8, dst8 = pair.input, pair.aux, pair.output
+        placed = f"constructed pair {pair.classes}"
+    elif slab is not None and consumer and out_bytes <= pl.GRANULE_BYTES - (1 << 30):
         # a thin write stream: input in a run of granules of one memory class, output in a granule of another (classes measured once
         # on the sweep's slab: fastlanes_amd/placement.py)
         cls, rates = SLAB["classes"]
@@ -195,6 +203,8 @@ def run(op, ty, w, gb, reps):
             if op == "transpose_delta_pack":              # pack's shape plus the bases on the read side
                 au = Z(128 * bpu.value)
             nu = n // bpu.value
+            if pair is not None and pair.classes:
+                wn = I(31)                                 # inside a constructed pair the library launches under the whole-column tile map
             g = lambda: lib.fl_internal_bare_stream(src8.data_ptr(), iu.value, aux8.data_ptr() if au.value else None, au.value, dst8.data_ptr(), ou.value, nu,
                                                     nt.value, wv.value, wn.value, None)
             g(); g()
@@ -205,6 +215,10 @@ def run(op, ty, w, gb, reps):
                 a.record(); g(); b.record(); b.synchronize()
                 bms.append(a.elapsed_time(b))
             bare = nu * (iu.value + au.value + ou.value) / sorted(bms)[len(bms) // 2] / 1e6
+    if pair is not None:
+        src = dst = bases = refs = src8 = aux8 = dst8 = None
+        del f
+        pair.free()
     return {"op": op, "ty": ty, "w": w, "n_blocks": n, "ms": round(med, 4), "GBps": round(gbps, 1),
             "frac": round(gbps / 8000, 4), "Gints": round(n * 1024 / med / 1e6, 1), "placed": placed,
             "bare_GBps": round(bare, 1) if bare else None, "of_bare": round(gbps / bare, 4) if bare else None}
@@ -227,9 +241,11 @@ def main():
     ap.add_argument("--gb", type=float, default=24.0)
     ap.add_argument("--reps", type=int, default=7)
     ap.add_argument("--cases", default="quick")
+    ap.add_argument("--types", default="", help="keep only these element types of the chosen cases (allwidths with --placement interleaved: one "
+                    "process per type -- a constructed pair's address ranges are never re-used within a process, 868 rows exhaust them)")
     ap.add_argument("--json", default=None)
     ap.add_argument("--placement", default="zoned", choices=("zoned", "separate", "interleaved"),
-                    help="interleaved (--cases mixed only): the column's buffers from fl_column_pair_alloc(FL_LAYOUT_INTERLEAVED) -- packed sides in one "
+                    help="interleaved (every materialising row; pairs of 8 GiB and more, so --gb 12): the column's buffers from fl_column_pair_alloc(FL_LAYOUT_INTERLEAVED) -- packed sides in one "
                          "class of memory, the unpacked side alternating between the other two")
     ap.add_argument("--window-ab", action="store_true", help="every row also under the whole-column tile map and under 2^16-block windows")
     ap.add_argument("--bare", action="store_true", help="pack / unpack / FoR / undelta_pack rows: also a bare stream of the row's bytes on the row's buffers (always on for allwidths)")
@@ -620,6 +636,8 @@ def main():
             torch.cuda.empty_cache()
         return
     out = []
+    if args.types:
+        cases = [c for c in cases if c[1] in args.types.split(",")]
     for op, ty, w in cases:
         r = run(op, ty, w, args.gb, args.reps)
         out.append(r)
@@ -631,6 +649,8 @@ def main():
         for op in ALLWIDTH_OPS:
             for ty in ("u8", "u16", "u32", "u64"):
                 rows = sorted((r["frac"], r["w"]) for r in out if r["op"] == op and r["ty"] == ty)
+                if not rows:
+                    continue
                 ob = sorted((r["of_bare"], r["w"]) for r in out if r["op"] == op and r["ty"] == ty and r.get("of_bare"))
                 print(f"# {op:24s} {ty:4s} min {rows[0][0]:.3f} (W={rows[0][1]:<2d})  median {rows[len(rows) // 2][0]:.3f}  max {rows[-1][0]:.3f} (W={rows[-1][1]:<2d})" +
                       (f"   | of the bare stream of the same bytes on the same buffers: min {ob[0][0]:.3f} (W={ob[0][1]:<2d})  median {ob[len(ob) // 2][0]:.3f}" if ob else ""))
