@@ -103,6 +103,8 @@ def parse():
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 PMC passes (roofline.traffic "
                     "then comes from profiles/pmc_traffic.json, or is null)")
     ap.add_argument("--no-config5", action="store_true", help="skip the strong-scaled mixed-width leg")
+    ap.add_argument("--no-dispatch-check", action="store_true", help="skip fl_internal_selftune_check after the timed region (it launches the "
+                    "workload's own kernel template on a slice of the buffers: under rocprofv3 --stats those launches would dilute the kernel's average)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend", default="auto", choices=("auto", "nccl", "gloo"),
                     help="control plane for the barrier / max-time reduction: auto = RCCL if every rank gets it working, "
@@ -114,7 +116,7 @@ def parse():
                          "allocates every layout below, times a bare stream on each before anything is filled and keeps the fastest pair, "
                          "every figure is reported (roofline.placement_probe_GBps); "
                          "interleaved: constructed from 1-GiB physical chunks whose class of memory the library measures (input in one "
-                         "class, output alternating between the other two); "
+                         "class, the output's chunks arranged for the eight XCDs' write positions); "
                          "separate: one hipMalloc per buffer, wherever the driver puts it; "
                          "zoned: input and output carved from one allocation, the output centred on a 64-GiB multiple")
     ap.add_argument("--verify", default="auto", choices=("auto", "full", "sample"),
@@ -778,7 +780,7 @@ PLACEMENT_TEXT = {
              "on the 64-GiB multiple behind it (include/fastlanes_amd.h, DESIGN.md section 4)",
     "separate": "fl_column_pair_alloc(FL_LAYOUT_SEPARATE): one hipMalloc per buffer, wherever the driver puts it",
     "interleaved": "fl_column_pair_alloc(FL_LAYOUT_INTERLEAVED): CONSTRUCTED from 1-GiB physical chunks (hipMemCreate / hipMemMap) whose class "
-                   "of memory the library measured -- the input inside one class, the output alternating between the other two "
+                   "of memory the library measured -- the input inside one class, the output's chunks arranged so that the eight XCDs' write positions spread over the classes at every moment "
                    "(include/fastlanes_amd.h, DESIGN.md section 4)",
     "torch": "one torch allocation per buffer (several ranks share one device)",
 }
@@ -1010,7 +1012,7 @@ def main():
     placed, classes = w.placement, getattr(w, "classes", "")
     bare = bare_stream(w) if rank == 0 else None     # after the checks (it overwrites the output), same buffers, same run
     tune = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_dispatch_check:
         try:
             tune = dispatch_check(w, gib=8.0)
         except Exception as e:                       # measurement tooling must never take the bench line down

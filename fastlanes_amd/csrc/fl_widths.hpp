@@ -390,7 +390,6 @@ __device__ __forceinline__ void unpack_images_to_global(const WidthsArgs& a, uin
 {
     using G = WaveBlock<T>;
     constexpr int TB = G::TB;
-    static_assert(BPW * G::BLOCK_BYTES <= 4096, "the blocks' store offsets must fit the 12-bit instruction offset");
     const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(a.unpacked + first * G::BLOCK_BYTES, 0, BPW * G::BLOCK_BYTES, 0x00020000);
     const unsigned out_base = lane * 16u, c16 = (lane & 7u) * 16u, rb = G::row_base(lane >> 3);
     static_for<(int)BPW>([&](auto J) {
@@ -481,6 +480,7 @@ __global__ __launch_bounds__(WG) void k_unpack_widths(WidthsArgs a)
     for_each_block_of_wave<T>(a, [&](uint64_t first, unsigned count, char* lds, unsigned lane) {
         if (a.prefetch && count > 1) {
             if constexpr (sizeof(T) <= 2) {                  // the shipped shapes of the narrow types, every block valid: the unrolled form
+                // (u32 with two blocks per wavefront through the same code ties with one block at 6 waves: 0.848 / 0.848, round 6)
                 if (count == a.bpw) {
                     if constexpr (sizeof(T) == 1) {
                         if (a.bpw == 4 && unpack_blocks_wave_static<T, 4>(a, first, lds, lane)) return;

@@ -206,7 +206,7 @@ class _DeviceBytes:
 class ColumnPair:
     """An (input, aux, output) triple of device buffers from fl_column_pair_alloc: `layout` "separate" (one allocation each), "zoned"
     (one allocation, the output centred on a 64-GiB multiple: pins ~64 GiB), "interleaved" (round 6: built from 1-GiB physical chunks
-    whose class of memory was measured -- the input inside one class, the output alternating between the other two) or "auto" (every
+    whose class of memory was measured -- the input inside one class, the output's chunks arranged so that the eight XCDs' write positions spread over classes) or "auto" (every
     candidate tried, a bare stream of in_bytes : out_bytes timed on each, the fastest kept -- synchronous, contents unspecified).
     .input / .aux / .output are uint8 torch tensors over the memory (zero copy; they do NOT own it), .layout the layout kept,
     .probe_GBps {"interleaved": .., "separate": .., "zoned": ..} (auto only), .classes the measured class of every chunk of an

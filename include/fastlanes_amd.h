@@ -138,10 +138,13 @@ int fl_fill_random(void *dst, size_t n_bytes, uint64_t seed, void *stream);
  *                          memory has three classes (most likely the three ranks of the HBM stacks; nothing in an address tells which):
  *                          concurrent writes are fastest spread over two classes, reads inside one, and reads and writes in different
  *                          ones.  More chunks than needed are created, every chunk's class is MEASURED (a 0.2-ms probe kernel per chunk and
- *                          class), `in` (and `aux`) get chunks of one class, `out` alternates between the other two in 2-GiB runs, the
- *                          rest is released.  u32 W=7 unpack at 10 M blocks: 0.864-0.866 of the 8 TB/s on every box, where two hipMallocs
- *                          give anything from 0.78 (both buffers in one class) to 0.86.  Transient cost: up to ~1.5 x the pair for a
- *                          second or so; pairs below 8 GiB are allocated as FL_LAYOUT_SEPARATE (a handful of chunks: nothing to arrange);
+ *                          class), `in` (and `aux`) get chunks of one class, `out`'s chunks are arranged so that the eight XCDs' concurrent write
+ *                          positions (XCD x walks the x-th eighth of `out`) are spread evenly over classes at every moment -- over the
+ *                          two classes `in` is not in when out_bytes >= 3 * in_bytes, over all three otherwise -- the rest is
+ *                          released.  While a pair is alive, calls whose buffers lie inside it launch under the whole-column tile map.
+ *                          u32 W=7 unpack at 10 M blocks: 0.866-0.869 of the 8 TB/s, pack 0.854, where two hipMallocs give anything
+ *                          from 0.78 (both buffers in one class) to 0.86.  Transient cost: a pool of twice the pair (at least 48 GiB, growing to three
+ *                          times the pair where the first pool lacks a class) for a second or so; pairs below 8 GiB are allocated as FL_LAYOUT_SEPARATE (a handful of chunks: nothing to arrange);
  *                          FL_ERR_HIP with hipErrorNotSupported where the device has no virtual-memory management.
  *   FL_LAYOUT_PROBE        the candidates are allocated one after the other -- INTERLEAVED, SEPARATE, and ZONED where its slab still fits --
  *                          a bare read/write stream of in_bytes : out_bytes (no codec work; fl_stream.hpp) is timed on each for a few

@@ -1893,7 +1893,7 @@ def test_column_pair_alloc_and_the_bare_stream(fl, oracle):
 @pytest.mark.parametrize("n_blocks", [2_000_000])
 def test_interleaved_column_pair_is_constructed_from_measured_chunks(fl, oracle, n_blocks):
     """FL_LAYOUT_INTERLEAVED (round 6): the pair is built from 1-GiB physical chunks whose class of memory
-    was measured; input + aux inside one class, the output alternating between the other two.  The codec decodes in it exactly as in
+    was measured; input + aux inside one class, the output's chunks arranged for the eight XCDs' write positions.  The codec decodes in it exactly as in
     plain allocations (oracle on the blocks around every chunk boundary, the whole output against a plain-allocation decode), a second
     pair never gets the first one's addresses (this ROCm keeps stale translations for re-used ranges: tools/exp_vmm remap), and
     "auto" reports the constructed layout's figure next to the others."""

@@ -31,7 +31,7 @@ _pairs = []
 
 def buffers(in_bytes, out_bytes, aux_bytes=0):
     """(input filled with random bits, aux likewise, output) -- plain tensors, or with --constructed one fl_column_pair_alloc(INTERLEAVED)
-    pair per case (the input + aux inside one class of memory, the output alternating between the other two: DESIGN.md section 4)"""
+    pair per case (the input + aux inside one class of memory, the output arranged for the eight XCDs' write positions: DESIGN.md section 4)"""
     if not CONSTRUCTED:
         return filled(in_bytes, 1), (filled(aux_bytes, 2) if aux_bytes else None), torch.empty(out_bytes, dtype=torch.uint8, device=dev)
     from fastlanes_amd import placement as pl

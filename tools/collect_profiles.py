@@ -38,7 +38,7 @@ for src, dst in (("bench_8ranks_one_device.json", f"{RD}_bench_8ranks_one_device
 cp(os.path.join(G, "multi_gpu_decode.json"), f"{RD}_multi_gpu_decode_c_driver.json")
 cp(os.path.join(G, "multi_gpu_decode_2threads.json"), f"{RD}_multi_gpu_decode_c_driver_2threads.json")
 cp(os.path.join(G, "ablayouts.txt"), f"{RD}_ablayouts.txt")
-for c in ("quick", "fused", "consume", "refbench", "batch", "mixed", "mixed_separate", "allwidths", "single"):
+for c in ("quick", "quick_constructed", "fused", "consume", "refbench", "batch", "mixed", "mixed_separate", "allwidths", "allwidths_constructed", "single"):
     cp(os.path.join(G, f"sweep_{c}.txt"), f"{RD}_sweep_{c}.txt")
 # one rocprofv3 kernel trace per BASELINE config (2, 5, 3 unpack, 3 pack, 4): the stats summary + the line printed inside that run
 for tag, dst in (("prof_trace", f"{RD}_bench_u32w7"), ("prof_trace_mixed", f"{RD}_bench_u32_mixed"), ("prof_trace_u64_unpack", f"{RD}_bench_u64w17_unpack"),

@@ -20,7 +20,7 @@ done
     # which layout does --placement auto keep for this workload on this box?  Ask an unprofiled run, then profile with that layout passed
     # explicitly: the trace then holds nothing but the warm-ups and the timed launches of the kernel (no probe launches on the other layout)
     lay=$(timeout 300 python $ROOT/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-pmc --no-config5 --verify sample 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); p=d['config']['placement']; print('zoned' if 'LAYOUT_ZONED' in p else 'interleaved' if 'LAYOUT_INTERLEAVED' in p else 'separate')")
-    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$R/$d -o bench -- python $ROOT/bench.py --workload $wl --steps 10 --no-cpu-baseline --no-pmc --no-config5 --placement ${lay:-separate} > $ROOT/$R/$d.log 2>&1; echo "rocprof $wl (placement ${lay:-separate}) rc=$?"
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$R/$d -o bench -- python $ROOT/bench.py --workload $wl --steps 10 --no-cpu-baseline --no-pmc --no-config5 --no-dispatch-check --placement ${lay:-separate} > $ROOT/$R/$d.log 2>&1; echo "rocprof $wl (placement ${lay:-separate}) rc=$?"
   done )
 for c in quick fused consume refbench single; do timeout 900 python tools/sweep.py --cases $c 2>&1 | grep -v amdgpu.ids > $R/sweep_$c.txt; done
 # mixed-width columns: each direction's buffers in a constructed layout (fl_column_pair_alloc: FL_LAYOUT_INTERLEAVED), then in plain tensors
@@ -28,6 +28,9 @@ timeout 900 python tools/sweep.py --cases mixed --placement interleaved 2>&1 | g
 timeout 900 python tools/sweep.py --cases mixed 2>&1 | grep -v amdgpu.ids > $R/sweep_mixed_separate.txt
 timeout 900 python tools/ablayouts.py --cases headline,config5,config4,config3 2>&1 | grep -v amdgpu.ids > $R/ablayouts.txt
 timeout 2400 python tools/sweep.py --cases allwidths --gb 8 --reps 5 2>&1 | grep -v amdgpu.ids > $R/sweep_allwidths.txt
+# ... and with every row's buffers in a constructed pair (one process per element type: a pair's address ranges are never re-used)
+bash tools/gpu/allwidths_constructed.sh $R/sweep_allwidths_constructed.txt > /dev/null
+timeout 900 python tools/sweep.py --cases quick --placement interleaved --gb 12 2>&1 | grep -v amdgpu.ids > $R/sweep_quick_constructed.txt
 timeout 600 python tools/sweep.py --cases batch --batch-all 2>&1 | grep -v amdgpu.ids > $R/sweep_batch.txt
 timeout 120 tools/host_latency > $R/host_latency.txt 2>&1
 timeout 600 python tools/pmc_single.py > $R/pmc_unpack_single.txt 2> $R/pmc_single.err; echo "pmc single rc=$?"

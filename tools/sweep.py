@@ -246,7 +246,7 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--placement", default="zoned", choices=("zoned", "separate", "interleaved"),
                     help="interleaved (every materialising row; pairs of 8 GiB and more, so --gb 12): the column's buffers from fl_column_pair_alloc(FL_LAYOUT_INTERLEAVED) -- packed sides in one "
-                         "class of memory, the unpacked side alternating between the other two")
+                         "class of memory, the other side arranged for the eight XCDs' write positions")
     ap.add_argument("--window-ab", action="store_true", help="every row also under the whole-column tile map and under 2^16-block windows")
     ap.add_argument("--bare", action="store_true", help="pack / unpack / FoR / undelta_pack rows: also a bare stream of the row's bytes on the row's buffers (always on for allwidths)")
     ap.add_argument("--batch-all", action="store_true", help="--cases batch: every element type and the pack direction too")
