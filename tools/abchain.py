@@ -39,29 +39,33 @@ for ty, W in cases:
     esz = T // 8
     n = min(10_000_000, (GB << 30) // (128 * W + 128 * T + 128))
     if "--constructed" in sys.argv:
-        # round 6: the buffers of each DIRECTION in a constructed layout (fl_column_pair_alloc: FL_LAYOUT_INTERLEAVED), one pair per
-        # direction and element type, sized for the type's largest case and sliced per width -- in memory of one class every variant
-        # reads the same figure (the memory is the bound) and the sweep decides nothing
+        # round 6: the buffers of each DIRECTION in a constructed pair (fl_column_pair_alloc: FL_LAYOUT_INTERLEAVED) -- in memory of one
+        # class every variant reads the same figure (the memory is the bound) and the sweep decides nothing.  ONE PAIR PER ROW AND
+        # DIRECTION, exactly the row's size (second half of round 6: a pair's output is arranged for the eight write positions of ITS
+        # length -- a slice of a larger pair is not a constructed layout); the library keeps the 1-GiB chunks between rows.  Bases, then
+        # references, in the pair's aux buffer.  One process per element type (--types): address ranges are never re-used.
         from fastlanes_amd import placement as pl
-        if CONSTRUCTED.get("ty") != ty:
-            for q in CONSTRUCTED.get("pairs", []):
-                q.free()
-            torch.cuda.empty_cache()
-            n_of = lambda w: min(10_000_000, (GB << 30) // (128 * w + 128 * T + 128))
-            n_max = n_of(0)
-            pk_max = max(n_of(w) * 128 * w for w in range(T + 1))
-            dec = pl.ColumnPair(pk_max, n_max * 128 * T, dev, aux_bytes=n_max * 128, layout="interleaved")
-            enc = pl.ColumnPair(n_max * 128 * T, 2 * pk_max, dev, aux_bytes=n_max * 128, layout="interleaved")
-            print(f"# {ty}: constructed pairs, measured classes (input + bases first): decode {dec.classes} | encode {enc.classes}", flush=True)
-            dec.input.copy_(rand_u8(pk_max, 2, dev))
-            dec.aux.copy_(rand_u8(n_max * 128, 3, dev))
-            enc.input.copy_(rand_u8(n_max * 128 * T, 1, dev))
-            enc.aux.copy_(dec.aux)
-            CONSTRUCTED.update(ty=ty, pairs=[dec, enc], pk_max=pk_max)
-        dec, enc = CONSTRUCTED["pairs"]
+        lib.fl_internal_pair_chunk_cache(128)
+        for q in CONSTRUCTED.get("pairs", []):
+            q.free()
+        aux_b = n * 128 + ((n * esz + 255) & ~255)
+        dec = pl.ColumnPair(max(n * 128 * W, 256), n * 128 * T, dev, aux_bytes=aux_b, layout="interleaved")
+        enc = pl.ColumnPair(n * 128 * T, max(n * 128 * W, 256), dev, aux_bytes=aux_b, layout="interleaved")
+        pairs = [dec, enc]
+        flat = None
+        if ty not in seen_plain:                           # transposes / delta / undelta: unpacked -> unpacked
+            flat = pl.ColumnPair(n * 128 * T, n * 128 * T, dev, aux_bytes=n * 128, layout="interleaved")
+            pairs.append(flat)
+        print(f"# {ty} W={W}: constructed pairs, measured classes (input + aux first): decode {dec.classes} | encode {enc.classes}", flush=True)
+        for q in pairs:
+            assert lib.fl_fill_random(q.input.data_ptr(), q.input.numel() & ~7, 2, None) == 0
+            assert lib.fl_fill_random(q.aux.data_ptr(), q.aux.numel() & ~7, 3, None) == 0
+        CONSTRUCTED.update(ty=ty, pairs=pairs)
         pk, out, bases = dec.input[:n * 128 * W].view(tdt), dec.output[:n * 128 * T].view(tdt), dec.aux[:n * 128].view(tdt)
+        refs_dec = dec.aux[n * 128:n * 128 + n * esz].view(tdt)
         un, bases_enc = enc.input[:n * 128 * T].view(tdt), enc.aux[:n * 128].view(tdt)
-        pk_out_c, pk_for_c = enc.output[:n * 128 * W].view(tdt), enc.output[CONSTRUCTED["pk_max"]:][:n * 128 * W].view(tdt)
+        refs_enc = enc.aux[n * 128:n * 128 + n * esz].view(tdt)
+        pk_out_c = pk_for_c = enc.output[:n * 128 * W].view(tdt)
     else:
         pk = rand_u8(n * 128 * W, 2, dev).view(tdt)
         un = rand_u8(n * 1024 * esz, 1, dev).view(tdt)
@@ -70,23 +74,30 @@ for ty, W in cases:
         bases_enc = bases
         pk_out_c = pk_for_c = None
     refs = bases[:n]
+    refs_e = refs
+    flat_un = flat_out = flat_bases = None
+    if "--constructed" in sys.argv:
+        refs, refs_e = refs_dec, refs_enc
+        if CONSTRUCTED["pairs"][-1] is not enc:
+            fq = CONSTRUCTED["pairs"][-1]
+            flat_un, flat_out, flat_bases = fq.input.view(tdt), fq.output.view(tdt), fq.aux[:n * 128].view(tdt)
     ops = {}
     if "--for" in sys.argv or ALL:      # FoR's bodies (rows of their own in the dispatch table since round 5)
         pk_for = torch.empty_like(pk) if pk_for_c is None else pk_for_c
         ops["unfor_pack"] = (lambda: fl.FoR.unfor_pack(W, pk, refs, output=out), n * (128 * W + 128 * T))
-        ops["for_pack"] = (lambda: fl.FoR.for_pack(W, un, refs, output=pk_for), n * (128 * W + 128 * T))
+        ops["for_pack"] = (lambda: fl.FoR.for_pack(W, un, refs_e, output=pk_for), n * (128 * W + 128 * T))
     ops.update({"undelta_pack": (lambda: fl.Delta.undelta_pack(W, pk, bases, output=out), n * (128 * W + 128 + 128 * T))})
     if True:
         pk_out = torch.empty_like(pk) if pk_out_c is None else pk_out_c
         ops["undelta_pack_untr"] = (lambda: fl.Delta.undelta_pack_untranspose(W, pk, bases, output=out), n * (128 * W + 128 + 128 * T))
         ops["transp_delta_pack"] = (lambda: fl.Delta.transpose_delta_pack(W, un, bases_enc, output=pk_out), n * (128 * W + 128 + 128 * T))
     if ty not in seen_plain:
-        ops["transpose"] = (lambda: fl.Transpose.transpose(un, output=out), n * 256 * T)
-        ops["untranspose"] = (lambda: fl.Transpose.untranspose(un, output=out), n * 256 * T)
-    if ty not in seen_plain:
         seen_plain.add(ty)
-        ops["undelta"] = (lambda: fl.Delta.undelta(un, bases, output=out), n * (256 * T + 128))
-        ops["delta"] = (lambda: fl.Delta.delta(un, bases, output=out), n * (256 * T + 128))
+        f_un, f_out, f_bases = (un, out, bases) if flat_un is None else (flat_un, flat_out, flat_bases)
+        ops["transpose"] = (lambda: fl.Transpose.transpose(f_un, output=f_out), n * 256 * T)
+        ops["untranspose"] = (lambda: fl.Transpose.untranspose(f_un, output=f_out), n * 256 * T)
+        ops["undelta"] = (lambda: fl.Delta.undelta(f_un, f_bases, output=f_out), n * (256 * T + 128))
+        ops["delta"] = (lambda: fl.Delta.delta(f_un, f_bases, output=f_out), n * (256 * T + 128))
     if T >= 32:                            # the two-blocks-per-wavefront form of the wide types' undelta_pack (a table entry 10 + waves)
         ops["undelta_pack_2b"] = ops["undelta_pack"]
     if "--only" in sys.argv:               # e.g. --only undelta_pack,undelta_pack_2b
@@ -94,6 +105,8 @@ for ty, W in cases:
         ops = {k: v for k, v in ops.items() if k in keep_ops}
     for name, (f, nbytes) in ops.items():
         res_t = pk_out if name == "transp_delta_pack" else pk_for if name == "for_pack" else out
+        if flat_out is not None and name in ("transpose", "untranspose", "undelta", "delta"):
+            res_t = flat_out
         two = 65536 * 2 if name.endswith("_2b") else 0
         lib.fl_internal_set_kernel_policy(1)
         f()
@@ -119,5 +132,6 @@ for ty, W in cases:
     # the lambdas in `ops` hold every buffer of the case: drop them with the buffers, or the caching allocator fragments until a
     # 45-GB case no longer fits (round 5: both boxes died at u64 W=64)
     del ops, f, pk, un, out, bases, refs, bases_enc
+    refs_e = refs_dec = refs_enc = flat_un = flat_out = flat_bases = f_un = f_out = f_bases = None
     pk_out = pk_for = res_t = pk_out_c = pk_for_c = None
     torch.cuda.empty_cache()

@@ -27,6 +27,8 @@ TD = {"u8": (torch.uint8, 8), "u16": (torch.uint16, 16), "u32": (torch.uint32, 3
 cases = [("u32", 7), ("u64", 17), ("u32", 12)]
 if ALL:
     cases = [(ty, w) for ty in ("u32", "u64", "u16", "u8") for w in range(TD[ty][1] + 1)]
+if "--types" in sys.argv:
+    cases = [c for c in cases if c[0] in sys.argv[sys.argv.index("--types") + 1].split(",")]
 print(f"GB/s (algorithmic bytes), median of {ROUNDS}, min(10 M blocks, {GB:.0f} GB) per launch, zone-aware placement; cc = cell-column kernel, "
       "wpb = wave-per-block at 3 4 5 6 8 waves/SIMD")
 def fill(t, seed):
@@ -41,10 +43,20 @@ for ty, W in cases:
     n = min(10_000_000, int(GB * 1e9 / bpb))
     # zone-aware placement (fastlanes_amd/placement.py), one slab per direction: the input inside one 64-GiB zone, the output
     # straddling two -- the layout bench.py uses, so that a row compares the two designs where the bench measures them
-    slab_u, pk8, _, un8 = pl.column_pair(n * 128 * W, n * 1024 * esz, dev)        # unpack: packed in, unpacked out
+    if "--constructed" in sys.argv:
+        # second half of round 6: each direction's buffers in a CONSTRUCTED pair of exactly the row's size (fl_column_pair_alloc:
+        # FL_LAYOUT_INTERLEAVED; in memory of one class every variant reads the same figure).  The library keeps the chunks between rows;
+        # one process per element type (--types): a pair's address ranges are never re-used.
+        lib.fl_internal_pair_chunk_cache(128)
+        slab_u = pl.ColumnPair(max(n * 128 * W, 256), n * 1024 * esz, dev, layout="interleaved")
+        slab_p = pl.ColumnPair(n * 1024 * esz, max(n * 128 * W, 256), dev, layout="interleaved")
+        pk8, un8, uni8, pko8 = slab_u.input[:n * 128 * W], slab_u.output, slab_p.input, slab_p.output[:n * 128 * W]
+        print(f"# u{T} W={W}: constructed pairs, measured classes (input first): decode {slab_u.classes} | encode {slab_p.classes}", flush=True)
+    else:
+        slab_u, pk8, _, un8 = pl.column_pair(n * 128 * W, n * 1024 * esz, dev)        # unpack: packed in, unpacked out
+        slab_p, uni8, _, pko8 = pl.column_pair(n * 1024 * esz, n * 128 * W, dev)      # pack: full-entropy values in (pack truncates)
     fill(pk8, 2)
     pk_in, un_out = pk8.view(tdt), un8.view(tdt)
-    slab_p, uni8, _, pko8 = pl.column_pair(n * 1024 * esz, n * 128 * W, dev)      # pack: full-entropy values in (pack truncates)
     fill(uni8, 1)
     un, pk_out = uni8.view(tdt), pko8.view(tdt)
     row = {}
@@ -63,5 +75,8 @@ for ty, W in cases:
     u, p = row["unpack"], row["pack"]
     print(f"u{T:<2d} W={W:<2d} | unpack cc {u[0]:6.0f}  wpb " + " ".join(f"{x:6.0f}" for x in u[1:]) +
           f" | pack cc {p[0]:6.0f}  wpb " + " ".join(f"{x:6.0f}" for x in p[1:]), flush=True)
-    del pk_in, pk_out, un, un_out, slab_u, slab_p, pk8, un8, uni8, pko8
+    del pk_in, pk_out, un, un_out, pk8, un8, uni8, pko8
+    if "--constructed" in sys.argv:
+        slab_u.free(); slab_p.free()
+    del slab_u, slab_p
     torch.cuda.empty_cache()

@@ -64,6 +64,7 @@ for case in cases:
                 if OP == "pack":
                     if mixed: fl.pack_widths(widths, offsets, un, col, check=False)
                     else: fl.BitPacking.pack(W, un, output=col)
+                elif OP == "undelta_pack" and mixed: fl.undelta_pack_widths(widths, offsets, col, bases, output=un, check=False)
                 elif OP == "undelta_pack": fl.Delta.undelta_pack(W, col, bases, output=un)
                 elif mixed: fl.unpack_widths(widths, offsets, col, output=un, check=False)
                 else: fl.BitPacking.unpack(W, col, output=un)
