@@ -14,7 +14,10 @@
 
 namespace fl {
 
-constexpr int WG = 256;             // 4 wavefronts; 32 blocks ("one tile") per workgroup
+#ifndef FL_WG
+#define FL_WG 256                   // (-DFL_WG=128 / 64: A/B builds only -- make WGSIZE=128 -> libfastlanes_amd_wg128.so)
+#endif
+constexpr int WG = FL_WG;           // 4 wavefronts; 32 blocks ("one tile") per workgroup
 constexpr int BLOCKS_PER_WG = WG / 8;
 
 enum UnpackBody { BODY_STORE = 0, BODY_ADD_REF = 1, BODY_UNDELTA = 2,
