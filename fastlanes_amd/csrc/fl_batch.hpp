@@ -179,7 +179,7 @@ hipError_t launch_batch_chain(const BatchArgs& b0, uint32_t max_blocks, int wave
     b.window_shift = tile_window_shift(chain_window_op<SRC, BODY, SNK>(), WaveBlock<T>::TB, TILE_BLOCKS);
     const unsigned need = TILE_BLOCKS * chain_wave_lds<T, SRC, SNK>();
     if (waves < 3) waves = 3;
-    const unsigned pad = (CU_LDS_BYTES / ((unsigned)waves * (256u / WG))) & ~1023u;
+    const unsigned pad = (CU_LDS_BYTES * (unsigned)WG / ((unsigned)waves * 256u)) & ~1023u;
     FL_LAUNCH((k_batch_chain<T, SRC, BODY, SNK>), dim3((unsigned)(b.tiles_per_xcd * 8)), dim3(WG), pad > need ? pad : need, s, b);
     return hipGetLastError();
 }

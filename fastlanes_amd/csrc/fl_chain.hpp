@@ -545,7 +545,7 @@ hipError_t launch_chain(const ChainArgs& a0, int waves, hipStream_t s)
     }
     const unsigned need = TILE_BLOCKS * chain_wave_lds<T, SRC, SNK>();
     if (waves < 3) waves = 3;
-    const unsigned pad = (CU_LDS_BYTES / ((unsigned)waves * (256u / WG))) & ~1023u;
+    const unsigned pad = (CU_LDS_BYTES * (unsigned)WG / ((unsigned)waves * 256u)) & ~1023u;
     FL_LAUNCH((k_chain<T, SRC, BODY, SNK, RD, BPW>), dim3((unsigned)(a.tiles_per_xcd * 8)), dim3(WG), pad > need ? pad : need, s, a);
     return hipGetLastError();
 }

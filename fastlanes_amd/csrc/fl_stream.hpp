@@ -65,7 +65,7 @@ inline hipError_t launch_bare_stream(BareArgs a, bool nt_loads, int waves, int w
     else a.window_shift = (unsigned)(window_log2_units - 2 < 3 ? 3 : window_log2_units - 2);       // tiles of 4 units
     if (waves < 3) waves = 3;
     if (waves > 8) waves = 8;
-    const unsigned lds = (CU_LDS_BYTES / ((unsigned)waves * (256u / WG))) & ~1023u;                                 // workgroups per CU = waves per SIMD
+    const unsigned lds = (CU_LDS_BYTES * (unsigned)WG / ((unsigned)waves * 256u)) & ~1023u;                                 // workgroups per CU = waves per SIMD
     if (nt_loads) FL_LAUNCH((k_bare_stream<true>), dim3((unsigned)(a.tiles_per_xcd * 8)), dim3(WG), lds, s, a);
     else FL_LAUNCH((k_bare_stream<false>), dim3((unsigned)(a.tiles_per_xcd * 8)), dim3(WG), lds, s, a);
     return hipGetLastError();

@@ -715,7 +715,7 @@ template <typename T> inline unsigned widths_lds_bytes(int waves, unsigned image
 {
     const unsigned need = (WG / 64) * WaveBlock<T>::BLOCK_BYTES * images_per_wave;
     if (waves < 3) waves = 3;                     // 53 KiB per workgroup: stays below the 64 KiB default dynamic-LDS limit
-    unsigned pad = (CU_LDS_BYTES / ((unsigned)waves * (256u / WG))) & ~1023u;
+    unsigned pad = (CU_LDS_BYTES * (unsigned)WG / ((unsigned)waves * 256u)) & ~1023u;
     return pad > need ? pad : need;
 }
 
