@@ -126,7 +126,10 @@ inline unsigned tile_window_shift(WindowOp op, unsigned type_bits, unsigned tile
 // ---------------------------------------------------------------------------
 // nt (2) | sc1 (16).  Round 3 re-tried 2, 3, 16, 17 and 19 on the wave-per-block kernels (separate processes, so +-3 % of
 // placement noise): none stands out against 18; plain sc1 (16) is 2 % behind.
-constexpr int STORE_AUX = 18;
+#ifndef FL_STORE_AUX
+#define FL_STORE_AUX 18             // (-DFL_STORE_AUX=n: A/B builds only -- make STOREAUX=n -> libfastlanes_amd_st<n>.so)
+#endif
+constexpr int STORE_AUX = FL_STORE_AUX;
 
 // (u8 / u16 at 4, 5 and 8 waves per SIMD measured equal or worse on the same buffers, round 3; only u8 W=1 gained.)
 template <typename T, int W> struct UnpackPolicy {
