@@ -3,6 +3,6 @@
 O=${1:-gpurun_out/r06b/sweep_allwidths_constructed.txt}
 mkdir -p $(dirname $O); : > $O
 for ty in u8 u16 u32 u64; do
-  timeout 1500 python tools/sweep.py --cases allwidths --types $ty --gb 12 --reps 5 --placement interleaved 2>&1 | grep -v amdgpu.ids >> $O
+  timeout 1500 python tools/sweep.py --cases allwidths --types $ty --gb 24 --reps 5 --placement interleaved 2>&1 | grep -v amdgpu.ids >> $O
 done
 grep "^# " $O | cut -c1-230
