@@ -963,10 +963,10 @@ struct ColumnPair {
 // Address ranges for FL_LAYOUT_INTERLEAVED.  On this ROCm (7.2) an address range that held a mapping, was unmapped and is mapped AGAIN --
 // even after hipMemAddressFree + hipMemAddressReserve -- keeps translating to the chunks it held FIRST (tools/exp_vmm remap,
 // profiles/r06_vmm_placement.txt): kernels would silently read and write memory that is no longer ours.  So no range is ever used twice
-// within a process: ranges are asked for at monotonically growing addresses of a private stretch of the address space (16 .. 80 TiB: enough for several hundred pairs -- a pair uses its own size plus its pool's, once; then hipErrorOutOfMemory), and
+// within a process: ranges are asked for at monotonically growing addresses of a private stretch of the address space (16 .. 112 TiB; a hint that collides with something mapped there just yields another address: enough for several hundred pairs -- a pair uses its own size plus its pool's, once; then hipErrorOutOfMemory), and
 // whatever the runtime returns is checked against every range this library used before.
 std::atomic<uintptr_t> g_va_next{(uintptr_t)0x100000000000ull};
-constexpr uintptr_t VA_ARENA_END = (uintptr_t)0x500000000000ull;
+constexpr uintptr_t VA_ARENA_END = (uintptr_t)0x700000000000ull;
 std::atomic_flag g_va_lock = ATOMIC_FLAG_INIT;
 std::vector<std::pair<uintptr_t, uintptr_t>> g_va_used;
 

@@ -241,6 +241,8 @@ def main():
     ap.add_argument("--gb", type=float, default=24.0)
     ap.add_argument("--reps", type=int, default=7)
     ap.add_argument("--cases", default="quick")
+    ap.add_argument("--wmin", type=int, default=0, help="keep only widths >= this")
+    ap.add_argument("--wmax", type=int, default=64, help="keep only widths <= this")
     ap.add_argument("--types", default="", help="keep only these element types of the chosen cases (allwidths with --placement interleaved: one "
                     "process per type -- a constructed pair's address ranges are never re-used within a process, 868 rows exhaust them)")
     ap.add_argument("--json", default=None)
@@ -638,6 +640,7 @@ def main():
     out = []
     if args.types:
         cases = [c for c in cases if c[1] in args.types.split(",")]
+    cases = [c for c in cases if args.wmin <= c[2] <= args.wmax]
     for op, ty, w in cases:
         r = run(op, ty, w, args.gb, args.reps)
         out.append(r)
