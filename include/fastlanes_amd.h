@@ -159,7 +159,9 @@ int fl_fill_random(void *dst, size_t n_bytes, uint64_t seed, void *stream);
  * alone reproduces.
  * (An INTERLEAVED pair's addresses are never handed out twice within a process: on this ROCm (7.2) an address range that is unmapped and
  * mapped again keeps translating to the FIRST chunks it held -- tools/exp_vmm remap -- so the library takes its ranges from a private,
- * monotonically growing part of the address space.)
+ * monotonically growing part of the address space, 16 .. 112 TiB: a pair uses its own size plus its pool's there, once, so a process can
+ * construct a few hundred large pairs; after that INTERLEAVED fails with FL_ERR_HIP (hipErrorOutOfMemory) and PROBE falls back to the plain
+ * layouts.)
  */
 enum { FL_LAYOUT_SEPARATE = 0, FL_LAYOUT_ZONED = 1, FL_LAYOUT_PROBE = 2, FL_LAYOUT_INTERLEAVED = 3, FL_LAYOUT_COUNT = 4 };
 int fl_column_pair_alloc(size_t in_bytes, size_t aux_bytes, size_t out_bytes, int layout, void *stream,
