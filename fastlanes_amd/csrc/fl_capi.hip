@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <initializer_list>
+#include <mutex>
 #include <new>
 #include <cmath>
 #include <vector>
@@ -1171,8 +1172,13 @@ bool fl_in_constructed_pair(std::initializer_list<const void*> ptrs)
     return false;
 }
 
+// (one construction at a time per process: the class probe TIMES small kernels, and two threads probing at once -- on one device or on two
+// that share nothing but this code -- would read each other's interference as class boundaries)
+std::mutex g_construct_mutex;
+
 hipError_t pair_alloc_interleaved(size_t in_bytes, size_t aux_bytes, size_t out_bytes, hipStream_t s, ColumnPair& p, int& rc)
 {
+    std::lock_guard<std::mutex> one_at_a_time(g_construct_mutex);
     rc = FL_OK;
     int dev = 0, vmm = 0;
     hipError_t e = hipGetDevice(&dev);

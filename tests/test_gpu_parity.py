@@ -1999,3 +1999,39 @@ def test_zero_copy_host_calls_under_load_never_fall_back(fl, oracle):
         stop.set()
         t.join()
     assert lib.fl_internal_zero_copy_fallbacks() == before
+
+
+@pytest.mark.gpu
+def test_two_threads_construct_pairs_at_once(fl, oracle):
+    """fl_column_pair_alloc(FL_LAYOUT_INTERLEAVED) from two host threads at the same time (the class probe times small kernels: constructions
+    are serialised inside the library); both pairs are constructed, disjoint, and decode exactly like plain tensors."""
+    import threading
+    import torch
+    from fastlanes_amd import placement as pl
+    n, W = 2_000_000, 7
+    ib, ob = n * 128 * W, n * 4096
+    g = torch.Generator(device="cuda:0").manual_seed(77)
+    pk = torch.randint(0, 1 << 31, (ib // 4,), dtype=torch.int32, device="cuda:0", generator=g).view(torch.uint32)
+    want = fl.BitPacking.unpack(W, pk)
+    pairs, errors = [None, None], []
+
+    def build(k):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                pairs[k] = pl.ColumnPair(ib, ob, "cuda:0", layout="interleaved")
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+    ts = [threading.Thread(target=build, args=(k,)) for k in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    torch.cuda.synchronize()
+    assert not errors, errors
+    a, b = pairs
+    assert a.layout == b.layout == "interleaved" and a.classes and b.classes
+    lo_a, hi_a = a.input.data_ptr(), a.output.data_ptr() + ob
+    lo_b, hi_b = b.input.data_ptr(), b.output.data_ptr() + ob
+    assert hi_a <= lo_b or hi_b <= lo_a
+    for p in pairs:
+        p.input.view(torch.uint32).copy_(pk)
+        assert torch.equal(fl.BitPacking.unpack(W, p.input.view(torch.uint32), output=p.output.view(torch.uint32)), want)
+        p.free()
