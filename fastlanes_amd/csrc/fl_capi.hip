@@ -1038,16 +1038,22 @@ void choose_chunks(const std::vector<int>& cls, size_t n_in, size_t n_out, int o
         size_t avail[4] = {by[0].size(), by[1].size(), by[2].size(), by[3].size()};
         avail[c] -= n_in;
         // cost = the mean over t of sum_k count_k^3 (8 positions: 4 + 4 + 0 costs 128, 8/3 each 57, all in one class 512) + a fee per
-        // FRACTION of the output taken from outside the rotation.  The cube and 300 for the input's own class rank the layouts as measured
-        // (unpack u32 W=7, input in A): out BC 128 (0.865) < ABC 157 (0.860) < AB 278 (0.855) < B alone 512 (0.80) < A alone 812 (0.78);
-        // with squares no fee ranks "in B | out four fifths A" behind "in A | out A and B alternating" AND keeps BC ahead of ABC.  300 is also
-        // more than the 288 / n_out a single chunk of the input's class gains by taking one of eight positions out of a 4 + 4 split.
-        double fee[4] = {0, 0, 0, 350.0};
-        bool in_rotation[3];
+        // FRACTION of the output taken from outside the rotation.  The cube and 600 for the input's own class rank the layouts as measured
+        // (unpack u32 W=7, input in A): out BC 128 (0.865) < ABC 257 (0.860) < AB 428 (0.855) < B alone 512 (0.80) < A alone 1112 (0.78);
+        // with squares no fee ranks "in B | out four fifths A" behind "in A | out A and B alternating" AND keeps BC ahead of ABC.  Below
+        // ~300 the search sprinkles chunks of the input's class into a balanced pool's output (one such chunk gains 288 / n_out by taking a
+        // position out of a 4 + 4 split): measured -0.4 % at 150, -0.0 ... -0.4 % at 300 against 1000 (profiles/r06_exp_own_class_fee.txt);
+        // above 768 "B alone" would beat "A and B alternating" where a class is missing.
+        static const double own_class_fee = [] { const char* e = getenv("FL_INTERNAL_OWN_CLASS_FEE"); return e ? atof(e) : 600.0; }();   // A/B tools
+        double fee[4] = {0, 0, 0, own_class_fee + 50.0};
+        bool in_rotation[3], plentiful = true;
         for (int k = 0; k < 3; ++k) {
             in_rotation[k] = out_classes == 3 || k != c;
-            fee[k] = in_rotation[k] ? 0.0 : 300.0;
+            if (in_rotation[k] && avail[k] * (size_t)out_classes < n_out + (size_t)out_classes - 1) plentiful = false;
         }
+        // ... where the rotation's classes cannot cover the output evenly the input's class has to help, and half the fee ranks "the scarce
+        // class + the input's class + the plentiful one, evenly" ahead of "two thirds in the plentiful class" (AB 0.855 against B alone 0.80)
+        for (int k = 0; k < 3; ++k) fee[k] = in_rotation[k] ? 0.0 : plentiful ? own_class_fee : 0.5 * own_class_fee;
         const int S[3] = {(c + 1) % 3, (c + 2) % 3, c};
         P.label.assign(n_out, 0);
         for (size_t j = 0; j < n_out; ++j) {                   // start: by the position of the chunk's centre
