@@ -1522,9 +1522,9 @@ int fl_internal_get_kernel_policy(void) { return g_kernel_policy.load(std::memor
 uint64_t fl_internal_zero_copy_fallbacks(void) { return g_zero_copy_fallbacks.load(std::memory_order_relaxed); }
 
 #ifdef FL_ALL_CELL_COLUMN
-const char* fl_version(void) { return "fastlanes_amd 0.5.0 (gfx950; wire format of spiraldb/fastlanes 0.1.8; FULL build: every cell-column instance, for A/B sweeps)"; }
+const char* fl_version(void) { return "fastlanes_amd 0.6.0 (gfx950; wire format of spiraldb/fastlanes 0.1.8; FULL build: every cell-column instance, for A/B sweeps)"; }
 #else
-const char* fl_version(void) { return "fastlanes_amd 0.5.0 (gfx950; wire format of spiraldb/fastlanes 0.1.8)"; }
+const char* fl_version(void) { return "fastlanes_amd 0.6.0 (gfx950; wire format of spiraldb/fastlanes 0.1.8)"; }
 #endif
 
 const char* fl_status_string(int status)
